@@ -1,0 +1,31 @@
+"""Pin the CPU oracle (oracle/rvt_oracle.py) against fixtures recorded from the unmodified
+reference (oracle/make_golden.py).  Runs on CPU; no GPU, no reference tree needed."""
+import pytest
+import torch
+
+from tests import casegen
+from tests.harness import compare, load_golden, oracle_run
+
+
+@pytest.mark.parametrize('name', list(casegen.CASES))
+def test_oracle_matches_reference_golden(name):
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    want = load_golden(name)
+    got = oracle_run(name, torch.float32)
+    # fp32 vs fp32, different op order (im2col einsum vs oneDNN conv, gather vs permute): 2e-4 is ample
+    compare(got, want, rtol=2e-4, what=f'oracle vs reference [{name}]', grad_rtol=5e-4)
+
+
+def test_oracle_fp64_agrees_with_fp32_reference():
+    """fp64 oracle vs fp32 reference golden: bounds the reference's own fp32 round-off."""
+    want = load_golden('micro')
+    got = oracle_run('micro', torch.float64)
+    compare(got, want, rtol=1e-4, what='fp64 oracle vs fp32 reference', grad_rtol=3e-4)
+
+
+def test_layerscale_blind_spot_is_real():
+    """with γ=1e-5 the attention/MLP path is invisible at 1e-3; with γ~U(0.5,1.5) it is not.
+    Guards the test-suite itself: the γ-randomised cases must be the ones that gate parity."""
+    a = load_golden('micro')
+    b = load_golden('micro_default_gamma')
+    assert abs(a['loss'] - b['loss']) > 1e-2
