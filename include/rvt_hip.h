@@ -1,0 +1,100 @@
+/* C ABI of librvt_hip.so — the MI355X (gfx950) kernels behind the RVT recurrent backbone.
+ *
+ * The reference (uzh-rpg/RVT) is pure PyTorch and has no FFI of its own; these entry points are the
+ * operator boundary a maintainer would bind (ctypes stub: rvt_amd/_lib.py).  Each
+ * one replaces the ATen op sequence of the cited reference lines.  Plain pointers and sizes only:
+ *   - every pointer is a DEVICE pointer unless stated otherwise;
+ *   - `dtype` selects the storage / MFMA input type of activations and weights:
+ *         RVT_F32  (0)  float   — parity mode, exact f32 MFMA
+ *         RVT_BF16 (1)  bfloat16 — performance mode
+ *     accumulators, LayerNorm/softmax statistics, the LSTM cell state `c`, biases, LayerNorm
+ *     affine parameters, LayerScale gammas and ALL gradient outputs of parameters are float32;
+ *   - activations are channels-last, token-major: X[frame][y][x][c] with frame = t*B + b;
+ *   - `stream` is a hipStream_t; calls are asynchronous, allocate nothing and are graph-capturable;
+ *   - return value 0 = ok, non-zero = error (message via rvt_last_error(), thread-local).
+ * Channel counts must be multiples of 8; dim_head a multiple of 8 and <= 32; partition size <= 96.
+ */
+#ifndef RVT_HIP_H
+#define RVT_HIP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { RVT_F32 = 0, RVT_BF16 = 1 };
+
+const char* rvt_last_error(void);
+/* 1 if this library is the CPU SIMT emulator build used by the unit tests, 0 for the gfx950 build */
+int rvt_is_emulator(void);
+
+/* Event-tensor cast + zero pad (modules/detection.py:133-134, utils/padding.py:29-44) fused with the
+ * NCHW -> channels-last repack: src [F][Cin][h][w] (uint8 if src_u8 else float32) ->
+ * dst [F][H][W][Cp] (dtype), zero padded to H>=h, W>=w, Cp>=Cin. */
+int rvt_prepack_input(const void* src, int src_u8, void* dst, int dtype, int F, int Cin, int h, int w,
+                      int H, int W, int Cp, void* stream);
+
+/* Down-sampling conv (maxvit.py:160-168,175; bias-free): in [F][H][W][Cin], w [Cout][k*k*Cin]
+ * (tap-major, cin fastest) -> out [F][Ho][Wo][Cout], Ho=(H+2*pad-k)/stride+1. */
+int rvt_conv_fwd(const void* in, const void* w, void* out, int dtype, int F, int H, int W, int Cin, int Cout,
+                 int k, int stride, int pad, void* stream);
+/* Input gradient: din[F][H][W][Cin] = conv^T(dy) (+ add).  wd = class-packed transposed weights, see
+ * rvt_conv_dgrad_weight_elems / rvt_amd.weights.pack_conv_dgrad: for each parity class (py,px) in
+ * row-major order a [Cin][nky*nkx*Cout] matrix.  `add` (nullable) has din's shape. */
+int rvt_conv_dgrad(const void* dy, const void* wd, const void* add, void* din, int dtype, int F, int H, int W,
+                   int Cin, int Cout, int k, int stride, int pad, void* stream);
+/* Weight gradient: dw[Cout][k*k*Cin] (float32) += dy^T im2col(in). */
+int rvt_conv_wgrad(const void* in, const void* dy, float* dw, int dtype, int F, int H, int W, int Cin, int Cout,
+                   int k, int stride, int pad, void* stream);
+
+/* LayerNorm over channels (maxvit.py:172,177,229,241). */
+int rvt_layernorm_fwd(const void* x, const float* w, const float* b, void* y, int dtype, int rows, int C,
+                      float eps, void* stream);
+/* dx = LN'(dy) (+ dres, nullable);  dw[C] += ..., db[C] += ... */
+int rvt_layernorm_bwd(const void* x, const float* w, const void* dy, const void* dres, void* dx, float* dw,
+                      float* db, int dtype, int rows, int C, float eps, void* stream);
+
+/* y[M][N] = f(x)[M][K] W[N][K]^T + bias (nullable);  f = exact GELU if gelu_in else identity
+ * (maxvit.py:347,353 and the MLP 100-118). */
+int rvt_linear_fwd(const void* x, const void* w, const float* bias, void* y, int dtype, int M, int N, int K,
+                   int gelu_in, void* stream);
+/* y = res + gamma * (f(x) W^T + bias)   — LayerScale + residual (maxvit.py:51-53,268-269). */
+int rvt_linear_scale_res_fwd(const void* x, const void* w, const float* bias, const float* gamma, const void* res,
+                             void* y, int dtype, int M, int N, int K, int gelu_in, void* stream);
+/* dx[M][K] = dy[M][N] Wt[K][N]^T, optionally * gelu'(pre[M][K]) (pre nullable). */
+int rvt_linear_dgrad(const void* dy, const void* wt, const void* gelu_pre, void* dx, int dtype, int M, int N, int K,
+                     void* stream);
+/* dw[N][K] (float32) += dy[M][N]^T f(x)[M][K]. */
+int rvt_linear_wgrad(const void* dy, const void* x, float* dw, int dtype, int M, int N, int K, int gelu_in,
+                     void* stream);
+/* out[N] (float32) += column sums of x[rows][N]. */
+int rvt_colsum(const void* x, float* out, int dtype, int rows, int N, void* stream);
+
+/* Partitioned multi-head attention core (maxvit.py:252-265,273-304,343-354 minus the two linears):
+ * qkv [F*H*W][3C] in image token order, per-head layout [q|k|v]; out [F*H*W][C].  window=1: ph x pw
+ * windows; window=0: dilated grid with grid size (ph,pw). */
+int rvt_attn_fwd(const void* qkv, void* out, int dtype, int F, int H, int W, int C, int dim_head, int ph, int pw,
+                 int window, void* stream);
+int rvt_attn_bwd(const void* qkv, const void* dout, void* dqkv, int dtype, int F, int H, int W, int C, int dim_head,
+                 int ph, int pw, int window, void* stream);
+
+/* ConvLSTM cell with 1x1 conv (rnn.py:52-67): mix = [x|h_prev] Wp^T + bp with gate-interleaved rows
+ * (row n' = (c/8)*32 + gate*8 + c%8, gates f,i,o,g); writes h_out [M][C], c_out [M][C] (float32) and,
+ * if gates != NULL, the activated gates [M][4C] in natural order [f|i|o|g]. */
+int rvt_lstm_fwd(const void* x, const void* h_prev, const float* c_prev, const void* w_perm, const float* b_perm,
+                 void* h_out, float* c_out, void* gates, int dtype, int M, int C, void* stream);
+/* BPTT element-wise part: consumes dh_in (+ dh_rec nullable), updates dc_rec in place, writes dz [M][4C]. */
+int rvt_lstm_gates_bwd(const void* dh_in, const void* dh_rec, float* dc_rec, const void* gates, const float* c_new,
+                       const float* c_prev, void* dz, int dtype, int M, int C, void* stream);
+/* [dx | dh_rec] = dz W : wt = W^T [2C][4C] natural gate order. */
+int rvt_lstm_dgrad(const void* dz, const void* wt, void* dx, void* dh_rec, int dtype, int M, int C, void* stream);
+/* dw[4C][2C] (float32) += dz^T [x | h_prev]. */
+int rvt_lstm_wgrad(const void* dz, const void* x, const void* h_prev, float* dw, int dtype, int M, int C, void* stream);
+
+/* Zero state rows of samples with mask[b] != 0 (modules/utils/detection.py:96-113).
+ * st is [B][per_sample] of float32 (is_f32) or `dtype`. */
+int rvt_state_reset_masked(void* st, const unsigned char* mask, int dtype, int B, size_t per_sample, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,117 @@
+"""ctypes binding of librvt_hip.so (include/rvt_hip.h) — the only compute path of this package.
+
+There is no PyTorch / CPU fallback: if the gfx950 library or a GPU is missing, every op raises.
+The unit tests may install the CPU SIMT-emulator build of the same kernel sources through
+``_install_test_library`` (tests/emu); that hook is never used by the package itself.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'librvt_hip.so')
+
+RVT_F32, RVT_BF16 = 0, 1
+_DT = {torch.float32: RVT_F32, torch.bfloat16: RVT_BF16}
+
+_lib: Optional[ctypes.CDLL] = None
+_is_emu = False
+
+_vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+_SIGS = {
+    'rvt_prepack_input': [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    'rvt_conv_fwd': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    'rvt_conv_dgrad': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    'rvt_conv_wgrad': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    'rvt_layernorm_fwd': [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
+    'rvt_layernorm_bwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
+    'rvt_linear_fwd': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    'rvt_linear_scale_res_fwd': [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    'rvt_linear_dgrad': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    'rvt_linear_wgrad': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    'rvt_colsum': [_vp, _vp, _i, _i, _i, _vp],
+    'rvt_attn_fwd': [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    'rvt_attn_bwd': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    'rvt_lstm_fwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    'rvt_lstm_gates_bwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    'rvt_lstm_dgrad': [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    'rvt_lstm_wgrad': [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    'rvt_state_reset_masked': [_vp, _vp, _i, _i, _sz, _vp],
+}
+EXPORTS = sorted(list(_SIGS) + ['rvt_last_error', 'rvt_is_emulator'])
+
+
+def _bind(lib: ctypes.CDLL) -> ctypes.CDLL:
+    for name, argtypes in _SIGS.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing -> loud
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    lib.rvt_last_error.restype = ctypes.c_char_p
+    lib.rvt_last_error.argtypes = []
+    lib.rvt_is_emulator.restype = ctypes.c_int
+    lib.rvt_is_emulator.argtypes = []
+    return lib
+
+
+def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
+    """dlopen + bind every symbol of include/rvt_hip.h (no GPU needed to *load*)."""
+    if not os.path.exists(path):
+        raise RuntimeError(f'{path} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                           f'(rvt_amd/csrc/build.sh).  rvt_amd has no fallback compute path.')
+    return _bind(ctypes.CDLL(path))
+
+
+def get_lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        lib = load_library()
+        if not torch.cuda.is_available():
+            raise RuntimeError('rvt_amd needs an AMD GPU (gfx950): torch.cuda.is_available() is False '
+                               'and there is no CPU fallback.')
+        _lib = lib
+    return _lib
+
+
+def _install_test_library(lib: Optional[ctypes.CDLL]) -> None:
+    """TEST HOOK ONLY (tests/emu): route calls to the CPU SIMT-emulator build of the kernel sources."""
+    global _lib, _is_emu
+    _lib = lib
+    _is_emu = bool(lib is not None and lib.rvt_is_emulator())
+
+
+def is_emulator() -> bool:
+    return _is_emu
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    try:
+        return _DT[dt]
+    except KeyError:
+        raise TypeError(f'rvt_amd kernels support float32 and bfloat16 activations, got {dt}') from None
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_contiguous():
+        raise ValueError('rvt_amd kernels need contiguous tensors')
+    if not (t.is_cuda or _is_emu):
+        raise RuntimeError('rvt_amd kernels need CUDA (ROCm) tensors; there is no CPU path')
+    return t.data_ptr()
+
+
+def stream_of(t: torch.Tensor) -> Optional[int]:
+    if t.is_cuda:
+        return torch.cuda.current_stream(t.device).cuda_stream
+    return None
+
+
+def call(name: str, *args) -> None:
+    lib = get_lib()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f'{name} failed: {lib.rvt_last_error().decode()}')

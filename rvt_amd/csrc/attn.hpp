@@ -1,0 +1,304 @@
+// Partitioned multi-head self-attention core (reference maxvit.py:343-354 on the partitions of
+// maxvit.py:273-304), forward and backward, one 64-lane wave per (frame, partition, head).
+//
+// The qkv activations stay in IMAGE token order [F*H*W][3C] (per-head channel layout [q|k|v], dh each —
+// reference maxvit.py:347); window / grid partitioning is pure index arithmetic on the token rows that a
+// partition gathers, so the reference's four permute().contiguous() copies per block never exist.
+//
+// MFMA formulation (L <= 96 tokens per partition, dh <= 32):
+//   S^T = K Q^T        A = K rows (keys j), B = Q rows (queries i)  -> lane owns ONE query column i,
+//                      its 16*NB accumulator registers run over keys  => softmax max/sum are in-lane
+//                      reductions plus one exchange with lane^32.
+//   O^T = V^T P^T      B = P^T straight from the accumulator registers: the MFMA pairs A's and B's
+//                      k-slots (half,e) one-to-one, so we are free to *choose* which key each slot
+//                      means; we pick the keys the lane already holds ( j = 32bj+16q+8(e>>2)+4*half+(e&3) )
+//                      and read V^T from LDS in that same order.  No register shuffles, no P round trip.
+// Backward recomputes S/P from the saved qkv (nothing but qkv and the output is ever stored):
+//   dP^T = V dO^T;  delta_i = sum_j P dP;  dS^T = P^T (dP^T - delta) * scale
+//   dQ^T = K^T dS^T (same slot trick);  dV = P^T-rows x dO,  dK = dS^T-rows x Q  (contraction over queries:
+//   P^T / dS^T take one trip through LDS to become row-major A operands).
+#pragma once
+#include "common.hpp"
+
+namespace rvt {
+
+struct AttnGeom {
+    int F, H, W, C, dh, heads, ph, pw, L, window;   // L = ph*pw
+    int nPw;        // partitions along x
+    int P;          // partitions per frame
+    float scale;
+    FastDiv dHeads, dP, dnPw, dpw;
+};
+
+// image-order token row of slot l of partition p of frame f
+__device__ __forceinline__ int attn_token(const AttnGeom& g, int f, int p, int l) {
+    uint32_t py, px, ly, lx;
+    g.dnPw.divmod((uint32_t)p, py, px);
+    g.dpw.divmod((uint32_t)l, ly, lx);
+    int y, x;
+    if (g.window) { y = py * g.ph + ly; x = px * g.pw + lx; }                  // maxvit.py:273-279
+    else { y = ly * (g.H / g.ph) + py; x = lx * (g.W / g.pw) + px; }           // maxvit.py:290-296 (dilated grid)
+    return (f * g.H + y) * g.W + x;
+}
+
+template <class T> __device__ __forceinline__ frag_t<T> load_chunk(const T* row, int chunk, int dh, bool valid) {
+    if (valid && chunk * 8 < dh) return frag_load<T>(row + chunk * 8);
+    return frag_zero<T>();
+}
+
+// write an 8-element chunk transposed: dst[(chunk*8+e)*pitch + col] = v[e]
+template <class T> __device__ __forceinline__ void store_transposed(T* dst, int pitch, int chunk, int col, const frag_t<T>& v) {
+#pragma unroll
+    for (int e = 0; e < 8; e++) dst[(chunk * 8 + e) * pitch + col] = v[e];
+}
+
+// A operand of the "slot trick": rows d = lane&31 of a transposed [32][pitch] LDS matrix, keys in slot order
+template <class T> __device__ __forceinline__ frag_t<T> load_slot_frag(const T* mt, int pitch, int li, int half, int bj, int q) {
+    const T* p = mt + li * pitch + 32 * bj + 16 * q + 4 * half;
+    frag_t<T> f;
+#pragma unroll
+    for (int e = 0; e < 4; e++) { f[e] = p[e]; f[4 + e] = p[8 + e]; }
+    return f;
+}
+
+template <class T> __device__ __forceinline__ frag_t<T> acc_slot_frag(const f32x16& a, int q) {
+    frag_t<T> f;
+#pragma unroll
+    for (int e = 0; e < 8; e++) f[e] = (T)a[8 * q + e];
+    return f;
+}
+
+// S^T column softmax for one query block; returns normalised P^T in s[][] (fp32)
+template <int NB>
+__device__ __forceinline__ void softmax_cols(f32x16 (&s)[NB], int lane, int L, float scale) {
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int bj = 0; bj < NB; bj++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            int j = 32 * bj + acc_row(r, lane);
+            if (j < L) mx = fmaxf(mx, s[bj][r]);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int bj = 0; bj < NB; bj++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            int j = 32 * bj + acc_row(r, lane);
+            float p = (j < L) ? __expf((s[bj][r] - mx) * scale) : 0.f;
+            s[bj][r] = p;
+            sum += p;
+        }
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int bj = 0; bj < NB; bj++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) s[bj][r] *= inv;
+}
+
+template <class T, int NB>
+__global__ void __launch_bounds__(64)
+attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, AttnGeom g) {
+    constexpr int LP = 32 * NB, PITCH = LP + 8;
+    __shared__ __attribute__((aligned(16))) T Vt[32 * PITCH];
+    const int lane = threadIdx.x & 63, li = lane & 31, half = lane >> 5;
+    uint32_t fp, head, f, p;
+    g.dHeads.divmod(blockIdx.x, fp, head);
+    g.dP.divmod(fp, f, p);
+    const int C3 = 3 * g.C, dh = g.dh;
+    const int qoff = head * 3 * dh, koff = qoff + dh, voff = qoff + 2 * dh;
+
+    int tok[NB]; bool valid[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        int l = 32 * b + li;
+        valid[b] = l < g.L;
+        tok[b] = attn_token(g, (int)f, (int)p, valid[b] ? l : 0);
+    }
+    // V^T -> LDS (zeros for padded keys so that 0 * garbage can never appear)
+#pragma unroll
+    for (int b = 0; b < NB; b++)
+#pragma unroll
+        for (int cc = 0; cc < 2; cc++) {
+            int chunk = half + 2 * cc;
+            frag_t<T> v = load_chunk<T>(qkv + (size_t)tok[b] * C3 + voff, chunk, dh, valid[b]);
+            store_transposed<T>(Vt, PITCH, chunk, 32 * b + li, v);
+        }
+    __syncthreads();
+
+#pragma unroll
+    for (int bi = 0; bi < NB; bi++) {
+        f32x16 s[NB];
+#pragma unroll
+        for (int bj = 0; bj < NB; bj++) acc_zero(s[bj]);
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            if (ks * 16 < dh) {
+                const int chunk = ks * 2 + half;
+                frag_t<T> qf = load_chunk<T>(qkv + (size_t)tok[bi] * C3 + qoff, chunk, dh, valid[bi]);
+#pragma unroll
+                for (int bj = 0; bj < NB; bj++) {
+                    frag_t<T> kf = load_chunk<T>(qkv + (size_t)tok[bj] * C3 + koff, chunk, dh, valid[bj]);
+                    mma32(s[bj], kf, qf);
+                }
+            }
+        }
+        softmax_cols<NB>(s, lane, g.L, g.scale);
+        f32x16 o; acc_zero(o);
+#pragma unroll
+        for (int bj = 0; bj < NB; bj++)
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+                mma32(o, load_slot_frag<T>(Vt, PITCH, li, half, bj, q), acc_slot_frag<T>(s[bj], q));
+        if (valid[bi]) {
+            T* orow = out + (size_t)tok[bi] * g.C + head * dh;
+#pragma unroll
+            for (int gq = 0; gq < 4; gq++) {
+                int d0 = 8 * gq + 4 * half;
+                if (d0 < dh) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) orow[d0 + e] = (T)o[4 * gq + e];
+                }
+            }
+        }
+    }
+}
+
+template <class T, int NB>
+__global__ void __launch_bounds__(64)
+attn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ dout, T* __restrict__ dqkv, AttnGeom g) {
+    constexpr int LP = 32 * NB, PITCH = LP + 8, PSP = 40;
+    __shared__ __attribute__((aligned(16))) T Qt[32 * PITCH];
+    __shared__ __attribute__((aligned(16))) T Kt[32 * PITCH];
+    __shared__ __attribute__((aligned(16))) T dOt[32 * PITCH];
+    __shared__ __attribute__((aligned(16))) T PS[LP * PSP];
+    const int lane = threadIdx.x & 63, li = lane & 31, half = lane >> 5;
+    uint32_t fp, head, f, p;
+    g.dHeads.divmod(blockIdx.x, fp, head);
+    g.dP.divmod(fp, f, p);
+    const int C3 = 3 * g.C, dh = g.dh;
+    const int qoff = head * 3 * dh, koff = qoff + dh, voff = qoff + 2 * dh, ooff = head * dh;
+
+    int tok[NB]; bool valid[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        int l = 32 * b + li;
+        valid[b] = l < g.L;
+        tok[b] = attn_token(g, (int)f, (int)p, valid[b] ? l : 0);
+    }
+#pragma unroll
+    for (int b = 0; b < NB; b++)
+#pragma unroll
+        for (int cc = 0; cc < 2; cc++) {
+            int chunk = half + 2 * cc;
+            const T* row = qkv + (size_t)tok[b] * C3;
+            store_transposed<T>(Qt, PITCH, chunk, 32 * b + li, load_chunk<T>(row + qoff, chunk, dh, valid[b]));
+            store_transposed<T>(Kt, PITCH, chunk, 32 * b + li, load_chunk<T>(row + koff, chunk, dh, valid[b]));
+            store_transposed<T>(dOt, PITCH, chunk, 32 * b + li,
+                                load_chunk<T>(dout + (size_t)tok[b] * g.C + ooff, chunk, dh, valid[b]));
+        }
+    __syncthreads();
+
+    f32x16 dk[NB], dv[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++) { acc_zero(dk[b]); acc_zero(dv[b]); }
+
+#pragma unroll
+    for (int bi = 0; bi < NB; bi++) {
+        f32x16 s[NB], dp[NB];
+#pragma unroll
+        for (int bj = 0; bj < NB; bj++) { acc_zero(s[bj]); acc_zero(dp[bj]); }
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            if (ks * 16 < dh) {
+                const int chunk = ks * 2 + half;
+                frag_t<T> qf = load_chunk<T>(qkv + (size_t)tok[bi] * C3 + qoff, chunk, dh, valid[bi]);
+                frag_t<T> df = load_chunk<T>(dout + (size_t)tok[bi] * g.C + ooff, chunk, dh, valid[bi]);
+#pragma unroll
+                for (int bj = 0; bj < NB; bj++) {
+                    const T* row = qkv + (size_t)tok[bj] * C3;
+                    mma32(s[bj], load_chunk<T>(row + koff, chunk, dh, valid[bj]), qf);
+                    mma32(dp[bj], load_chunk<T>(row + voff, chunk, dh, valid[bj]), df);
+                }
+            }
+        }
+        softmax_cols<NB>(s, lane, g.L, g.scale);
+        float delta = 0.f;
+#pragma unroll
+        for (int bj = 0; bj < NB; bj++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) delta += s[bj][r] * dp[bj][r];
+        delta += __shfl_xor(delta, 32);
+        // P^T -> LDS [key][query-in-block] for dV
+#pragma unroll
+        for (int bj = 0; bj < NB; bj++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) PS[(32 * bj + acc_row(r, lane)) * PSP + li] = (T)s[bj][r];
+        // dS^T (keeps the softmax scale so that dQ and dK need no further factor)
+#pragma unroll
+        for (int bj = 0; bj < NB; bj++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) dp[bj][r] = s[bj][r] * (dp[bj][r] - delta) * g.scale;
+        __syncthreads();
+#pragma unroll
+        for (int bj = 0; bj < NB; bj++)
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                frag_t<T> a = frag_load<T>(PS + (32 * bj + li) * PSP + ks * 16 + half * 8);
+                frag_t<T> b = frag_load<T>(dOt + li * PITCH + 32 * bi + ks * 16 + half * 8);
+                mma32(dv[bj], a, b);
+            }
+        __syncthreads();
+#pragma unroll
+        for (int bj = 0; bj < NB; bj++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) PS[(32 * bj + acc_row(r, lane)) * PSP + li] = (T)dp[bj][r];
+        __syncthreads();
+#pragma unroll
+        for (int bj = 0; bj < NB; bj++)
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                frag_t<T> a = frag_load<T>(PS + (32 * bj + li) * PSP + ks * 16 + half * 8);
+                frag_t<T> b = frag_load<T>(Qt + li * PITCH + 32 * bi + ks * 16 + half * 8);
+                mma32(dk[bj], a, b);
+            }
+        // dQ^T[d][i] = sum_j K^T[d][j] dS^T[j][i]   (slot trick, dS^T from registers)
+        f32x16 dq; acc_zero(dq);
+#pragma unroll
+        for (int bj = 0; bj < NB; bj++)
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+                mma32(dq, load_slot_frag<T>(Kt, PITCH, li, half, bj, q), acc_slot_frag<T>(dp[bj], q));
+        if (valid[bi]) {
+            T* qrow = dqkv + (size_t)tok[bi] * C3 + qoff;
+#pragma unroll
+            for (int gq = 0; gq < 4; gq++) {
+                int d0 = 8 * gq + 4 * half;
+                if (d0 < dh) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) qrow[d0 + e] = (T)dq[4 * gq + e];
+                }
+            }
+        }
+        __syncthreads();   // PS is rewritten by the next query block
+    }
+    // dK, dV: rows = keys, col = d = lane&31
+    // lanes of one half-wave write 32 consecutive channels of one token row
+#pragma unroll
+    for (int bj = 0; bj < NB; bj++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            int j = 32 * bj + acc_row(r, lane);
+            // token of key j: recompute (tok[] is indexed by this lane's own li)
+            if (j < g.L && li < dh) {
+                int t = attn_token(g, (int)f, (int)p, j);
+                T* row = dqkv + (size_t)t * C3;
+                row[koff + li] = (T)dk[bj][r];
+                row[voff + li] = (T)dv[bj][r];
+            }
+        }
+}
+
+}  // namespace rvt

@@ -1,0 +1,373 @@
+// extern "C" entry points of librvt_hip.so (declared in include/rvt_hip.h).
+// Host-side only: argument checks, source/epilogue descriptors, launch geometry.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <type_traits>
+
+#include "common.hpp"
+#include "gemm.hpp"
+#include "rowops.hpp"
+#include "attn.hpp"
+#include "../../include/rvt_hip.h"
+
+namespace rvt {
+static thread_local char g_err[512] = "";
+void set_last_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_last_error("%s: launch failed: %s", what, hipGetErrorString(e));
+        return 1;
+    }
+    return 0;
+}
+static inline int pow2_ge(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+static inline int imin(int a, int b) { return a < b ? a : b; }
+static inline int imax(int a, int b) { return a > b ? a : b; }
+static inline int grid_for(size_t units, int cap = 2048) {
+    size_t g = (units + 255) / 256;
+    if (g < 1) g = 1;
+    return (int)(g > (size_t)cap ? cap : g);
+}
+// split the token contraction of a weight gradient so that the launch fills the chip
+static inline int wgrad_ksplit(int out_rows, int out_cols, int tokens, int bn) {
+    int tiles = ((out_rows + 127) / 128) * ((out_cols + bn - 1) / bn);
+    int want = imax(1, 1024 / imax(1, tiles));
+    int maxs = imax(1, tokens / 512);
+    return imin(want, maxs);
+}
+}  // namespace rvt
+
+using namespace rvt;
+
+#define DISPATCH_DTYPE(dtype, ...)                                   \
+    do {                                                             \
+        if ((dtype) == RVT_F32) { typedef float T; __VA_ARGS__; }    \
+        else if ((dtype) == RVT_BF16) { typedef bf16 T; __VA_ARGS__; } \
+        else { set_last_error("bad dtype %d", (int)(dtype)); return 1; } \
+    } while (0)
+
+#define DISPATCH_BN(N, ...)                                          \
+    do {                                                             \
+        if ((N) <= 64) { constexpr int BN = 64; __VA_ARGS__; }       \
+        else { constexpr int BN = 128; __VA_ARGS__; }                \
+    } while (0)
+
+extern "C" {
+
+const char* rvt_last_error(void) { return g_err; }
+
+int rvt_is_emulator(void) {
+#ifdef RVT_EMU
+    return 1;
+#else
+    return 0;
+#endif
+}
+
+int rvt_prepack_input(const void* src, int src_u8, void* dst, int dtype, int F, int Cin, int h, int w, int H, int W,
+                      int Cp, void* stream) {
+    RVT_CHECK(Cp % 8 == 0 && Cp >= Cin && H >= h && W >= w, "prepack: bad shape Cp=%d Cin=%d", Cp, Cin);
+    hipStream_t st = (hipStream_t)stream;
+    int grid = grid_for((size_t)F * H * W, 8192);
+    DISPATCH_DTYPE(dtype, {
+        if (src_u8)
+            hipLaunchKernelGGL((prepack_kernel<T, unsigned char>), dim3(grid), dim3(256), 0, st,
+                               (const unsigned char*)src, (T*)dst, F, Cin, h, w, H, W, Cp);
+        else
+            hipLaunchKernelGGL((prepack_kernel<T, float>), dim3(grid), dim3(256), 0, st, (const float*)src, (T*)dst, F,
+                               Cin, h, w, H, W, Cp);
+    });
+    return check_launch("prepack");
+}
+
+}  // extern "C"
+template <class T>
+static Im2colSrc<T> make_im2col(const void* in, int F, int H, int W, int Cin, int k, int stride, int pad) {
+    Im2colSrc<T> s;
+    s.p = (const T*)in; s.H = H; s.W = W; s.Cin = Cin;
+    s.Ho = (H + 2 * pad - k) / stride + 1; s.Wo = (W + 2 * pad - k) / stride + 1;
+    s.kw = k; s.stride = stride; s.pad = pad;
+    s.rows = F * s.Ho * s.Wo; s.cols = k * k * Cin;
+    s.dHoWo = FastDiv(s.Ho * s.Wo); s.dWo = FastDiv(s.Wo); s.dkw = FastDiv(k); s.dCin = FastDiv(Cin);
+    return s;
+}
+extern "C" {
+// ---------------------------------------------------------------------------------------------- conv
+int rvt_conv_fwd(const void* in, const void* w, void* out, int dtype, int F, int H, int W, int Cin, int Cout, int k,
+                 int stride, int pad, void* stream) {
+    RVT_CHECK(Cin % 8 == 0 && Cout % 8 == 0, "conv_fwd: channels must be multiples of 8 (Cin=%d Cout=%d)", Cin, Cout);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_DTYPE(dtype, {
+        Im2colSrc<T> a = make_im2col<T>(in, F, H, W, Cin, k, stride, pad);
+        PlainSrc<T> b{(const T*)w, a.cols, Cout, a.cols};
+        EpStore<T> ep{(T*)out, Cout, nullptr, nullptr};
+        DISPATCH_BN(Cout, (launch_gemm<T, BN, false>(a, XfNone(), b, XfNone(), ep, a.rows, Cout, a.cols, 1, st)));
+    });
+    return check_launch("conv_fwd");
+}
+
+int rvt_conv_wgrad(const void* in, const void* dy, float* dw, int dtype, int F, int H, int W, int Cin, int Cout, int k,
+                   int stride, int pad, void* stream) {
+    RVT_CHECK(Cin % 8 == 0 && Cout % 8 == 0, "conv_wgrad: channels must be multiples of 8");
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_DTYPE(dtype, {
+        Im2colSrc<T> b = make_im2col<T>(in, F, H, W, Cin, k, stride, pad);
+        PlainSrc<T> a{(const T*)dy, Cout, b.rows, Cout};
+        EpAtomicF32 ep{dw, b.cols};
+        DISPATCH_BN(b.cols, (launch_gemm<T, BN, true>(a, XfNone(), b, XfNone(), ep, Cout, b.cols, b.rows,
+                                                      wgrad_ksplit(Cout, b.cols, b.rows, BN), st)));
+    });
+    return check_launch("conv_wgrad");
+}
+
+int rvt_conv_dgrad(const void* dy, const void* wd, const void* add, void* din, int dtype, int F, int H, int W, int Cin,
+                   int Cout, int k, int stride, int pad, void* stream) {
+    RVT_CHECK(Cin % 8 == 0 && Cout % 8 == 0, "conv_dgrad: channels must be multiples of 8");
+    RVT_CHECK(stride >= 1 && stride <= 4 && k <= 4 * stride, "conv_dgrad: unsupported k=%d stride=%d", k, stride);
+    hipStream_t st = (hipStream_t)stream;
+    const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+    DISPATCH_DTYPE(dtype, {
+        size_t woff = 0;
+        for (int py = 0; py < stride; py++)
+            for (int px = 0; px < stride; px++) {
+                DgradSrc<T> a;
+                a.dy = (const T*)dy; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
+                a.s = stride; a.pad = pad; a.py = py; a.px = px;
+                a.Hc = (H - py + stride - 1) / stride; a.Wc = (W - px + stride - 1) / stride;
+                a.nky = 0; a.nkx = 0;
+                for (int t = 0; t < k; t++) {
+                    if (t % stride == (py + pad) % stride) a.ky[a.nky++] = t;
+                    if (t % stride == (px + pad) % stride) a.kx[a.nkx++] = t;
+                }
+                if (a.Hc <= 0 || a.Wc <= 0) continue;
+                a.rows = F * a.Hc * a.Wc; a.cols = a.nky * a.nkx * Cout;
+                a.dHcWc = FastDiv(a.Hc * a.Wc); a.dWc = FastDiv(a.Wc); a.dCout = FastDiv(Cout);
+                PlainSrc<T> b{(const T*)wd + woff, a.cols, Cin, a.cols};
+                EpDgradScatter<T> ep{(T*)din, (const T*)add, H, W, Cin, stride, py, px, a.dHcWc, a.dWc};
+                DISPATCH_BN(Cin, (launch_gemm<T, BN, false>(a, XfNone(), b, XfNone(), ep, a.rows, Cin, a.cols, 1, st)));
+                woff += (size_t)Cin * a.cols;
+            }
+    });
+    return check_launch("conv_dgrad");
+}
+
+// ----------------------------------------------------------------------------------------- layernorm
+int rvt_layernorm_fwd(const void* x, const float* w, const float* b, void* y, int dtype, int rows, int C, float eps,
+                      void* stream) {
+    RVT_CHECK(C % 8 == 0 && C <= 512, "layernorm: C=%d must be a multiple of 8 and <= 512", C);
+    hipStream_t st = (hipStream_t)stream;
+    int G = pow2_ge(C / 8);
+    int rows_per_block = 4 * (64 / G);
+    int grid = imin(4096, imax(1, (rows + rows_per_block - 1) / rows_per_block));
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ln_fwd_kernel<T>), dim3(grid), dim3(256), 0, st, (const T*)x, w, b, (T*)y,
+                                             rows, C, G, eps));
+    return check_launch("layernorm_fwd");
+}
+
+int rvt_layernorm_bwd(const void* x, const float* w, const void* dy, const void* dres, void* dx, float* dw, float* db,
+                      int dtype, int rows, int C, float eps, void* stream) {
+    RVT_CHECK(C % 8 == 0 && C <= 512, "layernorm: C=%d must be a multiple of 8 and <= 512", C);
+    hipStream_t st = (hipStream_t)stream;
+    int G = pow2_ge(C / 8);
+    int rows_per_block = 4 * (64 / G);
+    int grid = imin(1024, imax(1, (rows + rows_per_block - 1) / rows_per_block));
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ln_bwd_kernel<T>), dim3(grid), dim3(256), 0, st, (const T*)x, w,
+                                             (const T*)dy, (const T*)dres, (T*)dx, dw, db, rows, C, G, eps));
+    return check_launch("layernorm_bwd");
+}
+
+int rvt_colsum(const void* x, float* out, int dtype, int rows, int N, void* stream) {
+    RVT_CHECK(N % 8 == 0, "colsum: N=%d must be a multiple of 8", N);
+    hipStream_t st = (hipStream_t)stream;
+    int NC = N / 8;
+    int NCP = imin(256, pow2_ge(NC));
+    int gy = (NC + NCP - 1) / NCP;
+    int nrl = 256 / NCP;
+    int gx = imin(1024, imax(1, (rows + nrl * 8 - 1) / (nrl * 8)));
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((colsum_kernel<T>), dim3(gx, gy), dim3(256), 0, st, (const T*)x, out, rows,
+                                             N, NCP));
+    return check_launch("colsum");
+}
+
+// -------------------------------------------------------------------------------------------- linear
+int rvt_linear_fwd(const void* x, const void* w, const float* bias, void* y, int dtype, int M, int N, int K, int gelu_in,
+                   void* stream) {
+    RVT_CHECK(N % 8 == 0 && K % 8 == 0, "linear_fwd: N=%d K=%d must be multiples of 8", N, K);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_DTYPE(dtype, {
+        PlainSrc<T> a{(const T*)x, K, M, K};
+        PlainSrc<T> b{(const T*)w, K, N, K};
+        EpStore<T> ep{(T*)y, N, bias, nullptr};
+        DISPATCH_BN(N, {
+            if (gelu_in) launch_gemm<T, BN, false>(a, XfGelu(), b, XfNone(), ep, M, N, K, 1, st);
+            else launch_gemm<T, BN, false>(a, XfNone(), b, XfNone(), ep, M, N, K, 1, st);
+        });
+    });
+    return check_launch("linear_fwd");
+}
+
+int rvt_linear_scale_res_fwd(const void* x, const void* w, const float* bias, const float* gamma, const void* res,
+                             void* y, int dtype, int M, int N, int K, int gelu_in, void* stream) {
+    RVT_CHECK(N % 8 == 0 && K % 8 == 0, "linear_scale_res_fwd: N=%d K=%d must be multiples of 8", N, K);
+    RVT_CHECK(bias && gamma && res, "linear_scale_res_fwd: bias, gamma and res are required");
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_DTYPE(dtype, {
+        PlainSrc<T> a{(const T*)x, K, M, K};
+        PlainSrc<T> b{(const T*)w, K, N, K};
+        EpScaleRes<T> ep{(T*)y, (const T*)res, N, bias, gamma};
+        DISPATCH_BN(N, {
+            if (gelu_in) launch_gemm<T, BN, false>(a, XfGelu(), b, XfNone(), ep, M, N, K, 1, st);
+            else launch_gemm<T, BN, false>(a, XfNone(), b, XfNone(), ep, M, N, K, 1, st);
+        });
+    });
+    return check_launch("linear_scale_res_fwd");
+}
+
+int rvt_linear_dgrad(const void* dy, const void* wt, const void* gelu_pre, void* dx, int dtype, int M, int N, int K,
+                     void* stream) {
+    RVT_CHECK(N % 8 == 0 && K % 8 == 0, "linear_dgrad: N=%d K=%d must be multiples of 8", N, K);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_DTYPE(dtype, {
+        PlainSrc<T> a{(const T*)dy, N, M, N};
+        PlainSrc<T> b{(const T*)wt, N, K, N};
+        DISPATCH_BN(K, {
+            if (gelu_pre) {
+                EpGeluBwd<T> ep{(T*)dx, (const T*)gelu_pre, K};
+                launch_gemm<T, BN, false>(a, XfNone(), b, XfNone(), ep, M, K, N, 1, st);
+            } else {
+                EpStore<T> ep{(T*)dx, K, nullptr, nullptr};
+                launch_gemm<T, BN, false>(a, XfNone(), b, XfNone(), ep, M, K, N, 1, st);
+            }
+        });
+    });
+    return check_launch("linear_dgrad");
+}
+
+int rvt_linear_wgrad(const void* dy, const void* x, float* dw, int dtype, int M, int N, int K, int gelu_in,
+                     void* stream) {
+    RVT_CHECK(N % 8 == 0 && K % 8 == 0, "linear_wgrad: N=%d K=%d must be multiples of 8", N, K);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_DTYPE(dtype, {
+        PlainSrc<T> a{(const T*)dy, N, M, N};
+        PlainSrc<T> b{(const T*)x, K, M, K};
+        EpAtomicF32 ep{dw, K};
+        DISPATCH_BN(K, {
+            int ks = wgrad_ksplit(N, K, M, BN);
+            if (gelu_in) launch_gemm<T, BN, true>(a, XfNone(), b, XfGelu(), ep, N, K, M, ks, st);
+            else launch_gemm<T, BN, true>(a, XfNone(), b, XfNone(), ep, N, K, M, ks, st);
+        });
+    });
+    return check_launch("linear_wgrad");
+}
+
+// ----------------------------------------------------------------------------------------- attention
+static int make_attn_geom(AttnGeom& g, int F, int H, int W, int C, int dh, int ph, int pw, int window) {
+    RVT_CHECK(C % 8 == 0 && dh % 8 == 0 && dh <= 32 && C % dh == 0, "attn: bad C=%d dim_head=%d", C, dh);
+    RVT_CHECK(H % ph == 0 && W % pw == 0, "attn: %dx%d not divisible by partition %dx%d", H, W, ph, pw);
+    RVT_CHECK(ph * pw <= 96, "attn: partition of %d tokens > 96 unsupported", ph * pw);
+    g.F = F; g.H = H; g.W = W; g.C = C; g.dh = dh; g.heads = C / dh; g.ph = ph; g.pw = pw; g.L = ph * pw;
+    g.window = window;
+    g.nPw = W / pw; g.P = (H / ph) * (W / pw);
+    g.scale = 1.0f / sqrtf((float)dh);
+    g.dHeads = FastDiv(g.heads); g.dP = FastDiv(g.P); g.dnPw = FastDiv(g.nPw); g.dpw = FastDiv(pw);
+    return 0;
+}
+
+int rvt_attn_fwd(const void* qkv, void* out, int dtype, int F, int H, int W, int C, int dim_head, int ph, int pw,
+                 int window, void* stream) {
+    AttnGeom g;
+    if (make_attn_geom(g, F, H, W, C, dim_head, ph, pw, window)) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)(F * g.P * g.heads));
+    int NB = (g.L + 31) / 32;
+    DISPATCH_DTYPE(dtype, {
+        if (NB == 1) hipLaunchKernelGGL((attn_fwd_kernel<T, 1>), grid, dim3(64), 0, st, (const T*)qkv, (T*)out, g);
+        else if (NB == 2) hipLaunchKernelGGL((attn_fwd_kernel<T, 2>), grid, dim3(64), 0, st, (const T*)qkv, (T*)out, g);
+        else hipLaunchKernelGGL((attn_fwd_kernel<T, 3>), grid, dim3(64), 0, st, (const T*)qkv, (T*)out, g);
+    });
+    return check_launch("attn_fwd");
+}
+
+int rvt_attn_bwd(const void* qkv, const void* dout, void* dqkv, int dtype, int F, int H, int W, int C, int dim_head,
+                 int ph, int pw, int window, void* stream) {
+    AttnGeom g;
+    if (make_attn_geom(g, F, H, W, C, dim_head, ph, pw, window)) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)(F * g.P * g.heads));
+    int NB = (g.L + 31) / 32;
+    DISPATCH_DTYPE(dtype, {
+        if (NB == 1)
+            hipLaunchKernelGGL((attn_bwd_kernel<T, 1>), grid, dim3(64), 0, st, (const T*)qkv, (const T*)dout, (T*)dqkv, g);
+        else if (NB == 2)
+            hipLaunchKernelGGL((attn_bwd_kernel<T, 2>), grid, dim3(64), 0, st, (const T*)qkv, (const T*)dout, (T*)dqkv, g);
+        else
+            hipLaunchKernelGGL((attn_bwd_kernel<T, 3>), grid, dim3(64), 0, st, (const T*)qkv, (const T*)dout, (T*)dqkv, g);
+    });
+    return check_launch("attn_bwd");
+}
+
+// ---------------------------------------------------------------------------------------------- lstm
+int rvt_lstm_fwd(const void* x, const void* h_prev, const float* c_prev, const void* w_perm, const float* b_perm,
+                 void* h_out, float* c_out, void* gates, int dtype, int M, int C, void* stream) {
+    RVT_CHECK(C % 8 == 0, "lstm_fwd: C=%d must be a multiple of 8", C);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_DTYPE(dtype, {
+        ConcatSrc<T> a{(const T*)x, (const T*)h_prev, C, M, 2 * C};
+        PlainSrc<T> b{(const T*)w_perm, 2 * C, 4 * C, 2 * C};
+        EpLstm<T> ep{b_perm, c_prev, c_out, (T*)h_out, (T*)gates, C};
+        DISPATCH_BN(4 * C, (launch_gemm<T, BN, false>(a, XfNone(), b, XfNone(), ep, M, 4 * C, 2 * C, 1, st)));
+    });
+    return check_launch("lstm_fwd");
+}
+
+int rvt_lstm_gates_bwd(const void* dh_in, const void* dh_rec, float* dc_rec, const void* gates, const float* c_new,
+                       const float* c_prev, void* dz, int dtype, int M, int C, void* stream) {
+    RVT_CHECK(C % 8 == 0, "lstm_gates_bwd: C=%d must be a multiple of 8", C);
+    hipStream_t st = (hipStream_t)stream;
+    int grid = grid_for((size_t)M * (C / 8), 4096);
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((lstm_gates_bwd_kernel<T>), dim3(grid), dim3(256), 0, st, (const T*)dh_in,
+                                             (const T*)dh_rec, dc_rec, (const T*)gates, c_new, c_prev, (T*)dz, M, C));
+    return check_launch("lstm_gates_bwd");
+}
+
+int rvt_lstm_dgrad(const void* dz, const void* wt, void* dx, void* dh_rec, int dtype, int M, int C, void* stream) {
+    RVT_CHECK(C % 8 == 0, "lstm_dgrad: C=%d must be a multiple of 8", C);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_DTYPE(dtype, {
+        PlainSrc<T> a{(const T*)dz, 4 * C, M, 4 * C};
+        PlainSrc<T> b{(const T*)wt, 4 * C, 2 * C, 4 * C};
+        EpSplit2<T> ep{(T*)dx, (T*)dh_rec, C};
+        DISPATCH_BN(2 * C, (launch_gemm<T, BN, false>(a, XfNone(), b, XfNone(), ep, M, 2 * C, 4 * C, 1, st)));
+    });
+    return check_launch("lstm_dgrad");
+}
+
+int rvt_lstm_wgrad(const void* dz, const void* x, const void* h_prev, float* dw, int dtype, int M, int C, void* stream) {
+    RVT_CHECK(C % 8 == 0, "lstm_wgrad: C=%d must be a multiple of 8", C);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_DTYPE(dtype, {
+        PlainSrc<T> a{(const T*)dz, 4 * C, M, 4 * C};
+        ConcatSrc<T> b{(const T*)x, (const T*)h_prev, C, M, 2 * C};
+        EpAtomicF32 ep{dw, 2 * C};
+        DISPATCH_BN(2 * C, (launch_gemm<T, BN, true>(a, XfNone(), b, XfNone(), ep, 4 * C, 2 * C, M,
+                                                     wgrad_ksplit(4 * C, 2 * C, M, BN), st)));
+    });
+    return check_launch("lstm_wgrad");
+}
+
+int rvt_state_reset_masked(void* st_, const unsigned char* mask, int dtype, int B, size_t per_sample, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    int grid = grid_for((size_t)B * per_sample, 4096);
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((state_reset_kernel<T>), dim3(grid), dim3(256), 0, st, (T*)st_, mask, B,
+                                             per_sample));
+    return check_launch("state_reset_masked");
+}
+
+}  // extern "C"

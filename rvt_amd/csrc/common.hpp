@@ -1,0 +1,160 @@
+// Common device/host helpers for the MI355X (gfx950) RVT backbone kernels.
+//
+// Conventions used by every kernel in this directory
+//   * wavefront = 64 lanes; all workgroups are 256 threads (4 waves) unless stated otherwise.
+//   * activations are token-major ("channels last"): X[frame][y][x][c], frame = t*B + b.
+//   * T is the storage/MFMA-input type: __bf16 (performance mode) or float (parity mode, exact
+//     f32 MFMA v_mfma_f32_32x32x2_f32).  Accumulation, LayerNorm/softmax statistics, the LSTM
+//     cell state and all parameter gradients are always fp32.
+//   * a "frag" is 8 consecutive K elements of one row: the per-lane A/B operand of one
+//     v_mfma_f32_32x32x16_bf16, or of eight v_mfma_f32_32x32x2_f32 (lane l supplies row l&31,
+//     k-slots 8*(l>>5)+0..7 — A and B use the same slot order, so the pairing is exact).
+//   * C/D layout of a 32x32 MFMA block: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5), r in [0,16).
+#pragma once
+#ifndef RVT_EMU
+#include <hip/hip_runtime.h>
+#endif
+#include <stdint.h>
+#include <stddef.h>
+
+namespace rvt {
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) float f32x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+template <class T> struct Frag;
+template <> struct Frag<float> { typedef f32x8 type; };
+template <> struct Frag<bf16> { typedef bf16x8 type; };
+template <class T> using frag_t = typename Frag<T>::type;
+
+template <class T> __device__ __forceinline__ frag_t<T> frag_zero() {
+    frag_t<T> z;
+#pragma unroll
+    for (int i = 0; i < 8; i++) z[i] = (T)0.0f;
+    return z;
+}
+template <class T> __device__ __forceinline__ frag_t<T> frag_load(const T* p) {
+    return *reinterpret_cast<const frag_t<T>*>(p);
+}
+template <class T> __device__ __forceinline__ void frag_store(T* p, const frag_t<T>& v) {
+    *reinterpret_cast<frag_t<T>*>(p) = v;
+}
+template <class T> __device__ __forceinline__ void frag_to_float(const frag_t<T>& f, float (&v)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = (float)f[i];
+}
+template <class T> __device__ __forceinline__ frag_t<T> frag_from_float(const float (&v)[8]) {
+    frag_t<T> f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) f[i] = (T)v[i];
+    return f;
+}
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// ---- MFMA: one 32x32 output block, K = 16 ------------------------------------------------------
+#ifndef RVT_EMU
+__device__ __forceinline__ void mma32(f32x16& c, const bf16x8& a, const bf16x8& b) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ void mma32(f32x16& c, const f32x8& a, const f32x8& b) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], c, 0, 0, 0);
+}
+#else
+template <class F> inline void mma32_emu(f32x16& c, const F& a, const F& b) {
+    float ab[16];
+    for (int j = 0; j < 8; j++) { ab[j] = (float)a[j]; ab[8 + j] = (float)b[j]; }
+    auto buf = emu::exchange(ab, sizeof(ab));
+    int lane = emu::g.cur->lane, col = lane & 31;
+    for (int r = 0; r < 16; r++) {
+        int row = acc_row(r, lane);
+        float s = c[r];
+        for (int h = 0; h < 2; h++) {
+            const float* pa = reinterpret_cast<const float*>(buf[row + 32 * h]);
+            const float* pb = reinterpret_cast<const float*>(buf[col + 32 * h]) + 8;
+            for (int e = 0; e < 8; e++) s += pa[e] * pb[e];
+        }
+        c[r] = s;
+    }
+}
+inline void mma32(f32x16& c, const bf16x8& a, const bf16x8& b) { mma32_emu(c, a, b); }
+inline void mma32(f32x16& c, const f32x8& a, const f32x8& b) { mma32_emu(c, a, b); }
+#endif
+
+__device__ __forceinline__ void acc_zero(f32x16& c) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) c[i] = 0.0f;
+}
+
+// ---- exact division by a runtime constant ------------------------------------------------------
+struct FastDiv {
+    uint32_t d, m, s;
+    FastDiv() : d(1), m(1), s(0) {}
+    explicit FastDiv(uint32_t d_) : d(d_) {
+        s = 0;
+        while ((1ull << s) < d) s++;
+        m = (uint32_t)(((1ull << 32) * ((1ull << s) - d)) / d + 1);
+    }
+    __device__ __forceinline__ uint32_t div(uint32_t n) const { return (__umulhi(n, m) + n) >> s; }
+    __device__ __forceinline__ void divmod(uint32_t n, uint32_t& q, uint32_t& r) const { q = div(n); r = n - q * d; }
+};
+
+// ---- swizzled LDS tile of [rows][128 bytes] ------------------------------------------------------
+// Every GEMM operand tile row is 128 bytes (64 bf16 or 32 f32) = 8 chunks of 16 B.  A wave's
+// ds_read_b128 of one logical chunk from 32 different rows would hit two 16-B slots of the 256-B
+// bank row (8-way); XOR-ing the chunk index with (row>>1)&7 spreads each 16-lane read group over all
+// 16 slots (MI355X guide: LDS banks for b128 = (addr/4)%64, 16-lane groups).
+__device__ __forceinline__ int lds_chunk_off(int row, int chunk16) {
+    return row * 128 + ((chunk16 ^ ((row >> 1) & 7)) << 4);
+}
+template <class T> struct TileGeom;
+template <> struct TileGeom<bf16> { static constexpr int BK = 64, FPR = 8, CPF = 1; };   // frags/row, 16B-chunks/frag
+template <> struct TileGeom<float> { static constexpr int BK = 32, FPR = 4, CPF = 2; };
+
+template <class T> __device__ __forceinline__ void tile_store_frag(char* tile, int row, int fc, const frag_t<T>& v) {
+    const u32x4* src = reinterpret_cast<const u32x4*>(&v);
+#pragma unroll
+    for (int c = 0; c < TileGeom<T>::CPF; c++)
+        *reinterpret_cast<u32x4*>(tile + lds_chunk_off(row, fc * TileGeom<T>::CPF + c)) = src[c];
+}
+template <class T> __device__ __forceinline__ frag_t<T> tile_load_frag(const char* tile, int row, int fc) {
+    frag_t<T> v;
+    u32x4* dst = reinterpret_cast<u32x4*>(&v);
+#pragma unroll
+    for (int c = 0; c < TileGeom<T>::CPF; c++)
+        dst[c] = *reinterpret_cast<const u32x4*>(tile + lds_chunk_off(row, fc * TileGeom<T>::CPF + c));
+    return v;
+}
+
+// ---- scalar math -------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_f(float x) {
+    // tanh via exp; exact to ~1e-7 relative, saturates correctly
+    float ax = fabsf(x);
+    float e = __expf(-2.0f * ax);
+    float t = (1.0f - e) / (1.0f + e);
+    return x < 0.0f ? -t : t;
+}
+
+// ---- error plumbing for the C ABI ------------------------------------------------------------------
+void set_last_error(const char* fmt, ...);
+#define RVT_CHECK(cond, ...)                      \
+    do {                                          \
+        if (!(cond)) {                            \
+            ::rvt::set_last_error(__VA_ARGS__);   \
+            return 1;                             \
+        }                                         \
+    } while (0)
+int check_launch(const char* what);
+
+}  // namespace rvt

@@ -1,0 +1,439 @@
+// One MFMA GEMM engine for every contraction on the RVT hot path.
+//
+//   D[m][n] (+)= sum_k A[m][k] * B[n][k]          (both operands addressed "row, k")
+//
+// Operands are *sources*: objects that map (row, column-segment) to a pointer to 8+ contiguous
+// elements, or nullptr for padding.  That one abstraction covers
+//   PlainSrc   row-major matrices (linear layers, weights),
+//   ConcatSrc  [x_t | h_{t-1}] of the ConvLSTM 1x1 conv (reference rnn.py:52,55) without a cat copy,
+//   Im2colSrc  the strided overlapping conv of the down-sampling stem (reference maxvit.py:160-168),
+//   DgradSrc   its input-gradient gather for one stride-parity class of input pixels.
+// Two loaders stage a 128-row x 128-byte tile into swizzled LDS:
+//   NT: the contraction index is the source's column (contiguous) -> 16/32-byte vector loads;
+//   TN: the contraction index is the source's ROW (token)  -> 4-byte loads from 8 consecutive
+//       tokens, transposed in registers (weight gradients: dW = dY^T X, contraction over tokens).
+// Results leave through an LDS-staged epilogue that hands 8 (or 32) consecutive columns of one row
+// to an epilogue functor (bias / GELU' / LayerScale+residual / LSTM gates / fp32 atomics for split-K).
+//
+// Tile: 128 x BN (BN = 64 or 128) per 256-thread workgroup, 4 waves as 2x2, each wave
+// (64 x BN/2) = 2 x (BN/64) MFMA 32x32 blocks; K tile = 128 bytes (64 bf16 / 32 f32), register-staged
+// double buffering (global->VGPR for tile k+1 is issued before the MFMAs of tile k).
+#pragma once
+#include "common.hpp"
+
+namespace rvt {
+
+// ------------------------------------------------------------------------------------------------
+// sources
+// ------------------------------------------------------------------------------------------------
+template <class T> struct PlainSrc {
+    const T* p; int ld; int rows; int cols;
+    typedef const T* Ctx;
+    __device__ __forceinline__ Ctx row_ctx(int m) const { return (m >= 0 && m < rows) ? p + (size_t)m * ld : nullptr; }
+    __device__ __forceinline__ void split(int kcol, int& seg, int& off) const { seg = 0; off = kcol; }
+    __device__ __forceinline__ const T* seg_ptr(const Ctx& c, int) const { return c; }
+};
+
+template <class T> struct ConcatSrc {   // [x | h], both [rows][C]
+    const T* x; const T* h; int C; int rows; int cols;  // cols = 2C
+    typedef int Ctx;
+    __device__ __forceinline__ Ctx row_ctx(int m) const { return (m >= 0 && m < rows) ? m : -1; }
+    __device__ __forceinline__ void split(int kcol, int& seg, int& off) const { seg = kcol >= C; off = kcol - seg * C; }
+    __device__ __forceinline__ const T* seg_ptr(const Ctx& c, int seg) const {
+        return c < 0 ? nullptr : (seg ? h : x) + (size_t)c * C;
+    }
+};
+
+// rows = output pixels (frame, oy, ox); columns = (ky, kx, cin) with cin fastest; input is [F][H][W][Cin]
+template <class T> struct Im2colSrc {
+    const T* p; int H, W, Cin, Ho, Wo, kw, stride, pad; int rows; int cols;  // cols = kh*kw*Cin
+    FastDiv dHoWo, dWo, dkw, dCin;
+    struct Ctx { int base; int iy0; int ix0; };
+    __device__ __forceinline__ Ctx row_ctx(int m) const {
+        Ctx c;
+        if (m < 0 || m >= rows) { c.base = -1; c.iy0 = 0; c.ix0 = 0; return c; }
+        uint32_t f, rem, oy, ox;
+        dHoWo.divmod((uint32_t)m, f, rem);
+        dWo.divmod(rem, oy, ox);
+        c.base = (int)f * H * W; c.iy0 = (int)oy * stride - pad; c.ix0 = (int)ox * stride - pad;
+        return c;
+    }
+    __device__ __forceinline__ void split(int kcol, int& seg, int& off) const {
+        uint32_t q, r; dCin.divmod((uint32_t)kcol, q, r); seg = (int)q; off = (int)r;
+    }
+    __device__ __forceinline__ const T* seg_ptr(const Ctx& c, int seg) const {
+        if (c.base < 0) return nullptr;
+        uint32_t ky, kx; dkw.divmod((uint32_t)seg, ky, kx);
+        int iy = c.iy0 + (int)ky, ix = c.ix0 + (int)kx;
+        if (iy < 0 || iy >= H || ix < 0 || ix >= W) return nullptr;
+        return p + ((size_t)c.base + (size_t)iy * W + ix) * Cin;
+    }
+};
+
+// Input-gradient gather of a strided conv for ONE parity class (py,px) of input pixels
+// y = s*yy+py, x = s*xx+px.  Only the taps ky ≡ (py+pad) mod s contribute:  oy = (y+pad-ky)/s.
+// rows = (frame, yy, xx) over the class; columns = (a, b, cout) over the class's taps Ky[a], Kx[b].
+template <class T> struct DgradSrc {
+    const T* dy; int Ho, Wo, Cout; int Hc, Wc;     // class extent
+    int s, pad, py, px; int nky, nkx; int ky[4], kx[4];
+    int rows; int cols;                             // cols = nky*nkx*Cout
+    FastDiv dHcWc, dWc, dCout;
+    struct Ctx { int f; int y; int x; };
+    __device__ __forceinline__ Ctx row_ctx(int m) const {
+        Ctx c;
+        if (m < 0 || m >= rows) { c.f = -1; c.y = 0; c.x = 0; return c; }
+        uint32_t f, rem, yy, xx;
+        dHcWc.divmod((uint32_t)m, f, rem);
+        dWc.divmod(rem, yy, xx);
+        c.f = (int)f; c.y = (int)yy * s + py; c.x = (int)xx * s + px;
+        return c;
+    }
+    __device__ __forceinline__ void split(int kcol, int& seg, int& off) const {
+        uint32_t q, r; dCout.divmod((uint32_t)kcol, q, r); seg = (int)q; off = (int)r;
+    }
+    __device__ __forceinline__ const T* seg_ptr(const Ctx& c, int seg) const {
+        if (c.f < 0) return nullptr;
+        int a = seg / nkx, b = seg - a * nkx;
+        int ny = c.y + pad - ky[a], nx = c.x + pad - kx[b];
+        if (ny < 0 || nx < 0) return nullptr;
+        int oy = ny / s, ox = nx / s;
+        if (oy >= Ho || ox >= Wo) return nullptr;
+        return dy + (((size_t)c.f * Ho + oy) * Wo + ox) * Cout;
+    }
+};
+
+// element-wise transforms applied to loaded operand values
+struct XfNone { __device__ __forceinline__ float operator()(float v) const { return v; } static constexpr bool identity = true; };
+struct XfGelu { __device__ __forceinline__ float operator()(float v) const { return gelu_f(v); } static constexpr bool identity = false; };
+
+template <class T, class Xf> __device__ __forceinline__ frag_t<T> xf_apply(const frag_t<T>& f, const Xf& xf) {
+    if (Xf::identity) return f;
+    frag_t<T> o;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o[i] = (T)xf((float)f[i]);
+    return o;
+}
+
+// ------------------------------------------------------------------------------------------------
+// tile loaders (global -> registers -> swizzled LDS)
+// ------------------------------------------------------------------------------------------------
+template <class T, int ROWS, class Src, class Xf> struct NTLoader {
+    static constexpr int FPR = TileGeom<T>::FPR;
+    static constexpr int NF = ROWS * FPR / 256;
+    typename Src::Ctx ctx[NF];
+    frag_t<T> r[NF];
+    __device__ __forceinline__ void init(const Src& s, int row0, int tid) {
+#pragma unroll
+        for (int i = 0; i < NF; i++) ctx[i] = s.row_ctx(row0 + (tid + i * 256) / FPR);
+    }
+    __device__ __forceinline__ void load(const Src& s, const Xf& xf, int k0, int kend, int tid) {
+#pragma unroll
+        for (int i = 0; i < NF; i++) {
+            int fc = (tid + i * 256) % FPR;
+            int kcol = k0 + fc * 8;
+            frag_t<T> v = frag_zero<T>();
+            if (kcol < kend) {
+                int seg, off;
+                s.split(kcol, seg, off);
+                const T* p = s.seg_ptr(ctx[i], seg);
+                if (p) v = xf_apply<T>(frag_load<T>(p + off), xf);
+            }
+            r[i] = v;
+        }
+    }
+    __device__ __forceinline__ void store(char* tile, int tid) const {
+#pragma unroll
+        for (int i = 0; i < NF; i++) {
+            int u = tid + i * 256;
+            tile_store_frag<T>(tile, u / FPR, u % FPR, r[i]);
+        }
+    }
+};
+
+// Transposing loader: tile row = source COLUMN (feature), contraction = source ROW (token).
+template <class T, int ROWS, class Src, class Xf> struct TNLoader {
+    static constexpr int V = 4 / (int)sizeof(T);          // features per 4-byte load: 2 (bf16) / 1 (f32)
+    static constexpr int FPR = TileGeom<T>::FPR;
+    static constexpr int RG = ROWS / V;                   // row groups per tile
+    static constexpr int NU = RG * FPR / 256;             // units per thread
+    int seg[NU], off[NU];
+    bool fvalid[NU];
+    frag_t<T> r[NU][V];
+    __device__ __forceinline__ void init(const Src& s, int row0, int tid) {
+#pragma unroll
+        for (int i = 0; i < NU; i++) {
+            int u = tid + i * 256;
+            int feat = row0 + (u % RG) * V;
+            fvalid[i] = feat < s.cols;
+            s.split(fvalid[i] ? feat : 0, seg[i], off[i]);
+        }
+    }
+    __device__ __forceinline__ void load(const Src& s, const Xf& xf, int k0, int kend, int tid) {
+#pragma unroll
+        for (int i = 0; i < NU; i++) {
+            int u = tid + i * 256;
+            int tok0 = k0 + (u / RG) * 8;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                int tok = tok0 + j;
+                float v[V];
+#pragma unroll
+                for (int e = 0; e < V; e++) v[e] = 0.0f;
+                if (fvalid[i] && tok < kend) {
+                    typename Src::Ctx c = s.row_ctx(tok);
+                    const T* p = s.seg_ptr(c, seg[i]);
+                    if (p) {
+#pragma unroll
+                        for (int e = 0; e < V; e++) v[e] = xf((float)p[off[i] + e]);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < V; e++) r[i][e][j] = (T)v[e];
+            }
+        }
+    }
+    __device__ __forceinline__ void store(char* tile, int tid) const {
+#pragma unroll
+        for (int i = 0; i < NU; i++) {
+            int u = tid + i * 256;
+#pragma unroll
+            for (int e = 0; e < V; e++) tile_store_frag<T>(tile, (u % RG) * V + e, u / RG, r[i][e]);
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// epilogues: called with UNIT consecutive columns (n0 .. n0+UNIT-1) of row m, both in range
+// ------------------------------------------------------------------------------------------------
+template <class T> struct EpStore {            // out = v (+bias) (+add)
+    static constexpr int UNIT = 8;
+    T* out; int ld; const float* bias; const T* add;
+    __device__ __forceinline__ void operator()(int m, int n0, float (&v)[8]) const {
+        if (bias) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] += bias[n0 + i];
+        }
+        if (add) {
+            float a[8]; frag_to_float<T>(frag_load<T>(add + (size_t)m * ld + n0), a);
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] += a[i];
+        }
+        frag_store<T>(out + (size_t)m * ld + n0, frag_from_float<T>(v));
+    }
+};
+
+template <class T> struct EpScaleRes {         // out = res + gamma * (v + bias)     (LayerScale + residual)
+    static constexpr int UNIT = 8;
+    T* out; const T* res; int ld; const float* bias; const float* gamma;
+    __device__ __forceinline__ void operator()(int m, int n0, float (&v)[8]) const {
+        float a[8]; frag_to_float<T>(frag_load<T>(res + (size_t)m * ld + n0), a);
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = a[i] + gamma[n0 + i] * (v[i] + bias[n0 + i]);
+        frag_store<T>(out + (size_t)m * ld + n0, frag_from_float<T>(v));
+    }
+};
+
+template <class T> struct EpGeluBwd {          // out = v * gelu'(pre[m][n])
+    static constexpr int UNIT = 8;
+    T* out; const T* pre; int ld;
+    __device__ __forceinline__ void operator()(int m, int n0, float (&v)[8]) const {
+        float a[8]; frag_to_float<T>(frag_load<T>(pre + (size_t)m * ld + n0), a);
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] *= gelu_grad_f(a[i]);
+        frag_store<T>(out + (size_t)m * ld + n0, frag_from_float<T>(v));
+    }
+};
+
+template <class T> struct EpSplit2 {           // columns [0,C) -> out0, [C,2C) -> out1 (both ld = C)
+    static constexpr int UNIT = 8;
+    T* out0; T* out1; int C;
+    __device__ __forceinline__ void operator()(int m, int n0, float (&v)[8]) const {
+        T* o = n0 < C ? out0 + (size_t)m * C + n0 : out1 + (size_t)m * C + (n0 - C);
+        frag_store<T>(o, frag_from_float<T>(v));
+    }
+};
+
+struct EpAtomicF32 {                           // split-K partial sums of a weight gradient
+    static constexpr int UNIT = 8;
+    float* out; int ld;
+    __device__ __forceinline__ void operator()(int m, int n0, float (&v)[8]) const {
+#pragma unroll
+        for (int i = 0; i < 8; i++) atomicAdd(out + (size_t)m * ld + n0 + i, v[i]);
+    }
+};
+
+// conv input-gradient of one parity class: row m = (frame, yy, xx) -> pixel (s*yy+py, s*xx+px); out = v + add
+template <class T> struct EpDgradScatter {
+    static constexpr int UNIT = 8;
+    T* out; const T* add; int H, W, Cin, s, py, px; FastDiv dHcWc, dWc;
+    __device__ __forceinline__ void operator()(int m, int n0, float (&v)[8]) const {
+        uint32_t f, rem, yy, xx;
+        dHcWc.divmod((uint32_t)m, f, rem);
+        dWc.divmod(rem, yy, xx);
+        size_t o = (((size_t)f * H + yy * s + py) * W + xx * s + px) * Cin + n0;
+        if (add) {
+            float a[8]; frag_to_float<T>(frag_load<T>(add + o), a);
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] += a[i];
+        }
+        frag_store<T>(out + o, frag_from_float<T>(v));
+    }
+};
+
+// ConvLSTM gates.  The 1x1-conv weight rows are pre-permuted so that GEMM column
+//   n' = (c/8)*32 + gate*8 + (c%8)      (gate order f,i,o,g — reference rnn.py:57-64)
+// i.e. a 32-column unit holds the four gates of 8 consecutive channels.
+template <class T> struct EpLstm {
+    static constexpr int UNIT = 32;
+    const float* bias;      // permuted like the columns, length 4C
+    const float* c_prev;    // [rows][C] fp32
+    float* c_out;           // [rows][C] fp32
+    T* h_out;               // [rows][C]
+    T* gates;               // [rows][4C] natural layout [f|i|o|g] (activated), may be null
+    int C;
+    __device__ __forceinline__ void operator()(int m, int n0, float (&v)[32]) const {
+        int c0 = (n0 >> 5) << 3;
+        float f[8], ig[8], o[8], g[8], cn[8], hn[8];
+        const float* cp = c_prev + (size_t)m * C + c0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            f[i] = sigmoid_f(v[i] + bias[n0 + i]);
+            ig[i] = sigmoid_f(v[8 + i] + bias[n0 + 8 + i]);
+            o[i] = sigmoid_f(v[16 + i] + bias[n0 + 16 + i]);
+            g[i] = tanh_f(v[24 + i] + bias[n0 + 24 + i]);
+            cn[i] = f[i] * cp[i] + ig[i] * g[i];
+            hn[i] = o[i] * tanh_f(cn[i]);
+        }
+        float* co = c_out + (size_t)m * C + c0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) co[i] = cn[i];
+        frag_store<T>(h_out + (size_t)m * C + c0, frag_from_float<T>(hn));
+        if (gates) {
+            T* gp = gates + (size_t)m * 4 * C + c0;
+            frag_store<T>(gp, frag_from_float<T>(f));
+            frag_store<T>(gp + C, frag_from_float<T>(ig));
+            frag_store<T>(gp + 2 * C, frag_from_float<T>(o));
+            frag_store<T>(gp + 3 * C, frag_from_float<T>(g));
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// the kernel
+// ------------------------------------------------------------------------------------------------
+template <int BN> struct GemmSmem {
+    static constexpr int MAIN = 2 * (128 + BN) * 128;
+    static constexpr int EPI = 128 * (BN + 4) * 4;
+    static constexpr int BYTES = MAIN > EPI ? MAIN : EPI;
+};
+
+template <class T, int BN, bool TN, class ASrc, class AXf, class BSrc, class BXf, class Ep>
+__global__ void __launch_bounds__(256)
+gemm_kernel(ASrc as, AXf axf, BSrc bs, BXf bxf, Ep ep, int M, int N, int K, int n_tiles, int ksplit_len) {
+    constexpr int BM = 128;
+    constexpr int BK = TileGeom<T>::BK;
+    constexpr int WN = BN / 64;
+    __shared__ __attribute__((aligned(16))) char smem[GemmSmem<BN>::BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile = blockIdx.x;
+    const int m0 = (tile / n_tiles) * BM, n0 = (tile % n_tiles) * BN;
+    const int kbeg = blockIdx.y * ksplit_len;
+    const int kend = (kbeg + ksplit_len < K) ? kbeg + ksplit_len : K;
+
+    typedef typename std::conditional<TN, TNLoader<T, BM, ASrc, AXf>, NTLoader<T, BM, ASrc, AXf>>::type LA;
+    typedef typename std::conditional<TN, TNLoader<T, BN, BSrc, BXf>, NTLoader<T, BN, BSrc, BXf>>::type LB;
+    LA la; LB lb;
+    la.init(as, m0, tid);
+    lb.init(bs, n0, tid);
+
+    f32x16 acc[2][WN];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < WN; j++) acc_zero(acc[i][j]);
+
+    constexpr int STAGE_BYTES = (BM + BN) * 128;   // A tile then B tile, two stages
+
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    if (nk > 0) {
+        la.load(as, axf, kbeg, kend, tid);
+        lb.load(bs, bxf, kbeg, kend, tid);
+        la.store(smem, tid);
+        lb.store(smem + BM * 128, tid);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt++) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nk;
+        const char* At = smem + cur * STAGE_BYTES;
+        const char* Bt = At + BM * 128;
+        if (more) {
+            la.load(as, axf, kbeg + (kt + 1) * BK, kend, tid);
+            lb.load(bs, bxf, kbeg + (kt + 1) * BK, kend, tid);
+        }
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ks++) {
+            const int fc = ks * 2 + (lane >> 5);
+            frag_t<T> a[2], b[WN];
+#pragma unroll
+            for (int i = 0; i < 2; i++) a[i] = tile_load_frag<T>(At, wm * 64 + i * 32 + (lane & 31), fc);
+#pragma unroll
+            for (int j = 0; j < WN; j++) b[j] = tile_load_frag<T>(Bt, wn * (BN / 2) + j * 32 + (lane & 31), fc);
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < WN; j++) mma32(acc[i][j], a[i], b[j]);
+        }
+        if (more) {
+            la.store(smem + (cur ^ 1) * STAGE_BYTES, tid);
+            lb.store(smem + (cur ^ 1) * STAGE_BYTES + BM * 128, tid);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: accumulators -> LDS (fp32, row pitch BN+4) -> UNIT-wide row segments ----
+    float* stage = reinterpret_cast<float*>(smem);
+    constexpr int LDS_LD = BN + 4;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < WN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                stage[(wm * 64 + i * 32 + acc_row(r, lane)) * LDS_LD + wn * (BN / 2) + j * 32 + (lane & 31)] = acc[i][j][r];
+    __syncthreads();
+    constexpr int UNIT = Ep::UNIT;
+    constexpr int UPR = BN / UNIT;
+    for (int u = tid; u < BM * UPR; u += 256) {
+        const int row = u / UPR, cu = u % UPR;
+        const int m = m0 + row, n = n0 + cu * UNIT;
+        if (m < M && n < N) {
+            float v[UNIT];
+#pragma unroll
+            for (int q = 0; q < UNIT / 4; q++) {
+                f32x4 t = *reinterpret_cast<const f32x4*>(stage + row * LDS_LD + cu * UNIT + q * 4);
+                v[q * 4 + 0] = t[0]; v[q * 4 + 1] = t[1]; v[q * 4 + 2] = t[2]; v[q * 4 + 3] = t[3];
+            }
+            ep(m, n, v);
+        }
+    }
+}
+
+template <class T, int BN, bool TN, class ASrc, class AXf, class BSrc, class BXf, class Ep>
+inline void launch_gemm(const ASrc& as, const AXf& axf, const BSrc& bs, const BXf& bxf, const Ep& ep,
+                        int M, int N, int K, int ksplit, hipStream_t stream) {
+    const int BK = TileGeom<T>::BK;
+    int n_tiles = (N + BN - 1) / BN;
+    int m_tiles = (M + 127) / 128;
+    if (ksplit < 1) ksplit = 1;
+    int klen = ((K + ksplit - 1) / ksplit + BK - 1) / BK * BK;
+    if (klen < BK) klen = BK;
+    int nsplit = (K + klen - 1) / klen;
+    if (nsplit < 1) nsplit = 1;
+    hipLaunchKernelGGL((gemm_kernel<T, BN, TN, ASrc, AXf, BSrc, BXf, Ep>), dim3(m_tiles * n_tiles, nsplit), dim3(256), 0,
+                       stream, as, axf, bs, bxf, ep, M, N, K, n_tiles, klen);
+}
+
+}  // namespace rvt

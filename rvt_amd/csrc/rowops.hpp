@@ -1,0 +1,234 @@
+// Row-wise / element-wise kernels of the RVT hot path: LayerNorm fwd/bwd, column sums (bias
+// gradients), the event-tensor prepack (uint8/float NCHW -> padded channels-last T), the ConvLSTM
+// gate backward.  All are HBM-bound: every thread moves 16-byte (bf16) / 32-byte (f32) vectors.
+#pragma once
+#include "common.hpp"
+
+namespace rvt {
+
+// reduce over groups of G consecutive lanes (G power of two <= 64)
+__device__ __forceinline__ float group_sum(float v, int G) {
+    for (int m = 1; m < G; m <<= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+// ---- LayerNorm forward over the channel axis (reference maxvit.py:172,177,229,241; eps 1e-5) ----
+// G lanes share a row (G = pow2 >= C/8), each lane holds 8 channels; 64/G rows per wave.
+template <class T>
+__global__ void __launch_bounds__(256)
+ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, T* __restrict__ y,
+              int rows, int C, int G, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int rpw = 64 / G;
+    const int cl = lane % G;
+    const bool cvalid = cl * 8 < C;
+    const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n_waves = gridDim.x * 4;
+    float wv[8], bv[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) { wv[i] = cvalid ? w[cl * 8 + i] : 0.f; bv[i] = cvalid ? b[cl * 8 + i] : 0.f; }
+    const int n_iter = (rows + rpw * n_waves - 1) / (rpw * n_waves);
+    for (int it = 0; it < n_iter; it++) {
+        const int row = (it * n_waves + wave_global) * rpw + lane / G;
+        const bool valid = cvalid && row < rows;
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = 0.f;
+        if (valid) frag_to_float<T>(frag_load<T>(x + (size_t)row * C + cl * 8), v);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) s += v[i];
+        const float mean = group_sum(s, G) / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { float d = valid ? v[i] - mean : 0.f; q += d * d; }
+        const float rstd = 1.0f / sqrtf(group_sum(q, G) / (float)C + eps);
+        if (valid) {
+            float o[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) o[i] = (v[i] - mean) * rstd * wv[i] + bv[i];
+            frag_store<T>(y + (size_t)row * C + cl * 8, frag_from_float<T>(o));
+        }
+    }
+}
+
+// ---- LayerNorm backward ------------------------------------------------------------------------
+// dx = rstd * (g - mean(g) - xhat*mean(g*xhat)),  g = dy*w;   dx_out = dx (+ dres);  dw += dy*xhat, db += dy
+template <class T>
+__global__ void __launch_bounds__(256)
+ln_bwd_kernel(const T* __restrict__ x, const float* __restrict__ w, const T* __restrict__ dy, const T* __restrict__ dres,
+              T* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db, int rows, int C, int G, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int rpw = 64 / G;
+    const int cl = lane % G;
+    const bool cvalid = cl * 8 < C;
+    const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n_waves = gridDim.x * 4;
+    float wv[8], aw[8], ab[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) { wv[i] = cvalid ? w[cl * 8 + i] : 0.f; aw[i] = 0.f; ab[i] = 0.f; }
+    const int n_iter = (rows + rpw * n_waves - 1) / (rpw * n_waves);
+    for (int it = 0; it < n_iter; it++) {
+        const int row = (it * n_waves + wave_global) * rpw + lane / G;
+        const bool valid = cvalid && row < rows;
+        float v[8], d[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) { v[i] = 0.f; d[i] = 0.f; }
+        if (valid) {
+            frag_to_float<T>(frag_load<T>(x + (size_t)row * C + cl * 8), v);
+            frag_to_float<T>(frag_load<T>(dy + (size_t)row * C + cl * 8), d);
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) s += v[i];
+        const float mean = group_sum(s, G) / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { float t = valid ? v[i] - mean : 0.f; q += t * t; }
+        const float rstd = 1.0f / sqrtf(group_sum(q, G) / (float)C + eps);
+        float xh[8], gsum = 0.f, gxsum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            xh[i] = valid ? (v[i] - mean) * rstd : 0.f;
+            float g = d[i] * wv[i];
+            gsum += g; gxsum += g * xh[i];
+            aw[i] += d[i] * xh[i]; ab[i] += d[i];
+        }
+        const float m1 = group_sum(gsum, G) / (float)C;
+        const float m2 = group_sum(gxsum, G) / (float)C;
+        if (valid) {
+            float o[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) o[i] = rstd * (d[i] * wv[i] - m1 - xh[i] * m2);
+            if (dres) {
+                float r[8]; frag_to_float<T>(frag_load<T>(dres + (size_t)row * C + cl * 8), r);
+#pragma unroll
+                for (int i = 0; i < 8; i++) o[i] += r[i];
+            }
+            frag_store<T>(dx + (size_t)row * C + cl * 8, frag_from_float<T>(o));
+        }
+    }
+    // fold the 64/G row-lanes of this wave that own the same columns, then one atomic per column per wave
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        for (int m = G; m < 64; m <<= 1) { aw[i] += __shfl_xor(aw[i], m); ab[i] += __shfl_xor(ab[i], m); }
+    }
+    if (cvalid && lane < G) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) { atomicAdd(dw + cl * 8 + i, aw[i]); atomicAdd(db + cl * 8 + i, ab[i]); }
+    }
+}
+
+// ---- column sums: out[n] += sum_m x[m][n]   (bias / LayerScale gradients) ------------------------
+// NCP = pow2 >= N/8 (<= 256) threads own one 8-column chunk each; 256/NCP row lanes per block.
+template <class T>
+__global__ void __launch_bounds__(256)
+colsum_kernel(const T* __restrict__ x, float* __restrict__ out, int rows, int N, int NCP) {
+    __shared__ float red[256 * 8];
+    const int tid = threadIdx.x;
+    const int c = tid % NCP + blockIdx.y * NCP;
+    const int rl = tid / NCP, nrl = 256 / NCP;
+    const bool cvalid = c * 8 < N;
+    float a[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) a[i] = 0.f;
+    if (cvalid) {
+        for (int row = blockIdx.x * nrl + rl; row < rows; row += gridDim.x * nrl) {
+            float v[8]; frag_to_float<T>(frag_load<T>(x + (size_t)row * N + c * 8), v);
+#pragma unroll
+            for (int i = 0; i < 8; i++) a[i] += v[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) red[tid * 8 + i] = a[i];
+    __syncthreads();
+    if (rl == 0 && cvalid) {
+        for (int r = 1; r < nrl; r++)
+#pragma unroll
+            for (int i = 0; i < 8; i++) a[i] += red[(r * NCP + tid) * 8 + i];
+#pragma unroll
+        for (int i = 0; i < 8; i++) atomicAdd(out + c * 8 + i, a[i]);
+    }
+}
+
+// ---- event-tensor prepack (reference modules/detection.py:133-134 cast + utils/padding.py:29-44) ----
+// src: [F][Cin][h][w] uint8 or float, unpadded.  dst: [F][H][W][Cp] T, zero padded bottom/right and in channels.
+template <class T, class S>
+__global__ void __launch_bounds__(256)
+prepack_kernel(const S* __restrict__ src, T* __restrict__ dst, int F, int Cin, int h, int w, int H, int W, int Cp) {
+    const size_t total = (size_t)F * H * W;
+    for (size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x; pix < total; pix += (size_t)gridDim.x * 256) {
+        const int x = (int)(pix % W);
+        const int y = (int)((pix / W) % H);
+        const int f = (int)(pix / ((size_t)W * H));
+        const bool in = (y < h) && (x < w);
+        T* o = dst + pix * Cp;
+        for (int c0 = 0; c0 < Cp; c0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                int c = c0 + i;
+                v[i] = (in && c < Cin) ? (float)src[(((size_t)f * Cin + c) * h + y) * w + x] : 0.f;
+            }
+            frag_store<T>(o + c0, frag_from_float<T>(v));
+        }
+    }
+}
+
+// ---- ConvLSTM gate backward (element-wise part of BPTT; reference forward rnn.py:57-67) --------
+// dh = dh_in (+ dh_rec);  do = dh*tanh(c);  dc = dc_rec + dh*o*(1-tanh(c)^2);
+// dz = [dc*c_prev*f(1-f), dc*g*i(1-i), do*o(1-o), dc*i*(1-g^2)];  dc_rec <- dc*f
+template <class T>
+__global__ void __launch_bounds__(256)
+lstm_gates_bwd_kernel(const T* __restrict__ dh_in, const T* __restrict__ dh_rec, float* __restrict__ dc_rec,
+                      const T* __restrict__ gates, const float* __restrict__ c_new, const float* __restrict__ c_prev,
+                      T* __restrict__ dz, int M, int C) {
+    const int cpr = C / 8;
+    const size_t total = (size_t)M * cpr;
+    for (size_t u = (size_t)blockIdx.x * 256 + threadIdx.x; u < total; u += (size_t)gridDim.x * 256) {
+        const size_t m = u / cpr;
+        const int c0 = (int)(u % cpr) * 8;
+        float dh[8], f[8], ig[8], o[8], g[8];
+        frag_to_float<T>(frag_load<T>(dh_in + m * C + c0), dh);
+        if (dh_rec) {
+            float r[8]; frag_to_float<T>(frag_load<T>(dh_rec + m * C + c0), r);
+#pragma unroll
+            for (int i = 0; i < 8; i++) dh[i] += r[i];
+        }
+        const T* gp = gates + m * 4 * C + c0;
+        frag_to_float<T>(frag_load<T>(gp), f);
+        frag_to_float<T>(frag_load<T>(gp + C), ig);
+        frag_to_float<T>(frag_load<T>(gp + 2 * C), o);
+        frag_to_float<T>(frag_load<T>(gp + 3 * C), g);
+        float zf[8], zi[8], zo[8], zg[8];
+        float* dcp = dc_rec + m * C + c0;
+        const float* cn = c_new + m * C + c0;
+        const float* cp = c_prev + m * C + c0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            float tc = tanh_f(cn[i]);
+            float dc = dcp[i] + dh[i] * o[i] * (1.f - tc * tc);
+            zo[i] = dh[i] * tc * o[i] * (1.f - o[i]);
+            zf[i] = dc * cp[i] * f[i] * (1.f - f[i]);
+            zi[i] = dc * g[i] * ig[i] * (1.f - ig[i]);
+            zg[i] = dc * ig[i] * (1.f - g[i] * g[i]);
+            dcp[i] = dc * f[i];
+        }
+        T* zp = dz + m * 4 * C + c0;
+        frag_store<T>(zp, frag_from_float<T>(zf));
+        frag_store<T>(zp + C, frag_from_float<T>(zi));
+        frag_store<T>(zp + 2 * C, frag_from_float<T>(zo));
+        frag_store<T>(zp + 3 * C, frag_from_float<T>(zg));
+    }
+}
+
+// zero the state rows of the samples flagged in `mask` (reference modules/utils/detection.py:96-113)
+template <class S>
+__global__ void __launch_bounds__(256)
+state_reset_kernel(S* __restrict__ st, const unsigned char* __restrict__ mask, int B, size_t per_sample) {
+    const size_t total = (size_t)B * per_sample;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256)
+        if (mask[i / per_sample]) st[i] = (S)0.0f;
+}
+
+}  // namespace rvt

@@ -1,0 +1,185 @@
+"""Tensor-level wrappers over the C ABI (include/rvt_hip.h).  torch is used for device memory and
+streams only; every op below is one HIP kernel launch (conv_dgrad: one per stride-parity class)."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+
+Tensor = torch.Tensor
+
+
+def _out(like: Tensor, shape, dtype=None, out: Optional[Tensor] = None) -> Tensor:
+    if out is not None:
+        assert tuple(out.shape) == tuple(shape) and out.is_contiguous()
+        return out
+    return torch.empty(shape, dtype=dtype or like.dtype, device=like.device)
+
+
+def prepack_input(src: Tensor, H: int, W: int, Cp: int, dtype: torch.dtype, out: Optional[Tensor] = None) -> Tensor:
+    """(F,Cin,h,w) uint8/float32 -> (F,H,W,Cp) `dtype`, zero padded (cast+pad of modules/detection.py:133-134)."""
+    assert src.dim() == 4 and src.dtype in (torch.uint8, torch.float32)
+    src = src.contiguous()
+    F_, Cin, h, w = src.shape
+    dst = _out(src, (F_, H, W, Cp), dtype, out)
+    L.call('rvt_prepack_input', L.ptr(src), int(src.dtype == torch.uint8), L.ptr(dst), L.dtype_code(dtype),
+           F_, Cin, h, w, H, W, Cp, L.stream_of(src))
+    return dst
+
+
+def conv_out_hw(H: int, W: int, k: int, stride: int, pad: int):
+    return (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+
+
+def conv_fwd(x: Tensor, w: Tensor, k: int, stride: int, pad: int, out: Optional[Tensor] = None) -> Tensor:
+    F_, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    assert w.shape[1] == k * k * Cin and w.dtype == x.dtype
+    Ho, Wo = conv_out_hw(H, W, k, stride, pad)
+    y = _out(x, (F_, Ho, Wo, Cout), out=out)
+    L.call('rvt_conv_fwd', L.ptr(x), L.ptr(w), L.ptr(y), L.dtype_code(x.dtype), F_, H, W, Cin, Cout, k, stride, pad,
+           L.stream_of(x))
+    return y
+
+
+def conv_dgrad(dy: Tensor, wd: Tensor, add: Optional[Tensor], H: int, W: int, Cin: int, k: int, stride: int, pad: int,
+               out: Optional[Tensor] = None) -> Tensor:
+    F_, Ho, Wo, Cout = dy.shape
+    din = _out(dy, (F_, H, W, Cin), out=out)
+    L.call('rvt_conv_dgrad', L.ptr(dy), L.ptr(wd), L.ptr(add), L.ptr(din), L.dtype_code(dy.dtype), F_, H, W, Cin, Cout,
+           k, stride, pad, L.stream_of(dy))
+    return din
+
+
+def conv_wgrad(x: Tensor, dy: Tensor, dw: Tensor, k: int, stride: int, pad: int) -> None:
+    F_, H, W, Cin = x.shape
+    Cout = dy.shape[-1]
+    assert dw.dtype == torch.float32 and tuple(dw.shape) == (Cout, k * k * Cin)
+    L.call('rvt_conv_wgrad', L.ptr(x), L.ptr(dy), L.ptr(dw), L.dtype_code(x.dtype), F_, H, W, Cin, Cout, k, stride, pad,
+           L.stream_of(x))
+
+
+def layernorm_fwd(x: Tensor, w: Tensor, b: Tensor, eps: float, out: Optional[Tensor] = None) -> Tensor:
+    C = x.shape[-1]
+    rows = x.numel() // C
+    y = _out(x, x.shape, out=out)
+    L.call('rvt_layernorm_fwd', L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), L.dtype_code(x.dtype), rows, C, float(eps),
+           L.stream_of(x))
+    return y
+
+
+def layernorm_bwd(x: Tensor, w: Tensor, dy: Tensor, dres: Optional[Tensor], dw: Tensor, db: Tensor, eps: float,
+                  out: Optional[Tensor] = None) -> Tensor:
+    C = x.shape[-1]
+    rows = x.numel() // C
+    dx = _out(x, x.shape, out=out)
+    L.call('rvt_layernorm_bwd', L.ptr(x), L.ptr(w), L.ptr(dy), L.ptr(dres), L.ptr(dx), L.ptr(dw), L.ptr(db),
+           L.dtype_code(x.dtype), rows, C, float(eps), L.stream_of(x))
+    return dx
+
+
+def linear_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor], gelu_in: bool = False, out: Optional[Tensor] = None) -> Tensor:
+    K = x.shape[-1]
+    M = x.numel() // K
+    N = w.shape[0]
+    assert w.shape[1] == K and w.dtype == x.dtype
+    y = _out(x, (*x.shape[:-1], N), out=out)
+    L.call('rvt_linear_fwd', L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(y), L.dtype_code(x.dtype), M, N, K, int(gelu_in),
+           L.stream_of(x))
+    return y
+
+
+def linear_scale_res_fwd(x: Tensor, w: Tensor, bias: Tensor, gamma: Tensor, res: Tensor, gelu_in: bool = False,
+                         out: Optional[Tensor] = None) -> Tensor:
+    K = x.shape[-1]
+    M = x.numel() // K
+    N = w.shape[0]
+    assert w.shape[1] == K and res.shape[-1] == N
+    y = _out(res, res.shape, out=out)
+    L.call('rvt_linear_scale_res_fwd', L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(gamma), L.ptr(res), L.ptr(y),
+           L.dtype_code(x.dtype), M, N, K, int(gelu_in), L.stream_of(x))
+    return y
+
+
+def linear_dgrad(dy: Tensor, wt: Tensor, gelu_pre: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
+    """dx = dy @ wt.T with wt = W^T stored [K][N] (optionally folded with LayerScale), * gelu'(gelu_pre)."""
+    N = dy.shape[-1]
+    M = dy.numel() // N
+    K = wt.shape[0]
+    assert wt.shape[1] == N
+    dx = _out(dy, (*dy.shape[:-1], K), out=out)
+    L.call('rvt_linear_dgrad', L.ptr(dy), L.ptr(wt), L.ptr(gelu_pre), L.ptr(dx), L.dtype_code(dy.dtype), M, N, K,
+           L.stream_of(dy))
+    return dx
+
+
+def linear_wgrad(dy: Tensor, x: Tensor, dw: Tensor, gelu_in: bool = False) -> None:
+    N = dy.shape[-1]
+    K = x.shape[-1]
+    M = dy.numel() // N
+    assert dw.dtype == torch.float32 and tuple(dw.shape) == (N, K) and x.numel() // K == M
+    L.call('rvt_linear_wgrad', L.ptr(dy), L.ptr(x), L.ptr(dw), L.dtype_code(dy.dtype), M, N, K, int(gelu_in),
+           L.stream_of(dy))
+
+
+def colsum(x: Tensor, out: Tensor) -> None:
+    N = x.shape[-1]
+    assert out.dtype == torch.float32 and out.numel() == N
+    L.call('rvt_colsum', L.ptr(x), L.ptr(out), L.dtype_code(x.dtype), x.numel() // N, N, L.stream_of(x))
+
+
+def attn_fwd(qkv: Tensor, F_: int, H: int, W: int, C: int, dh: int, ph: int, pw: int, window: bool,
+             out: Optional[Tensor] = None) -> Tensor:
+    o = _out(qkv, (F_, H, W, C), out=out)
+    L.call('rvt_attn_fwd', L.ptr(qkv), L.ptr(o), L.dtype_code(qkv.dtype), F_, H, W, C, dh, ph, pw, int(window),
+           L.stream_of(qkv))
+    return o
+
+
+def attn_bwd(qkv: Tensor, dout: Tensor, F_: int, H: int, W: int, C: int, dh: int, ph: int, pw: int, window: bool,
+             out: Optional[Tensor] = None) -> Tensor:
+    d = _out(qkv, qkv.shape, out=out)
+    L.call('rvt_attn_bwd', L.ptr(qkv), L.ptr(dout), L.ptr(d), L.dtype_code(qkv.dtype), F_, H, W, C, dh, ph, pw,
+           int(window), L.stream_of(qkv))
+    return d
+
+
+def lstm_fwd(x: Tensor, h_prev: Tensor, c_prev: Tensor, w_perm: Tensor, b_perm: Tensor, h_out: Tensor, c_out: Tensor,
+             gates: Optional[Tensor]) -> None:
+    C = x.shape[-1]
+    M = x.numel() // C
+    assert c_prev.dtype == torch.float32 and c_out.dtype == torch.float32
+    L.call('rvt_lstm_fwd', L.ptr(x), L.ptr(h_prev), L.ptr(c_prev), L.ptr(w_perm), L.ptr(b_perm), L.ptr(h_out),
+           L.ptr(c_out), L.ptr(gates), L.dtype_code(x.dtype), M, C, L.stream_of(x))
+
+
+def lstm_gates_bwd(dh_in: Tensor, dh_rec: Optional[Tensor], dc_rec: Tensor, gates: Tensor, c_new: Tensor,
+                   c_prev: Tensor, dz: Tensor) -> None:
+    C = dh_in.shape[-1]
+    M = dh_in.numel() // C
+    L.call('rvt_lstm_gates_bwd', L.ptr(dh_in), L.ptr(dh_rec), L.ptr(dc_rec), L.ptr(gates), L.ptr(c_new), L.ptr(c_prev),
+           L.ptr(dz), L.dtype_code(dh_in.dtype), M, C, L.stream_of(dh_in))
+
+
+def lstm_dgrad(dz: Tensor, wt: Tensor, dx: Tensor, dh_rec: Tensor) -> None:
+    C = dx.shape[-1]
+    M = dx.numel() // C
+    L.call('rvt_lstm_dgrad', L.ptr(dz), L.ptr(wt), L.ptr(dx), L.ptr(dh_rec), L.dtype_code(dz.dtype), M, C,
+           L.stream_of(dz))
+
+
+def lstm_wgrad(dz: Tensor, x: Tensor, h_prev: Tensor, dw: Tensor) -> None:
+    C = x.shape[-1]
+    M = x.numel() // C
+    assert dw.dtype == torch.float32 and tuple(dw.shape) == (4 * C, 2 * C)
+    L.call('rvt_lstm_wgrad', L.ptr(dz), L.ptr(x), L.ptr(h_prev), L.ptr(dw), L.dtype_code(dz.dtype), M, C,
+           L.stream_of(dz))
+
+
+def state_reset_masked(st: Tensor, mask: Tensor) -> None:
+    """Zero rows st[b] where mask[b] (modules/utils/detection.py:96-113); st is (B, ...)."""
+    B = st.shape[0]
+    m = mask.to(device=st.device, dtype=torch.uint8).contiguous()
+    L.call('rvt_state_reset_masked', L.ptr(st), L.ptr(m), L.dtype_code(st.dtype), B, st.numel() // B, L.stream_of(st))

@@ -1,0 +1,257 @@
+"""Per-kernel parity: every C-ABI entry point against a plain fp32/fp64 torch restatement of the op,
+on the CPU emulator build (always) and on the real gfx950 build (-m gpu)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from rvt_amd import ops, weights
+from tests.backends import backend  # noqa: F401
+
+DTYPES = [torch.float32, torch.bfloat16]
+TOL = {torch.float32: 2e-5, torch.bfloat16: 2e-2}
+
+
+def rnd(shape, dev, dt, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dt).to(dev)
+
+
+def close(got, want, dt, what, scale=None, mult=1.0):
+    got = got.detach().double().cpu()
+    want = want.detach().double().cpu()
+    s = scale if scale is not None else max(want.abs().max().item(), 1e-6)
+    err = (got - want).abs().max().item() / s
+    assert err <= TOL[dt] * mult, f'{what}: rel err {err:.3e} (tol {TOL[dt] * mult:.1e})'
+
+
+def f64(t):
+    return t.detach().double().cpu()
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+@pytest.mark.parametrize('u8', [True, False])
+def test_prepack(backend, dt, u8):
+    g = torch.Generator().manual_seed(0)
+    src = torch.randint(0, 11, (3, 20, 5, 7), generator=g, dtype=torch.uint8)
+    if not u8:
+        src = src.float()
+    out = ops.prepack_input(src.to(backend), 8, 8, 24, dt)
+    want = torch.zeros(3, 8, 8, 24)
+    want[:, :5, :7, :20] = src.float().permute(0, 2, 3, 1)
+    close(out, want, dt, 'prepack', mult=0.0 if dt == torch.float32 else 1.0)
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+@pytest.mark.parametrize('M,N,K,gelu', [(200, 72, 40, False), (130, 136, 64, True), (64, 16, 16, False), (257, 264, 136, False)])
+def test_linear_fwd(backend, dt, M, N, K, gelu):
+    x, w = rnd((M, K), backend, dt, 1), rnd((N, K), backend, dt, 2, 0.3)
+    b = rnd((N,), backend, torch.float32, 3)
+    y = ops.linear_fwd(x, w, b, gelu_in=gelu)
+    xa = f64(x)
+    if gelu:
+        xa = F.gelu(xa)
+        if dt == torch.bfloat16:
+            xa = xa.to(dt).double()
+    close(y, xa @ f64(w).t() + f64(b), dt, 'linear_fwd')
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+def test_linear_scale_res(backend, dt):
+    M, N, K = 150, 48, 192
+    x, w, res = rnd((M, K), backend, dt, 1), rnd((N, K), backend, dt, 2, 0.2), rnd((M, N), backend, dt, 5)
+    b, gam = rnd((N,), backend, torch.float32, 3), rnd((N,), backend, torch.float32, 4)
+    y = ops.linear_scale_res_fwd(x, w, b, gam, res, gelu_in=True)
+    xa = F.gelu(f64(x))
+    if dt == torch.bfloat16:
+        xa = xa.to(dt).double()
+    close(y, f64(res) + f64(gam) * (xa @ f64(w).t() + f64(b)), dt, 'linear_scale_res')
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+@pytest.mark.parametrize('with_gelu', [False, True])
+def test_linear_dgrad(backend, dt, with_gelu):
+    M, N, K = 140, 96, 72
+    dy, wt = rnd((M, N), backend, dt, 1), rnd((K, N), backend, dt, 2, 0.2)
+    pre = rnd((M, K), backend, dt, 3) if with_gelu else None
+    dx = ops.linear_dgrad(dy, wt, pre)
+    want = f64(dy) @ f64(wt).t()
+    if with_gelu:
+        p = f64(pre).requires_grad_(True)
+        F.gelu(p).sum().backward()
+        want = want * p.grad
+    close(dx, want, dt, 'linear_dgrad')
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+@pytest.mark.parametrize('M,N,K,gelu', [(300, 24, 40, False), (1100, 136, 72, True), (70, 264, 16, False)])
+def test_linear_wgrad(backend, dt, M, N, K, gelu):
+    dy, x = rnd((M, N), backend, dt, 1), rnd((M, K), backend, dt, 2)
+    dw = torch.zeros(N, K, device=backend)
+    ops.linear_wgrad(dy, x, dw, gelu_in=gelu)
+    xa = f64(x)
+    if gelu:
+        xa = F.gelu(xa)
+        if dt == torch.bfloat16:
+            xa = xa.to(dt).double()
+    close(dw, f64(dy).t() @ xa, dt, 'linear_wgrad')
+    ops.linear_wgrad(dy, x, dw, gelu_in=gelu)          # accumulates
+    close(dw, 2 * (f64(dy).t() @ xa), dt, 'linear_wgrad accumulate')
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+@pytest.mark.parametrize('rows,N', [(77, 144), (300, 16), (40, 2048 + 64)])
+def test_colsum(backend, dt, rows, N):
+    x = rnd((rows, N), backend, dt, 1)
+    out = torch.zeros(N, device=backend)
+    ops.colsum(x, out)
+    close(out, f64(x).sum(0), dt, 'colsum', mult=0.1 if dt == torch.bfloat16 else 1.0)
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+@pytest.mark.parametrize('rows,C', [(37, 48), (100, 64), (9, 16), (21, 512), (33, 384)])
+def test_layernorm(backend, dt, rows, C):
+    x = rnd((rows, C), backend, dt, 1, 2.0)
+    w, b = rnd((C,), backend, torch.float32, 2), rnd((C,), backend, torch.float32, 3)
+    dy, dres = rnd((rows, C), backend, dt, 4), rnd((rows, C), backend, dt, 5)
+    y = ops.layernorm_fwd(x, w, b, 1e-5)
+    xr = f64(x).requires_grad_(True)
+    wr, br = f64(w).requires_grad_(True), f64(b).requires_grad_(True)
+    yr = F.layer_norm(xr, (C,), wr, br, 1e-5)
+    close(y, yr, dt, 'ln_fwd')
+    yr.backward(f64(dy))
+    dw, db = torch.zeros(C, device=backend), torch.zeros(C, device=backend)
+    dx = ops.layernorm_bwd(x, w, dy, dres, dw, db, 1e-5)
+    close(dx, xr.grad + f64(dres), dt, 'ln_bwd dx')
+    close(dw, wr.grad, dt, 'ln_bwd dw')
+    close(db, br.grad, dt, 'ln_bwd db')
+
+
+def ref_attention(qkv, Fr, H, W, C, dh, ph, pw, window):
+    """plain restatement of maxvit.py:273-304,343-354 on (F,H,W,3C) -> (F,H,W,C)"""
+    heads = C // dh
+    x = qkv.reshape(Fr, H, W, 3 * C)
+    if window:
+        t = x.reshape(Fr, H // ph, ph, W // pw, pw, 3 * C).permute(0, 1, 3, 2, 4, 5)
+    else:
+        t = x.reshape(Fr, ph, H // ph, pw, W // pw, 3 * C).permute(0, 2, 4, 1, 3, 5)
+    t = t.reshape(-1, ph * pw, heads, 3, dh)
+    q, k, v = t[:, :, :, 0].transpose(1, 2), t[:, :, :, 1].transpose(1, 2), t[:, :, :, 2].transpose(1, 2)
+    a = torch.softmax(q @ k.transpose(-1, -2) * dh ** -0.5, dim=-1)
+    o = (a @ v).transpose(1, 2).reshape(-1, ph, pw, C)
+    if window:
+        o = o.reshape(Fr, H // ph, W // pw, ph, pw, C).permute(0, 1, 3, 2, 4, 5)
+    else:
+        o = o.reshape(Fr, H // ph, W // pw, ph, pw, C).permute(0, 3, 1, 4, 2, 5)
+    return o.reshape(Fr, H, W, C)
+
+
+ATTN_CASES = [  # F, H, W, C, dh, ph, pw
+    (2, 4, 6, 32, 16, 2, 3),       # L=6   (NB=1), 2 heads
+    (1, 12, 20, 64, 32, 6, 10),    # L=60  (NB=2), 1Mpx partition
+    (1, 8, 20, 32, 32, 8, 10),     # L=80  (NB=3), Gen1 partition
+    (1, 4, 6, 48, 24, 2, 3),       # dim_head 24 (RVT-Small)
+    (1, 6, 10, 16, 8, 6, 10),      # dim_head 8, one partition per frame
+]
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+@pytest.mark.parametrize('window', [True, False])
+@pytest.mark.parametrize('case', ATTN_CASES)
+def test_attention(backend, dt, window, case):
+    Fr, H, W, C, dh, ph, pw = case
+    qkv = rnd((Fr, H, W, 3 * C), backend, dt, 1)
+    dout = rnd((Fr, H, W, C), backend, dt, 2)
+    out = ops.attn_fwd(qkv, Fr, H, W, C, dh, ph, pw, window)
+    qr = f64(qkv).requires_grad_(True)
+    want = ref_attention(qr, Fr, H, W, C, dh, ph, pw, window)
+    close(out, want, dt, 'attn_fwd')
+    want.backward(f64(dout))
+    dq = ops.attn_bwd(qkv, dout, Fr, H, W, C, dh, ph, pw, window)
+    close(dq, qr.grad, dt, 'attn_bwd', mult=2.0)
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+@pytest.mark.parametrize('M,C', [(150, 16), (70, 72)])
+def test_lstm_cell(backend, dt, M, C):
+    x, h = rnd((M, C), backend, dt, 1), rnd((M, C), backend, dt, 2)
+    c = rnd((M, C), backend, torch.float32, 3)
+    w = rnd((4 * C, 2 * C), backend, torch.float32, 4, 0.3)
+    b = rnd((4 * C,), backend, torch.float32, 5, 0.3)
+    perm = weights.lstm_gate_perm(C, backend)
+    w_t = w.to(dt)
+    h_out = torch.empty(M, C, dtype=dt, device=backend)
+    c_out = torch.empty(M, C, device=backend)
+    gates = torch.empty(M, 4 * C, dtype=dt, device=backend)
+    ops.lstm_fwd(x, h, c, w_t[perm].contiguous(), b[perm].contiguous(), h_out, c_out, gates)
+    xr, hr, cr = f64(x).requires_grad_(True), f64(h).requires_grad_(True), f64(c).requires_grad_(True)
+    wr, br = f64(w_t).requires_grad_(True), f64(b)
+    mix = torch.cat([xr, hr], 1) @ wr.t() + br
+    fg, ig, og = torch.sigmoid(mix[:, :C]), torch.sigmoid(mix[:, C:2 * C]), torch.sigmoid(mix[:, 2 * C:3 * C])
+    gg = torch.tanh(mix[:, 3 * C:])
+    cn = fg * cr + ig * gg
+    hn = og * torch.tanh(cn)
+    close(c_out, cn, dt, 'lstm c')
+    close(h_out, hn, dt, 'lstm h')
+    close(gates, torch.cat([fg, ig, og, gg], 1), dt, 'lstm gates')
+    # backward of one step with incoming dh (two parts) and dc
+    dh_in, dh_rec = rnd((M, C), backend, dt, 6), rnd((M, C), backend, dt, 7)
+    dc_rec = rnd((M, C), backend, torch.float32, 8)
+    (hn * (f64(dh_in) + f64(dh_rec))).sum().backward(retain_graph=True)
+    (cn * f64(dc_rec)).sum().backward()
+    dz = torch.empty(M, 4 * C, dtype=dt, device=backend)
+    dc_io = dc_rec.clone()
+    # the kernel consumes the *saved* (rounded) gates and fp32 cell states
+    ops.lstm_gates_bwd(dh_in, dh_rec, dc_io, gates, c_out, c, dz)
+    close(dc_io, cr.grad, dt, 'lstm dc_prev', mult=2.0)
+    dx = torch.empty(M, C, dtype=dt, device=backend)
+    dhp = torch.empty(M, C, dtype=dt, device=backend)
+    ops.lstm_dgrad(dz, w_t.t().contiguous(), dx, dhp)
+    close(dx, xr.grad, dt, 'lstm dx', mult=2.0)
+    close(dhp, hr.grad, dt, 'lstm dh_prev', mult=2.0)
+    dw = torch.zeros(4 * C, 2 * C, device=backend)
+    ops.lstm_wgrad(dz, x, h, dw)
+    close(dw, wr.grad, dt, 'lstm dw', mult=2.0)
+
+
+CONV_CASES = [  # F, H, W, Cin, Cout, k, s, p
+    (2, 8, 12, 16, 32, 3, 2, 1),
+    (1, 16, 24, 20, 16, 7, 4, 3),     # stem: Cin=20 padded to 24
+    (2, 8, 8, 16, 24, 2, 2, 0),       # non-overlapping patch (overlap=False)
+    (1, 6, 10, 72, 136, 3, 2, 1),
+]
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv(backend, dt, case):
+    Fr, H, W, Cin, Cout, k, s, p = case
+    cp = weights.round8(Cin)
+    x = rnd((Fr, H, W, cp), backend, dt, 1)
+    x[..., Cin:] = 0
+    w = rnd((Cout, Cin, k, k), backend, torch.float32, 2, 0.2).to(dt)
+    y = ops.conv_fwd(x, weights.pack_conv_fwd(w.float(), cp, dt), k, s, p)
+    xr = f64(x)[..., :Cin].permute(0, 3, 1, 2).requires_grad_(True)
+    wr = f64(w).requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, s, p)
+    close(y, yr.permute(0, 2, 3, 1), dt, 'conv_fwd')
+    dy = rnd(tuple(y.shape), backend, dt, 3)
+    yr.backward(f64(dy).permute(0, 3, 1, 2))
+    dw = torch.zeros(Cout, k * k * cp, device=backend)
+    ops.conv_wgrad(x, dy, dw, k, s, p)
+    close(weights.unpack_conv_wgrad(dw, Cin, k), wr.grad, dt, 'conv_wgrad')
+    if Cin % 8 == 0:
+        add = rnd((Fr, H, W, Cin), backend, dt, 4)
+        din = ops.conv_dgrad(dy, weights.pack_conv_dgrad(w.float(), s, p, dt), add, H, W, Cin, k, s, p)
+        close(din, xr.grad.permute(0, 2, 3, 1) + f64(add), dt, 'conv_dgrad')
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+def test_state_reset(backend, dt):
+    st = rnd((3, 4, 5, 8), backend, dt, 1)
+    ref = st.clone()
+    ops.state_reset_masked(st, torch.tensor([True, False, True]))
+    ref[0] = 0
+    ref[2] = 0
+    assert torch.equal(st.cpu(), ref.cpu())
