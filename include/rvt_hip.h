@@ -60,9 +60,10 @@ int rvt_linear_fwd(const void* x, const void* w, const float* bias, void* y, int
 /* y = res + gamma * (f(x) W^T + bias)   — LayerScale + residual (maxvit.py:51-53,268-269). */
 int rvt_linear_scale_res_fwd(const void* x, const void* w, const float* bias, const float* gamma, const void* res,
                              void* y, int dtype, int M, int N, int K, int gelu_in, void* stream);
-/* dx[M][K] = dy[M][N] Wt[K][N]^T, optionally * gelu'(pre[M][K]) (pre nullable). */
-int rvt_linear_dgrad(const void* dy, const void* wt, const void* gelu_pre, void* dx, int dtype, int M, int N, int K,
-                     void* stream);
+/* dx[M][K] = dy[M][N] Wt[K][N]^T, optionally * gelu'(pre[M][K]) (pre nullable), optionally + add[M][K]
+ * (add nullable; not combinable with gelu_pre). */
+int rvt_linear_dgrad(const void* dy, const void* wt, const void* gelu_pre, const void* add, void* dx, int dtype, int M,
+                     int N, int K, void* stream);
 /* dw[N][K] (float32) += dy[M][N]^T f(x)[M][K]. */
 int rvt_linear_wgrad(const void* dy, const void* x, float* dw, int dtype, int M, int N, int K, int gelu_in,
                      void* stream);

@@ -1,0 +1,305 @@
+"""MI355X-native drop-in for the reference recurrent backbone.
+
+Mirrors /root/reference/models/detection/recurrent_backbone/maxvit_rnn.py:
+  * ``RNNDetector(mdl_config)`` reads the same ``model.backbone`` keys (maxvit_rnn.py:28-33,144-160;
+    maxvit.py:134,157-158,201-213), exposes ``stage_dims``, ``strides``, ``num_stages``, ``stages``,
+    ``get_stage_dims`` / ``get_strides`` (maxvit_rnn.py:81-91);
+  * owns ``nn.Parameter``s with the reference's names and shapes, default-initialised the same way, so
+    reference checkpoints load with ``load_state_dict``;
+  * ``forward(x, prev_states=None, token_mask=None) -> ({1..4: (B,C,H,W)}, [(h,c)]*4)`` like
+    maxvit_rnn.py:93-105, differentiable w.r.t. parameters and ``prev_states``;
+  * ``forward_sequence(xs, prev_states)`` runs a whole (T,B,C,h,w) sequence stage-major (rvt_amd/stage.py) —
+    what the training step (rvt_amd/step.py) calls instead of T separate ``forward`` calls.
+All arithmetic happens in the HIP kernels behind include/rvt_hip.h; the torch modules below are
+parameter containers only and are never called.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .stage import StageGeom, stage_seq_backward, stage_seq_forward
+from .weights import StageWeights, round8
+
+Tensor = torch.Tensor
+LstmState = Optional[Tuple[Tensor, Tensor]]
+LstmStates = List[LstmState]
+BackboneFeatures = Dict[int, Tensor]
+
+
+class _Holder(nn.Module):
+    """Parameter container (keeps the reference's state_dict hierarchy); never called."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError('parameter container: compute happens in rvt_amd HIP kernels')
+
+
+def _cfg_get(cfg, key, default=None):
+    if hasattr(cfg, 'get'):
+        return cfg.get(key, default)
+    return getattr(cfg, key, default)
+
+
+def _make_attention_block(dim: int, attention_cfg, skip_first_norm: bool) -> _Holder:
+    """Parameters of PartitionAttentionCl (maxvit.py:193-250)."""
+    norm_eps = _cfg_get(attention_cfg, 'norm_eps', 1e-5)
+    dim_head = _cfg_get(attention_cfg, 'dim_head', 32)
+    attention_bias = _cfg_get(attention_cfg, 'attention_bias', True)
+    mlp_bias = _cfg_get(attention_cfg, 'mlp_bias', True)
+    mlp_ratio = _cfg_get(attention_cfg, 'mlp_ratio', 4)
+    ls_init = _cfg_get(attention_cfg, 'ls_init_value', 1e-5)
+    if attention_cfg.use_torch_mha:
+        raise NotImplementedError('use_torch_mha=True has a different parameter layout (maxvit.py:307-325)')
+    if attention_cfg.mlp_gated:
+        raise NotImplementedError('mlp_gated=True (GLU, maxvit.py:56-82) is not built; all shipped configs use False')
+    if attention_cfg.mlp_activation != 'gelu':
+        raise NotImplementedError(f'mlp_activation={attention_cfg.mlp_activation}: only exact GELU is built')
+    for k in ('drop_path', 'drop_mlp'):
+        if _cfg_get(attention_cfg, k, 0.0) > 0:
+            raise NotImplementedError(f'{k} > 0: stochastic layers are not built (all shipped configs use 0)')
+    if not (attention_bias and mlp_bias) or not ls_init > 0:
+        raise NotImplementedError('bias-free linears / ls_init_value<=0 are not built')
+    assert dim % dim_head == 0 and dim_head % 8 == 0 and dim_head <= 32, f'dim_head={dim_head} unsupported'
+    blk = _Holder()
+    blk.norm1 = nn.Identity() if skip_first_norm else nn.LayerNorm(dim, eps=norm_eps)
+    blk.self_attn = _Holder()
+    blk.self_attn.qkv = nn.Linear(dim, dim * 3, bias=True)
+    blk.self_attn.proj = nn.Linear(dim, dim, bias=True)
+    blk.ls1 = _Holder()
+    blk.ls1.gamma = nn.Parameter(ls_init * torch.ones(dim))
+    blk.norm2 = nn.LayerNorm(dim, eps=norm_eps)
+    blk.mlp = _Holder()
+    inner = int(dim * mlp_ratio)
+    blk.mlp.net = nn.Sequential(nn.Sequential(nn.Linear(dim, inner, bias=True), nn.GELU()), nn.Dropout(0.0),
+                                nn.Linear(inner, dim, bias=True))
+    blk.ls2 = _Holder()
+    blk.ls2.gamma = nn.Parameter(ls_init * torch.ones(dim))
+    return blk
+
+
+class RNNDetectorStage(_Holder):
+    """Parameters of one stage (maxvit_rnn.py:130-167)."""
+
+    def __init__(self, dim_in: int, stage_dim: int, spatial_downsample_factor: int, num_blocks: int,
+                 enable_token_masking: bool, stage_cfg):
+        super().__init__()
+        assert isinstance(num_blocks, int) and num_blocks > 0
+        ds, lstm_cfg, attention_cfg = stage_cfg.downsample, stage_cfg.lstm, stage_cfg.attention
+        if ds.type != 'patch':
+            raise NotImplementedError(ds.type)                                   # maxvit.py:134-140
+        assert spatial_downsample_factor in (2, 4, 8)
+        overlap = _cfg_get(ds, 'overlap', True)
+        if not _cfg_get(ds, 'norm_affine', True):
+            raise NotImplementedError('norm_affine=False is not built')
+        k = (spatial_downsample_factor - 1) * 2 + 1 if overlap else spatial_downsample_factor
+        pad = k // 2 if overlap else 0
+        self.geom_conv = (k, spatial_downsample_factor, pad)
+        self.downsample_cf2cl = _Holder()
+        self.downsample_cf2cl.conv = nn.Conv2d(dim_in, stage_dim, k, stride=spatial_downsample_factor, padding=pad,
+                                               bias=False)
+        self.downsample_cf2cl.norm = nn.LayerNorm(stage_dim, eps=1e-5)
+        blocks = []
+        for i in range(num_blocks):
+            pair = _Holder()
+            pair.att_window = _make_attention_block(stage_dim, attention_cfg, skip_first_norm=(i == 0))
+            pair.att_grid = _make_attention_block(stage_dim, attention_cfg, skip_first_norm=False)
+            blocks.append(pair)
+        self.att_blocks = nn.ModuleList(blocks)
+        if lstm_cfg.dws_conv:
+            raise NotImplementedError('dws_conv=True (depth-wise 3x3 in the ConvLSTM, rnn.py:25-29) is not built yet; '
+                                      'every shipped config sets dws_conv: False')
+        if _cfg_get(lstm_cfg, 'drop_cell_update', 0) > 0:
+            raise NotImplementedError('drop_cell_update > 0 is not built')
+        self.lstm = _Holder()
+        self.lstm.conv1x1 = nn.Conv2d(stage_dim * 2, stage_dim * 4, kernel_size=1)
+        self.mask_token = nn.Parameter(torch.zeros(1, 1, 1, stage_dim)) if enable_token_masking else None
+        if self.mask_token is not None:
+            nn.init.normal_(self.mask_token, std=.02)                            # maxvit_rnn.py:166
+
+
+class RNNDetector(nn.Module):
+    def __init__(self, mdl_config, compute_dtype: torch.dtype = torch.float32):
+        super().__init__()
+        in_channels = mdl_config.input_channels
+        embed_dim = mdl_config.embed_dim
+        dim_multiplier = tuple(mdl_config.dim_multiplier)
+        num_blocks = tuple(mdl_config.num_blocks)
+        t_max = tuple(mdl_config.T_max_chrono_init)          # parsed, asserted, unused — like the reference
+        enable_masking = mdl_config.enable_masking
+        num_stages = len(num_blocks)
+        assert num_stages == 4
+        assert isinstance(embed_dim, int)
+        assert num_stages == len(dim_multiplier) == len(t_max)
+        patch_size = mdl_config.stem.patch_size
+        attention_cfg = mdl_config.stage.attention
+        ps = attention_cfg.partition_size
+        self.partition_size = (ps, ps) if isinstance(ps, int) else tuple(ps)
+        assert len(self.partition_size) == 2
+        self.dim_head = _cfg_get(attention_cfg, 'dim_head', 32)
+        self.norm_eps = _cfg_get(attention_cfg, 'norm_eps', 1e-5)
+        self.in_channels = in_channels
+        self.num_blocks = num_blocks
+        in_res = _cfg_get(mdl_config, 'in_res_hw', None)
+        self.in_res_hw = tuple(in_res) if in_res is not None else None
+        self.compute_dtype = compute_dtype
+
+        self.stage_dims = [embed_dim * x for x in dim_multiplier]
+        self.stages = nn.ModuleList()
+        self.strides = []
+        input_dim, stride = in_channels, 1
+        for si in range(num_stages):
+            f = patch_size if si == 0 else 2
+            self.stages.append(RNNDetectorStage(input_dim, self.stage_dims[si], f, num_blocks[si],
+                                                enable_masking and si == 0, mdl_config.stage))
+            stride *= f
+            self.strides.append(stride)
+            input_dim = self.stage_dims[si]
+        self.num_stages = num_stages
+        self._param_names = [n for n, _ in self.named_parameters()]
+
+    # ---- reference API ------------------------------------------------------------------------------
+    def get_stage_dims(self, stages: Tuple[int, ...]) -> Tuple[int, ...]:
+        idx = [x - 1 for x in stages]
+        assert min(idx) >= 0 and max(idx) < len(self.stages), idx
+        return tuple(self.stage_dims[i] for i in idx)
+
+    def get_strides(self, stages: Tuple[int, ...]) -> Tuple[int, ...]:
+        idx = [x - 1 for x in stages]
+        assert min(idx) >= 0 and max(idx) < len(self.stages), idx
+        return tuple(self.strides[i] for i in idx)
+
+    def forward(self, x: Tensor, prev_states: Optional[LstmStates] = None, token_mask: Optional[Tensor] = None) \
+            -> Tuple[BackboneFeatures, LstmStates]:
+        feats, states = self.forward_sequence(x[None], prev_states, None if token_mask is None else token_mask[None])
+        return {k: v[0] for k, v in feats.items()}, states
+
+    # ---- sequence API -------------------------------------------------------------------------------
+    def stage_geoms(self, H: int, W: int) -> List[StageGeom]:
+        out = []
+        cin = self.in_channels
+        for si, st in enumerate(self.stages):
+            k, s, p = st.geom_conv
+            g = StageGeom(C=self.stage_dims[si], Cin=cin, H_in=H, W_in=W, k=k, stride=s, pad=p,
+                          ph=self.partition_size[0], pw=self.partition_size[1], dim_head=self.dim_head,
+                          num_blocks=self.num_blocks[si], eps=self.norm_eps)
+            H, W, cin = g.H, g.W, g.C
+            assert H % g.ph == 0 and W % g.pw == 0, \
+                f'stage {si + 1}: {H}x{W} not divisible by partition {self.partition_size} (maxvit.py:275-276)'
+            out.append(g)
+        return out
+
+    def forward_sequence(self, xs: Union[Tensor, Sequence[Tensor]], prev_states: Optional[LstmStates] = None,
+                         token_masks: Optional[Tensor] = None):
+        """xs: (T,B,Cin,h,w) uint8/float or a list of T (B,Cin,h,w) tensors (the reference's EV_REPR list).
+        Returns ({stage: (T,B,C,H,W)}, [(h,c)]*4); h = features of the last step, c fp32."""
+        if not torch.is_tensor(xs):
+            xs = torch.stack(list(xs), 0)
+        assert xs.dim() == 5 and xs.shape[2] == self.in_channels
+        if prev_states is None:
+            prev_states = [None] * self.num_stages
+        assert len(prev_states) == self.num_stages
+        flat_states = []
+        for st in prev_states:
+            flat_states += [None, None] if st is None else [st[0], st[1]]
+        params = [p for _, p in self.named_parameters()]
+        outs = _BackboneSeqFn.apply(self, xs, token_masks, *flat_states, *params)
+        feats = {s + 1: outs[2 * s] for s in range(self.num_stages)}
+        states = [(outs[2 * s][-1], outs[2 * s + 1]) for s in range(self.num_stages)]
+        return feats, states
+
+
+def _to_cl(t: Tensor, dtype: torch.dtype) -> Tensor:
+    """(…,C,H,W)-shaped -> contiguous (…,H,W,C) in `dtype` (free when t is already a channels-last view)."""
+    nd = t.dim()
+    perm = list(range(nd - 3)) + [nd - 2, nd - 1, nd - 3]
+    return t.permute(*perm).to(dtype).contiguous()
+
+
+class _BackboneSeqFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod: RNNDetector, xs: Tensor, token_masks: Optional[Tensor], *rest):
+        ns = mod.num_stages
+        states_in, params = rest[:2 * ns], rest[2 * ns:]
+        names = mod._param_names
+        p = dict(zip(names, params))
+        dt = mod.compute_dtype
+        T, B, Cin, h, w = xs.shape
+        Hm, Wm = mod.in_res_hw if mod.in_res_hw is not None else (h, w)
+        assert h <= Hm and w <= Wm, f'input {h}x{w} larger than model resolution {Hm}x{Wm}'
+        geoms = mod.stage_geoms(Hm, Wm)
+        need_grad = any(ctx.needs_input_grad[3:])
+        src = xs.reshape(T * B, Cin, h, w)
+        if src.dtype not in (torch.uint8, torch.float32):
+            src = src.float()
+        inp = ops.prepack_input(src, Hm, Wm, round8(Cin), dt)
+        sws, svs, outs = [], [], []
+        for si in range(ns):
+            g = geoms[si]
+            pre = f'stages.{si}.'
+            sw = StageWeights(p, pre, g.C, g.Cin, g.k, g.stride, g.pad, g.num_blocks, dt, need_grad)
+            h0, c0 = states_in[2 * si], states_in[2 * si + 1]
+            if h0 is not None:
+                h0, c0 = _to_cl(h0, dt), _to_cl(c0, torch.float32)
+            tm = mt = None
+            if si == 0 and token_masks is not None:
+                assert mod.stages[0].mask_token is not None, 'No mask token present in this stage'
+                tm, mt = token_masks.to(xs.device), p[pre + 'mask_token'].detach()
+            Hall, Call, sv = stage_seq_forward(sw, g, inp, h0, c0, T, B, need_grad, tm, mt)
+            sws.append(sw)
+            svs.append(sv)
+            inp = Hall[1:].reshape(T * B, g.H, g.W, g.C)
+            outs += [Hall[1:].permute(0, 1, 4, 2, 3), Call[T].permute(0, 3, 1, 2)]
+        ctx.mod, ctx.geoms, ctx.sws, ctx.svs, ctx.p = mod, geoms, sws, svs, p
+        ctx.T, ctx.B = T, B
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gout):
+        mod, geoms, T, B = ctx.mod, ctx.geoms, ctx.T, ctx.B
+        ns = mod.num_stages
+        dt = mod.compute_dtype
+        grads_by_name: Dict[str, Tensor] = {}
+        state_grads: List[Optional[Tensor]] = [None] * (2 * ns)
+        d_from_above = None          # conv dgrad of stage s+1, already including this stage's own feature cotangent
+        hook = getattr(mod, '_stage_grad_hook', None)
+        for si in range(ns - 1, -1, -1):
+            g = geoms[si]
+            dF, dC = gout[2 * si], gout[2 * si + 1]
+            if si == ns - 1:
+                dH = None if dF is None else _to_cl(dF, dt)
+            else:
+                dH = d_from_above.view(T, B, g.H, g.W, g.C)
+            dc_last = None if dC is None else _to_cl(dC, torch.float32)
+            # cotangent attached to THIS stage's input frames = feature cotangent of the stage below
+            prev_cot = None
+            if si > 0 and gout[2 * (si - 1)] is not None:
+                gp = geoms[si - 1]
+                prev_cot = _to_cl(gout[2 * (si - 1)], dt).view(T * B, gp.H, gp.W, gp.C)
+            d_in, dh0, dc0, grads = stage_seq_backward(ctx.sws[si], g, ctx.svs[si], dH, dc_last, T, B, si > 0,
+                                                       prev_cot, ctx.p, f'stages.{si}.')
+            d_from_above = d_in
+            grads_by_name.update(grads)
+            if ctx.needs_input_grad[3 + 2 * si]:
+                state_grads[2 * si] = dh0.permute(0, 3, 1, 2)
+                state_grads[2 * si + 1] = dc0.permute(0, 3, 1, 2)
+            if hook is not None:
+                hook(si, grads)
+            ctx.svs[si] = None
+        pgrads = []
+        for i, n in enumerate(mod._param_names):
+            gr = grads_by_name.get(n)
+            if gr is not None:
+                gr = gr.reshape(ctx.p[n].shape).to(ctx.p[n].dtype)
+            pgrads.append(gr if ctx.needs_input_grad[3 + 2 * ns + i] else None)
+        return (None, None, None, *state_grads, *pgrads)
+
+
+def build_recurrent_backbone(backbone_cfg, compute_dtype: torch.dtype = torch.float32):
+    """Registry entry point (reference recurrent_backbone/__init__.py:6-11)."""
+    if backbone_cfg.name == 'MaxViTRNN':
+        return RNNDetector(backbone_cfg, compute_dtype=compute_dtype)
+    raise NotImplementedError(backbone_cfg.name)

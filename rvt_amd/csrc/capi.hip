@@ -230,9 +230,10 @@ int rvt_linear_scale_res_fwd(const void* x, const void* w, const float* bias, co
     return check_launch("linear_scale_res_fwd");
 }
 
-int rvt_linear_dgrad(const void* dy, const void* wt, const void* gelu_pre, void* dx, int dtype, int M, int N, int K,
-                     void* stream) {
+int rvt_linear_dgrad(const void* dy, const void* wt, const void* gelu_pre, const void* add, void* dx, int dtype, int M,
+                     int N, int K, void* stream) {
     RVT_CHECK(N % 8 == 0 && K % 8 == 0, "linear_dgrad: N=%d K=%d must be multiples of 8", N, K);
+    RVT_CHECK(!(gelu_pre && add), "linear_dgrad: gelu_pre and add are mutually exclusive");
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_DTYPE(dtype, {
         PlainSrc<T> a{(const T*)dy, N, M, N};
@@ -242,7 +243,7 @@ int rvt_linear_dgrad(const void* dy, const void* wt, const void* gelu_pre, void*
                 EpGeluBwd<T> ep{(T*)dx, (const T*)gelu_pre, K};
                 launch_gemm<T, BN, false>(a, XfNone(), b, XfNone(), ep, M, K, N, 1, st);
             } else {
-                EpStore<T> ep{(T*)dx, K, nullptr, nullptr};
+                EpStore<T> ep{(T*)dx, K, nullptr, (const T*)add};
                 launch_gemm<T, BN, false>(a, XfNone(), b, XfNone(), ep, M, K, N, 1, st);
             }
         });

@@ -103,15 +103,16 @@ def linear_scale_res_fwd(x: Tensor, w: Tensor, bias: Tensor, gamma: Tensor, res:
     return y
 
 
-def linear_dgrad(dy: Tensor, wt: Tensor, gelu_pre: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
-    """dx = dy @ wt.T with wt = W^T stored [K][N] (optionally folded with LayerScale), * gelu'(gelu_pre)."""
+def linear_dgrad(dy: Tensor, wt: Tensor, gelu_pre: Optional[Tensor] = None, add: Optional[Tensor] = None,
+                 out: Optional[Tensor] = None) -> Tensor:
+    """dx = dy @ wt.T with wt = W^T stored [K][N] (optionally folded with LayerScale), * gelu'(gelu_pre) or + add."""
     N = dy.shape[-1]
     M = dy.numel() // N
     K = wt.shape[0]
     assert wt.shape[1] == N
     dx = _out(dy, (*dy.shape[:-1], K), out=out)
-    L.call('rvt_linear_dgrad', L.ptr(dy), L.ptr(wt), L.ptr(gelu_pre), L.ptr(dx), L.dtype_code(dy.dtype), M, N, K,
-           L.stream_of(dy))
+    L.call('rvt_linear_dgrad', L.ptr(dy), L.ptr(wt), L.ptr(gelu_pre), L.ptr(add), L.ptr(dx), L.dtype_code(dy.dtype),
+           M, N, K, L.stream_of(dy))
     return dx
 
 

@@ -1,0 +1,218 @@
+"""Stage-major execution of one backbone stage over a whole event-tensor sequence.
+
+The reference runs time-major: for every time step, all four stages (modules/detection.py:131-148 →
+maxvit_rnn.py:93-105).  Only the ConvLSTM is recurrent, and stage s at time t depends on stage s-1 at
+the SAME t only, so here each stage processes all T·B frames at once (down-sampling conv + LayerNorm +
+window block + grid block as large batched kernels) and then scans its ConvLSTM over t.  The result is
+bit-for-bit the same dataflow; it only reorders independent work.  Backward runs stages 4→1, each as a
+reverse ConvLSTM scan (BPTT) followed by the batched block / conv backward, so a stage's parameter
+gradients are final as soon as that stage is done (used by rvt_amd.dist to overlap the all-reduce).
+
+Layout: activations [T*B][H][W][C] channels-last in the compute dtype; LSTM cell state fp32.
+`Hall`/`Call` carry T+1 time slots: slot 0 is the incoming state, slot t+1 the state after step t.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import ops
+from .weights import StageWeights, unpack_conv_wgrad
+
+Tensor = torch.Tensor
+
+
+@dataclass
+class StageGeom:
+    C: int
+    Cin: int
+    H_in: int
+    W_in: int
+    k: int
+    stride: int
+    pad: int
+    ph: int
+    pw: int
+    dim_head: int
+    num_blocks: int
+    eps: float
+
+    @property
+    def H(self) -> int:
+        return (self.H_in + 2 * self.pad - self.k) // self.stride + 1
+
+    @property
+    def W(self) -> int:
+        return (self.W_in + 2 * self.pad - self.k) // self.stride + 1
+
+
+class StageSaved:
+    """Activations kept for backward (everything else is recomputed from these)."""
+    __slots__ = ('inp', 'y0', 'blocks', 'x_last', 'Hall', 'Call', 'gates', 'mask')
+
+    def __init__(self):
+        self.blocks: List[Dict[str, Tensor]] = []
+
+
+def stage_seq_forward(sw: StageWeights, g: StageGeom, inp: Tensor, h0: Optional[Tensor], c0: Optional[Tensor],
+                      T: int, B: int, save: bool, token_mask: Optional[Tensor] = None,
+                      mask_token: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Optional[StageSaved]]:
+    """inp: (T*B, H_in, W_in, cin_pad).  Returns Hall (T+1,B,H,W,C), Call (T+1,B,H,W,C) fp32, saved."""
+    F_ = T * B
+    H, W, C = g.H, g.W, g.C
+    dt, dev = inp.dtype, inp.device
+    sv = StageSaved() if save else None
+
+    y0 = ops.conv_fwd(inp, sw.conv_w, g.k, g.stride, g.pad)                      # maxvit.py:175
+    x = ops.layernorm_fwd(y0, sw.ln_w, sw.ln_b, g.eps)                            # maxvit.py:177
+    if token_mask is not None:                                                    # maxvit_rnn.py:174-176
+        x = torch.where(token_mask.reshape(F_, H, W, 1), mask_token.reshape(1, 1, 1, C).to(dt), x)
+    if save:
+        sv.inp, sv.y0, sv.mask = inp, y0, token_mask
+
+    for pair in sw.blocks:
+        for bw, window in ((pair[0], True), (pair[1], False)):
+            u = x if bw['n1_w'] is None else ops.layernorm_fwd(x, bw['n1_w'], bw['n1_b'], g.eps)
+            qkv = ops.linear_fwd(u, bw['qkv_w'], bw['qkv_b'])                     # maxvit.py:347
+            a = ops.attn_fwd(qkv, F_, H, W, C, g.dim_head, g.ph, g.pw, window)    # maxvit.py:349-352
+            xmid = ops.linear_scale_res_fwd(a, bw['proj_w'], bw['proj_b'], bw['g1'], x)        # :353, :268
+            v2 = ops.layernorm_fwd(xmid, bw['n2_w'], bw['n2_b'], g.eps)
+            hd = ops.linear_fwd(v2, bw['fc1_w'], bw['fc1_b'])                     # MLP fc1 (pre-GELU)
+            xout = ops.linear_scale_res_fwd(hd, bw['fc2_w'], bw['fc2_b'], bw['g2'], xmid, gelu_in=True)  # :269
+            if save:
+                sv.blocks.append(dict(xin=x, qkv=qkv, a=a, xmid=xmid, hd=hd))
+            x = xout
+
+    Hall = torch.empty((T + 1, B, H, W, C), dtype=dt, device=dev)
+    Call = torch.empty((T + 1, B, H, W, C), dtype=torch.float32, device=dev)
+    if h0 is None:
+        Hall[0].zero_()                                                           # rnn.py:43-47
+        Call[0].zero_()
+    else:
+        Hall[0].copy_(h0)
+        Call[0].copy_(c0)
+    gates = torch.empty((T, B, H, W, 4 * C), dtype=dt, device=dev) if save else None
+    xt = x.view(T, B, H, W, C)
+    for t in range(T):                                                            # rnn.py:52-67, one launch per step
+        ops.lstm_fwd(xt[t], Hall[t], Call[t], sw.lstm_w, sw.lstm_b, Hall[t + 1], Call[t + 1],
+                     gates[t] if save else None)
+    if save:
+        sv.x_last, sv.Hall, sv.Call, sv.gates = x, Hall, Call, gates
+    return Hall, Call, sv
+
+
+def stage_seq_backward(sw: StageWeights, g: StageGeom, sv: StageSaved, dH: Optional[Tensor], dc_last: Optional[Tensor],
+                       T: int, B: int, need_input_grad: bool, prev_cot: Optional[Tensor],
+                       p: Dict[str, Tensor], pre: str) -> Tuple[Optional[Tensor], Tensor, Tensor, Dict[str, Tensor]]:
+    """dH: (T,B,H,W,C) cotangent of Hall[1:] (None = zeros); dc_last: (B,H,W,C) fp32 cotangent of Call[T].
+    prev_cot: cotangent already attached to this stage's INPUT frames (T*B,H_in,W_in,Cin) (added to the conv dgrad).
+    Returns (d_input or None, dh0, dc0, {param name: fp32 grad})."""
+    F_ = T * B
+    H, W, C = g.H, g.W, g.C
+    dt, dev = sv.y0.dtype, sv.y0.device
+    f32 = torch.float32
+    grads: Dict[str, Tensor] = {}
+    zeros = lambda *shape: torch.zeros(shape, dtype=f32, device=dev)
+
+    # ---- ConvLSTM BPTT ------------------------------------------------------------------------------
+    if dH is None:
+        dH = torch.zeros((T, B, H, W, C), dtype=dt, device=dev)
+    dz = torch.empty((T, B, H, W, 4 * C), dtype=dt, device=dev)
+    dx = torch.empty((T, B, H, W, C), dtype=dt, device=dev)
+    dc_rec = zeros(B, H, W, C) if dc_last is None else dc_last.to(f32).contiguous().clone()
+    dh_rec = None
+    dh_buf = [torch.empty((B, H, W, C), dtype=dt, device=dev) for _ in range(2)]
+    for t in range(T - 1, -1, -1):
+        ops.lstm_gates_bwd(dH[t], dh_rec, dc_rec, sv.gates[t], sv.Call[t + 1], sv.Call[t], dz[t])
+        nxt = dh_buf[t & 1]
+        ops.lstm_dgrad(dz[t], sw.lstm_wt, dx[t], nxt)
+        dh_rec = nxt
+    dwl = zeros(4 * C, 2 * C)
+    ops.lstm_wgrad(dz.view(F_, H, W, 4 * C), sv.x_last, sv.Hall[:T].reshape(F_, H, W, C), dwl)
+    dbl = zeros(4 * C)
+    ops.colsum(dz, dbl)
+    grads[pre + 'lstm.conv1x1.weight'] = dwl.reshape(4 * C, 2 * C, 1, 1)
+    grads[pre + 'lstm.conv1x1.bias'] = dbl
+    dh0, dc0 = dh_rec, dc_rec
+    dx = dx.view(F_, H, W, C)
+    del dz
+
+    # ---- attention blocks, reversed ---------------------------------------------------------------------
+    bi_flat = len(sv.blocks)
+    for pi in range(len(sw.blocks) - 1, -1, -1):
+        for which in (1, 0):
+            bw = sw.blocks[pi][which]
+            window = which == 0
+            bi_flat -= 1
+            s = sv.blocks[bi_flat]
+            bp = f'{pre}att_blocks.{pi}.{"att_window" if window else "att_grid"}.'
+            # MLP branch: xout = xmid + g2 * (gelu(hd) W2^T + b2)
+            S2 = zeros(C, 4 * C)
+            ops.linear_wgrad(dx, s['hd'], S2, gelu_in=True)
+            cs = zeros(C)
+            ops.colsum(dx, cs)
+            grads[bp + 'mlp.net.2.weight'] = bw['g2'][:, None] * S2
+            grads[bp + 'mlp.net.2.bias'] = bw['g2'] * cs
+            grads[bp + 'ls2.gamma'] = (bw['fc2_w32'] * S2).sum(1) + p[bp + 'mlp.net.2.bias'].detach().to(f32) * cs
+            dhd = ops.linear_dgrad(dx, bw['fc2_wt'], gelu_pre=s['hd'])
+            v2 = ops.layernorm_fwd(s['xmid'], bw['n2_w'], bw['n2_b'], g.eps)
+            dW1 = zeros(4 * C, C)
+            ops.linear_wgrad(dhd, v2, dW1)
+            db1 = zeros(4 * C)
+            ops.colsum(dhd, db1)
+            grads[bp + 'mlp.net.0.0.weight'] = dW1
+            grads[bp + 'mlp.net.0.0.bias'] = db1
+            dv2 = ops.linear_dgrad(dhd, bw['fc1_wt'])
+            del dhd, v2
+            dn2w, dn2b = zeros(C), zeros(C)
+            dxmid = ops.layernorm_bwd(s['xmid'], bw['n2_w'], dv2, dx, dn2w, dn2b, g.eps)
+            grads[bp + 'norm2.weight'] = dn2w
+            grads[bp + 'norm2.bias'] = dn2b
+            del dv2
+            # attention branch: xmid = xin + g1 * (a Wp^T + bp)
+            S1 = zeros(C, C)
+            ops.linear_wgrad(dxmid, s['a'], S1)
+            cs1 = zeros(C)
+            ops.colsum(dxmid, cs1)
+            grads[bp + 'self_attn.proj.weight'] = bw['g1'][:, None] * S1
+            grads[bp + 'self_attn.proj.bias'] = bw['g1'] * cs1
+            grads[bp + 'ls1.gamma'] = (bw['proj_w32'] * S1).sum(1) + p[bp + 'self_attn.proj.bias'].detach().to(f32) * cs1
+            da = ops.linear_dgrad(dxmid, bw['proj_wt'])
+            dqkv = ops.attn_bwd(s['qkv'], da, F_, H, W, C, g.dim_head, g.ph, g.pw, window)
+            del da
+            u = s['xin'] if bw['n1_w'] is None else ops.layernorm_fwd(s['xin'], bw['n1_w'], bw['n1_b'], g.eps)
+            dWq = zeros(3 * C, C)
+            ops.linear_wgrad(dqkv, u, dWq)
+            dbq = zeros(3 * C)
+            ops.colsum(dqkv, dbq)
+            grads[bp + 'self_attn.qkv.weight'] = dWq
+            grads[bp + 'self_attn.qkv.bias'] = dbq
+            if bw['n1_w'] is None:
+                dx = ops.linear_dgrad(dqkv, bw['qkv_wt'], add=dxmid)
+            else:
+                du = ops.linear_dgrad(dqkv, bw['qkv_wt'])
+                dn1w, dn1b = zeros(C), zeros(C)
+                dx = ops.layernorm_bwd(s['xin'], bw['n1_w'], du, dxmid, dn1w, dn1b, g.eps)
+                grads[bp + 'norm1.weight'] = dn1w
+                grads[bp + 'norm1.bias'] = dn1b
+                del du
+            del dqkv, dxmid, u
+
+    # ---- token mask, down-sampling LayerNorm + conv ---------------------------------------------------------
+    if sv.mask is not None:
+        m = sv.mask.reshape(F_, H, W, 1)
+        grads[pre + 'mask_token'] = (dx.to(f32) * m).sum((0, 1, 2)).reshape(1, 1, 1, C)
+        dx = torch.where(m, torch.zeros((), dtype=dt, device=dev), dx)
+    dlw, dlb = zeros(C), zeros(C)
+    dy0 = ops.layernorm_bwd(sv.y0, sw.ln_w, dx, None, dlw, dlb, g.eps)
+    grads[pre + 'downsample_cf2cl.norm.weight'] = dlw
+    grads[pre + 'downsample_cf2cl.norm.bias'] = dlb
+    dwc = zeros(C, g.k * g.k * sw.cin_pad)
+    ops.conv_wgrad(sv.inp, dy0, dwc, g.k, g.stride, g.pad)
+    grads[pre + 'downsample_cf2cl.conv.weight'] = unpack_conv_wgrad(dwc, g.Cin, g.k)
+    d_in = None
+    if need_input_grad:
+        d_in = ops.conv_dgrad(dy0, sw.conv_wd, prev_cot, g.H_in, g.W_in, g.Cin, g.k, g.stride, g.pad)
+    return d_in, dh0, dc0, grads
