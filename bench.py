@@ -1,0 +1,273 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: RVT backbone forward + BPTT backward (+ optimizer step, + gradient
+all-reduce when N>1) over one synthetic event-tensor sequence batch.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload base_1mpx|tiny_gen1] [--dtype bf16|f32]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (default): BASELINE.json configs[2] — RVT-Base, 1 Mpx shape (20x360x640 uint8, padded to 384x640
+by the model), T=21, batch=24 per GPU, bf16, random-init weights, inputs resident in HBM.
+A "step" = forward_sequence over (T,B) + backward with random upstream gradients on the stage 2/3/4
+features of all T frames (what the FPN consumes) + fused AdamW on the backbone parameters; with N>1 the
+per-stage gradient buckets are all-reduced over RCCL, overlapped with the remaining backward.
+Metric: event-tensors/s = N*B*T / step time (weak scaling: per-GPU work fixed).
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# ALGORITHMIC matmul FLOPs per event-tensor (SURVEY.md §8d / BASELINE.md §2; 2*MAC of conv+linear+attention,
+# fwd+bwd = 3*fwd - stem dgrad)
+WORKLOADS = {
+    'base_1mpx': dict(size='base', dataset='gen4', hw=(360, 640), T=21, B=24, f_fwd=20.616e9, f_fwdbwd=59.922e9,
+                      label='RVT-Base, 1Mpx 20x360x640 (padded 384x640), T=21, B=24/GPU'),
+    'tiny_gen1': dict(size='tiny', dataset='gen1', hw=(240, 304), T=21, B=8, f_fwd=2.001e9, f_fwdbwd=5.683e9,
+                      label='RVT-Tiny, Gen1 20x240x304 (padded 256x320), T=21, B=8/GPU'),
+}
+PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}     # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+
+
+def linear_flops(M, N, K):
+    return 2.0 * M * N * K
+
+
+class OpTimer:
+    """HIP-event timing of individual C-ABI launches on torch's current stream (the stream the kernels are
+    launched on).  Used for the `roofline` object: per-launch duration of the dominant kernel family."""
+
+    def __init__(self):
+        self.records = {}
+        self.enabled_for = None     # None = all ops, or a set of names
+
+    def install(self):
+        from rvt_amd import _lib
+        self._orig = _lib.call
+        timer = self
+
+        def timed_call(name, *args):
+            if timer.enabled_for is not None and name not in timer.enabled_for:
+                return timer._orig(name, *args)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            timer._orig(name, *args)
+            e1.record()
+            timer.records.setdefault(name, []).append((e0, e1, args))
+        _lib.call = timed_call
+        # ops.py binds `L.call` at call time through the module attribute, so patching _lib.call suffices
+
+    def uninstall(self):
+        from rvt_amd import _lib
+        _lib.call = self._orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, recs in self.records.items():
+            ms = [a.elapsed_time(b) for a, b, _ in recs]
+            out[name] = dict(calls=len(ms), total_ms=sum(ms), avg_ms=sum(ms) / len(ms))
+        return out
+
+
+def gemm_flops_of_call(name, args):
+    """Algorithmic FLOPs of one launch of a GEMM-family entry point, from its own arguments."""
+    if name in ('rvt_linear_fwd',):
+        M, N, K = args[5], args[6], args[7]
+        return linear_flops(M, N, K)
+    if name == 'rvt_linear_scale_res_fwd':
+        M, N, K = args[7], args[8], args[9]
+        return linear_flops(M, N, K)
+    if name == 'rvt_linear_dgrad':
+        M, N, K = args[6], args[7], args[8]
+        return linear_flops(M, N, K)
+    if name == 'rvt_linear_wgrad':
+        M, N, K = args[4], args[5], args[6]
+        return linear_flops(M, N, K)
+    if name in ('rvt_lstm_fwd', 'rvt_lstm_dgrad', 'rvt_lstm_wgrad'):
+        M, C = args[-3], args[-2]
+        return linear_flops(M, 4 * C, 2 * C)
+    return None
+
+
+def build_model(wl, dtype, device):
+    from rvt_amd import RNNDetector, backbone_config
+    torch.manual_seed(0)
+    cfg = backbone_config(wl['size'], wl['dataset'])
+    m = RNNDetector(cfg, compute_dtype=dtype).to(device)
+    return m
+
+
+def make_batch(wl, device, seed):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    xs = torch.randint(0, 11, (wl['T'], wl['B'], 20, *wl['hw']), generator=g, dtype=torch.uint8)
+    return xs.to(device)
+
+
+def cpu_baseline(wl):
+    """The CPU oracle (a port of the reference algorithm, oracle/rvt_oracle.py) timed on this box's host
+    cores on a bounded sample of the same workload: same model size and resolution, reduced B*T."""
+    from oracle import rvt_oracle as O
+    from rvt_amd import backbone_config
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    cfgd = backbone_config(wl['size'], wl['dataset'])
+    cfg = O.OracleCfg(embed_dim=cfgd.embed_dim, dim_head=cfgd.stage.attention.dim_head,
+                      partition_size=tuple(cfgd.stage.attention.partition_size))
+    m = build_model(wl, torch.float32, 'cpu')
+    params = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    B, T = 2, 3
+    g = torch.Generator().manual_seed(1)
+    xs = torch.randint(0, 11, (T, B, 20, *wl['hw']), generator=g, dtype=torch.uint8)
+    best = float('inf')
+    for _ in range(3):
+        t0 = time.perf_counter()
+        feats, _ = O.sequence_forward(xs, None, params, cfg, tuple(cfgd.in_res_hw))
+        loss = sum(feats[t][s].sum() for t in range(T) for s in (2, 3, 4))
+        torch.autograd.grad(loss, list(params.values()), allow_unused=True)
+        best = min(best, time.perf_counter() - t0)
+    return dict(value=round(B * T / best, 3), unit='event-tensors/s', cores=ncores, kind='port',
+                sample=f'{wl["label"].split(",")[0]} same resolution, B={B}, T={T}, fp32, fwd+bwd, best of 3 '
+                       f'({best:.2f} s per pass), torch CPU threads={ncores}')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--workload', default='base_1mpx', choices=list(WORKLOADS))
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--batch', type=int, default=None, help='override per-GPU batch (debug only)')
+    ap.add_argument('--seq', type=int, default=None, help='override T (debug only)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-optimizer', action='store_true')
+    ap.add_argument('--op-breakdown', default=None, help='write a per-op HIP-event time table to this path')
+    args = ap.parse_args()
+
+    wl = dict(WORKLOADS[args.workload])
+    if args.batch:
+        wl['B'] = args.batch
+    if args.seq:
+        wl['T'] = args.seq
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
+    device = torch.device('cuda', local_rank)
+    torch.cuda.set_device(device)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group('nccl', device_id=device)      # "nccl" = RCCL on ROCm
+
+    dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    model = build_model(wl, dtype, device)
+    params = [p for p in model.parameters()]
+    opt = None if args.no_optimizer else torch.optim.AdamW(params, lr=2e-4, fused=True)
+    from rvt_amd.dist import StageGradReducer
+    reducer = StageGradReducer().attach(model) if world > 1 else None
+
+    xs = make_batch(wl, device, seed=1 + rank)
+    T, B = wl['T'], wl['B']
+    geoms = model.stage_geoms(*model.in_res_hw)
+    gen = torch.Generator(device=device).manual_seed(7)
+    cots = {s + 1: torch.randn((T, B, geoms[s].H, geoms[s].W, geoms[s].C), generator=gen, device=device,
+                               dtype=dtype).permute(0, 1, 4, 2, 3) for s in (1, 2, 3)}
+
+    def step():
+        feats, states = model.forward_sequence(xs, None)
+        torch.autograd.backward([feats[s] for s in (2, 3, 4)], [cots[s] for s in (2, 3, 4)])
+        if reducer is not None:
+            reducer.finish()
+        if opt is not None:
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+        else:
+            for p in params:
+                p.grad = None
+
+    def barrier():
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+
+    # which GEMM-family entry point dominates? (one instrumented, untimed step)
+    timer = OpTimer()
+    timer.install()
+    step()
+    prof = timer.summary()
+    dominant = max((n for n in prof if gemm_flops_of_call(n, timer.records[n][0][2]) is not None),
+                   key=lambda n: prof[n]['total_ms'])
+    if args.op_breakdown and rank == 0:
+        with open(args.op_breakdown, 'w') as f:
+            tot = sum(v['total_ms'] for v in prof.values())
+            f.write(f'# per-op HIP-event time of ONE step ({wl["label"]}, {args.dtype}); sum = {tot:.2f} ms\n')
+            for n, v in sorted(prof.items(), key=lambda kv: -kv[1]['total_ms']):
+                f.write(f'{n:28s} calls={v["calls"]:5d} total={v["total_ms"]:9.3f} ms avg={v["avg_ms"]:8.4f} ms '
+                        f'({100 * v["total_ms"] / tot:5.1f} %)\n')
+    timer.records.clear()
+    timer.enabled_for = {dominant}
+
+    barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        step()
+    e1.record()
+    barrier()
+    wall = time.perf_counter() - t0
+    timer.uninstall()
+    if world > 1:
+        tmax = torch.tensor([wall], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        wall = float(tmax.item())
+    ms_per_step = 1e3 * wall / args.steps
+    events_per_s = world * B * T / (wall / args.steps)
+
+    if rank == 0:
+        # roofline of the dominant GEMM entry point: algorithmic FLOPs of its launches / HIP-event time of the
+        # same launches inside the timed region
+        recs = timer.records[dominant]
+        dom_ms = sum(a.elapsed_time(b) for a, b, _ in recs)
+        dom_flops = sum(gemm_flops_of_call(dominant, r[2]) for r in recs)
+        peak = PEAK_TFLOPS[args.dtype]
+        achieved = dom_flops / (dom_ms * 1e-3) / 1e12
+        path_tflops = events_per_s / world * wl['f_fwdbwd'] / 1e12
+        out = {
+            'metric': 'event-tensors/sec (fwd+bwd) RVT-Base T=21 1Mpx; % MFMA roofline' if args.workload == 'base_1mpx'
+            else 'event-tensors/sec (fwd+bwd)',
+            'value': round(events_per_s, 2), 'unit': 'event-tensors/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': wl['label'], 'global_batch': world * B, 'seq_len': T,
+                       'parallelism': f'dp{world}', 'optimizer': 'none' if opt is None else 'AdamW(fused)',
+                       'upstream_grads': 'random cotangents on stage 2-4 features of all T frames'},
+            'mfma_roofline_frac_whole_step': round(path_tflops / peak, 4),
+            'algorithmic_tflops_per_gpu': round(path_tflops, 2),
+            'roofline': {'bound': 'mfma', 'kernel': dominant, 'achieved': round(achieved, 2), 'peak': peak,
+                         'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4), 'traffic': None,
+                         'launches': len(recs), 'avg_launch_ms': round(dom_ms / len(recs), 4),
+                         'share_of_step': round(dom_ms / (ms_per_step * args.steps), 3)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(wl)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

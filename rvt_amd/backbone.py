@@ -282,12 +282,12 @@ class _BackboneSeqFn(torch.autograd.Function):
             d_in, dh0, dc0, grads = stage_seq_backward(ctx.sws[si], g, ctx.svs[si], dH, dc_last, T, B, si > 0,
                                                        prev_cot, ctx.p, f'stages.{si}.')
             d_from_above = d_in
+            if hook is not None:          # e.g. rvt_amd.dist.StageGradReducer: start this stage's all-reduce now
+                hook(si, grads)
             grads_by_name.update(grads)
             if ctx.needs_input_grad[3 + 2 * si]:
                 state_grads[2 * si] = dh0.permute(0, 3, 1, 2)
                 state_grads[2 * si + 1] = dc0.permute(0, 3, 1, 2)
-            if hook is not None:
-                hook(si, grads)
             ctx.svs[si] = None
         pgrads = []
         for i, n in enumerate(mod._param_names):
