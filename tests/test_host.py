@@ -1,0 +1,132 @@
+"""CPU-only host-logic tests: C-ABI exports, loader behaviour without a GPU, state bookkeeping,
+training-step glue, config derivation, and the world_size-2 gradient reducer over gloo."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+import rvt_amd
+from rvt_amd import _lib, backbone_config
+from rvt_amd.states import RNNStates, merge_mixed_batches
+from rvt_amd.types import DataType, DatasetSamplingMode
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    hdr = open(os.path.join(ROOT, 'include', 'rvt_hip.h')).read()
+    return sorted(set(re.findall(r'\b(rvt_[a-z0-9_]+)\s*\(', hdr)))
+
+
+def test_header_and_binding_agree():
+    assert declared_symbols() == _lib.EXPORTS
+
+
+def test_hip_library_loads_and_exports_every_symbol():
+    """The gfx950 build must dlopen on a GPU-less host and export everything include/rvt_hip.h declares
+    (no compute call is made)."""
+    if not os.path.exists(_lib.LIB_PATH):
+        subprocess.run(['bash', os.path.join(ROOT, 'rvt_amd', 'csrc', 'build.sh')], check=True, capture_output=True)
+    lib = _lib.load_library()
+    for sym in declared_symbols():
+        assert hasattr(lib, sym), sym
+    assert lib.rvt_is_emulator() == 0
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='checks the GPU-less failure mode')
+def test_product_path_fails_loudly_without_gpu():
+    """No CPU fallback: with no GPU the package must raise, never silently compute elsewhere."""
+    _lib._install_test_library(None)
+    m = rvt_amd.RNNDetector(backbone_config('tiny', 'gen1'))
+    x = torch.zeros(1, 20, 240, 304)
+    with pytest.raises(RuntimeError, match='no CPU fallback|needs an AMD GPU|CUDA'):
+        m(x)
+
+
+def test_config_derivation_matches_reference_modifier():
+    """config/modifier.py:28-41: Gen1 240x304 -> 256x320, partition (8,10); 1Mpx 360x640 -> 384x640, (6,10)."""
+    g1 = backbone_config('tiny', 'gen1')
+    assert tuple(g1.in_res_hw) == (256, 320) and tuple(g1.stage.attention.partition_size) == (8, 10)
+    g4 = backbone_config('base', 'gen4')
+    assert tuple(g4.in_res_hw) == (384, 640) and tuple(g4.stage.attention.partition_size) == (6, 10)
+    assert backbone_config('small', 'gen1').stage.attention.dim_head == 24
+
+
+def test_module_surface_matches_reference():
+    m = rvt_amd.RNNDetector(backbone_config('base', 'gen4'))
+    assert m.stage_dims == [64, 128, 256, 512] and m.strides == [4, 8, 16, 32] and m.num_stages == 4
+    assert m.get_stage_dims((2, 3, 4)) == (128, 256, 512) and m.get_strides((2, 3, 4)) == (8, 16, 32)
+    n_params = sum(p.numel() for p in m.parameters())
+    assert n_params == 12_783_168 or abs(n_params - 12.78e6) < 0.02e6      # 12.78 M (Base backbone)
+    sd = m.state_dict()
+    assert 'stages.0.att_blocks.0.att_window.norm1.weight' not in sd          # Identity for the first window block
+    assert 'stages.0.att_blocks.0.att_grid.norm1.weight' in sd
+    assert tuple(sd['stages.3.lstm.conv1x1.weight'].shape) == (2048, 1024, 1, 1)
+    assert float(sd['stages.1.att_blocks.0.att_grid.ls2.gamma'][0]) == pytest.approx(1e-5)
+    with pytest.raises(AssertionError):
+        m.get_stage_dims((0,))
+
+
+def test_rnn_states_semantics():
+    st = RNNStates()
+    assert st.get_states(0) is None
+    st.reset(0, torch.tensor([True, False]))            # no-op before first save
+    h = torch.ones(2, 4, 3, 3, requires_grad=True) * 2
+    c = torch.ones(2, 4, 3, 3)
+    st.save_states_and_detach(0, [(h, c)] * 4)
+    got = st.get_states(0)
+    assert got[0][0].requires_grad is False
+    assert st.get_states(1) is None
+    st.reset(0, torch.tensor([True, False]))
+    assert float(st.get_states(0)[0][0][0].abs().sum()) == 0 and float(st.get_states(0)[0][0][1].sum()) == 2 * 36
+    st.reset(0, [1])
+    assert float(st.get_states(0)[0][1].abs().sum()) == 0
+
+
+def test_merge_mixed_batches():
+    a = {'worker_id': 3, 'data': {DataType.EV_REPR: [torch.zeros(2, 1)], DataType.IS_FIRST_SAMPLE: torch.tensor([True, False])}}
+    b = {'worker_id': 9, 'data': {DataType.EV_REPR: [torch.ones(1, 1)], DataType.IS_FIRST_SAMPLE: torch.tensor([True])}}
+    out = merge_mixed_batches({DatasetSamplingMode.STREAM: a, DatasetSamplingMode.RANDOM: b})
+    assert out['worker_id'] == 3
+    assert out['data'][DataType.EV_REPR][0].shape == (3, 1)
+    assert out['data'][DataType.IS_FIRST_SAMPLE].tolist() == [True, False, True]
+    assert merge_mixed_batches(a) is a
+
+
+REDUCER_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from rvt_amd.dist import StageGradReducer
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+dist.init_process_group('gloo')
+red = StageGradReducer()
+class M: pass
+m = M(); red.attach(m)
+torch.manual_seed(0)
+ref = {s: {f'stages.{s}.w': torch.randn(5, 3), f'stages.{s}.b': torch.randn(7)} for s in range(4)}
+mine = {s: {k: v * (rank + 1) for k, v in g.items()} for s, g in ref.items()}
+for s in (3, 2, 1, 0):                     # backward order: stage 4 first
+    m._stage_grad_hook(s, mine[s])
+red.finish()
+scale = sum(r + 1 for r in range(world)) / world
+for s in range(4):
+    for k in ref[s]:
+        assert torch.allclose(mine[s][k], ref[s][k] * scale, atol=1e-6), (s, k)
+        assert mine[s][k].shape == ref[s][k].shape
+dist.destroy_process_group()
+print('OK', rank)
+'''
+
+
+def test_stage_grad_reducer_world2_gloo(tmp_path):
+    script = tmp_path / 'w.py'
+    script.write_text(REDUCER_WORKER)
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+                        '--master-addr', '127.0.0.1', '--master-port', '29731', str(script), ROOT],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count('OK') == 2
