@@ -19,6 +19,7 @@
 // (64 x BN/2) = 2 x (BN/64) MFMA 32x32 blocks; K tile = 128 bytes (64 bf16 / 32 f32), register-staged
 // double buffering (global->VGPR for tile k+1 is issued before the MFMAs of tile k).
 #pragma once
+#include <type_traits>
 #include "common.hpp"
 
 namespace rvt {
@@ -151,54 +152,78 @@ template <class T, int ROWS, class Src, class Xf> struct NTLoader {
 };
 
 // Transposing loader: tile row = source COLUMN (feature), contraction = source ROW (token).
-template <class T, int ROWS, class Src, class Xf> struct TNLoader {
-    static constexpr int V = 4 / (int)sizeof(T);          // features per 4-byte load: 2 (bf16) / 1 (f32)
-    static constexpr int FPR = TileGeom<T>::FPR;
-    static constexpr int RG = ROWS / V;                   // row groups per tile
-    static constexpr int NU = RG * FPR / 256;             // units per thread
-    int seg[NU], off[NU];
-    bool fvalid[NU];
-    frag_t<T> r[NU][V];
-    __device__ __forceinline__ void init(const Src& s, int row0, int tid) {
+// Work unit = 8 features x 8 tokens: eight 16-byte (bf16) / 32-byte (f32) row-contiguous loads, an 8x8
+// transpose in registers, eight frag stores (one per feature, 8 consecutive tokens each).  Lanes run along the
+// feature axis, so a wave's loads cover whole 256-byte row segments.  A tile has (ROWS/8)*(BK/8) <= 128 units;
+// the A loader uses the low threads and the B loader the high threads so both halves of the workgroup load.
+template <class T> struct Transpose8;
+template <> struct Transpose8<float> {
+    static __device__ __forceinline__ void run(const f32x8 (&in)[8], f32x8 (&out)[8]) {
 #pragma unroll
-        for (int i = 0; i < NU; i++) {
-            int u = tid + i * 256;
-            int feat = row0 + (u % RG) * V;
-            fvalid[i] = feat < s.cols;
-            s.split(fvalid[i] ? feat : 0, seg[i], off[i]);
+        for (int f = 0; f < 8; f++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) out[f][j] = in[j][f];
+    }
+};
+template <> struct Transpose8<bf16> {
+    static __device__ __forceinline__ void run(const bf16x8 (&in)[8], bf16x8 (&out)[8]) {
+        // 16-bit 8x8 transpose on packed dwords: out[f].dword[q] = { in[2q].half[f], in[2q+1].half[f] }
+        u32x4 w[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) w[j] = *reinterpret_cast<const u32x4*>(&in[j]);
+#pragma unroll
+        for (int f = 0; f < 8; f++) {
+            u32x4 o;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                uint32_t a = w[2 * q][f >> 1], b = w[2 * q + 1][f >> 1];
+                o[q] = (f & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
+            }
+            out[f] = *reinterpret_cast<const bf16x8*>(&o);
+        }
+    }
+};
+
+template <class T, int ROWS, class Src, class Xf, bool HIGH> struct TNLoader {
+    static constexpr int FPR = TileGeom<T>::FPR;          // token chunks (of 8) per K tile
+    static constexpr int FC = ROWS / 8;                   // feature chunks per tile
+    static constexpr int NUNITS = FC * FPR;               // <= 128
+    static_assert(NUNITS <= 256, "tile too large for one unit per thread");
+    int u;                                                // this thread's unit or -1
+    int seg, off;
+    bool fvalid;
+    frag_t<T> r[8];
+    __device__ __forceinline__ void init(const Src& s, int row0, int tid) {
+        u = HIGH ? tid - (256 - NUNITS) : tid;
+        if (u >= NUNITS) u = -1;
+        seg = 0; off = 0; fvalid = false;
+        if (u >= 0) {
+            int feat = row0 + (u % FC) * 8;
+            fvalid = feat < s.cols;
+            if (fvalid) s.split(feat, seg, off);
         }
     }
     __device__ __forceinline__ void load(const Src& s, const Xf& xf, int k0, int kend, int tid) {
+        if (u < 0) return;
+        frag_t<T> in[8];
+        const int tok0 = k0 + (u / FC) * 8;
 #pragma unroll
-        for (int i = 0; i < NU; i++) {
-            int u = tid + i * 256;
-            int tok0 = k0 + (u / RG) * 8;
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                int tok = tok0 + j;
-                float v[V];
-#pragma unroll
-                for (int e = 0; e < V; e++) v[e] = 0.0f;
-                if (fvalid[i] && tok < kend) {
-                    typename Src::Ctx c = s.row_ctx(tok);
-                    const T* p = s.seg_ptr(c, seg[i]);
-                    if (p) {
-#pragma unroll
-                        for (int e = 0; e < V; e++) v[e] = xf((float)p[off[i] + e]);
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < V; e++) r[i][e][j] = (T)v[e];
+        for (int j = 0; j < 8; j++) {
+            frag_t<T> v = frag_zero<T>();
+            const int tok = tok0 + j;
+            if (fvalid && tok < kend) {
+                typename Src::Ctx c = s.row_ctx(tok);
+                const T* p = s.seg_ptr(c, seg);
+                if (p) v = xf_apply<T>(frag_load<T>(p + off), xf);
             }
+            in[j] = v;
         }
+        Transpose8<T>::run(in, r);
     }
     __device__ __forceinline__ void store(char* tile, int tid) const {
+        if (u < 0) return;
 #pragma unroll
-        for (int i = 0; i < NU; i++) {
-            int u = tid + i * 256;
-#pragma unroll
-            for (int e = 0; e < V; e++) tile_store_frag<T>(tile, (u % RG) * V + e, u / RG, r[i][e]);
-        }
+        for (int f = 0; f < 8; f++) tile_store_frag<T>(tile, (u % FC) * 8 + f, u / FC, r[f]);
     }
 };
 
@@ -342,8 +367,8 @@ gemm_kernel(ASrc as, AXf axf, BSrc bs, BXf bxf, Ep ep, int M, int N, int K, int 
     const int kbeg = blockIdx.y * ksplit_len;
     const int kend = (kbeg + ksplit_len < K) ? kbeg + ksplit_len : K;
 
-    typedef typename std::conditional<TN, TNLoader<T, BM, ASrc, AXf>, NTLoader<T, BM, ASrc, AXf>>::type LA;
-    typedef typename std::conditional<TN, TNLoader<T, BN, BSrc, BXf>, NTLoader<T, BN, BSrc, BXf>>::type LB;
+    typedef typename std::conditional<TN, TNLoader<T, BM, ASrc, AXf, false>, NTLoader<T, BM, ASrc, AXf>>::type LA;
+    typedef typename std::conditional<TN, TNLoader<T, BN, BSrc, BXf, true>, NTLoader<T, BN, BSrc, BXf>>::type LB;
     LA la; LB lb;
     la.init(as, m0, tid);
     lb.init(bs, n0, tid);
