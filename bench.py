@@ -246,6 +246,16 @@ def main():
             for n, v in sorted(prof.items(), key=lambda kv: -kv[1]['total_ms']):
                 f.write(f'{n:28s} calls={v["calls"]:5d} total={v["total_ms"]:9.3f} ms avg={v["avg_ms"]:8.4f} ms '
                         f'({100 * v["total_ms"] / tot:5.1f} %)\n')
+            f.write('# by (op, integer args after the pointers) — which stage / shape the time goes to\n')
+            by = {}
+            for n, recs in timer.records.items():
+                for a, b, ar in recs:
+                    key = (n, tuple(x for x in ar if isinstance(x, int) and not isinstance(x, bool) and 0 <= x < (1 << 31))[-8:])
+                    e = by.setdefault(key, [0, 0.0])
+                    e[0] += 1
+                    e[1] += a.elapsed_time(b)
+            for (n, key), (cnt, ms) in sorted(by.items(), key=lambda kv: -kv[1][1])[:60]:
+                f.write(f'{n:28s} {str(key):60s} calls={cnt:4d} total={ms:9.3f} ms\n')
     timer.records.clear()
     timer.enabled_for = {dominant}
 

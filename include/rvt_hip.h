@@ -64,9 +64,10 @@ int rvt_linear_scale_res_fwd(const void* x, const void* w, const float* bias, co
  * (add nullable; not combinable with gelu_pre). */
 int rvt_linear_dgrad(const void* dy, const void* wt, const void* gelu_pre, const void* add, void* dx, int dtype, int M,
                      int N, int K, void* stream);
-/* dw[N][K] (float32) += dy[M][N]^T f(x)[M][K]. */
-int rvt_linear_wgrad(const void* dy, const void* x, float* dw, int dtype, int M, int N, int K, int gelu_in,
-                     void* stream);
+/* dw[N][K] (float32) += dy[M][N]^T f(x)[M][K];  if dy_colsum != NULL also dy_colsum[N] += column sums of dy
+ * (the bias gradient), computed from the tiles the kernel streams anyway. */
+int rvt_linear_wgrad(const void* dy, const void* x, float* dw, float* dy_colsum, int dtype, int M, int N, int K,
+                     int gelu_in, void* stream);
 /* out[N] (float32) += column sums of x[rows][N]. */
 int rvt_colsum(const void* x, float* out, int dtype, int rows, int N, void* stream);
 
@@ -88,8 +89,9 @@ int rvt_lstm_gates_bwd(const void* dh_in, const void* dh_rec, float* dc_rec, con
                        const float* c_prev, void* dz, int dtype, int M, int C, void* stream);
 /* [dx | dh_rec] = dz W : wt = W^T [2C][4C] natural gate order. */
 int rvt_lstm_dgrad(const void* dz, const void* wt, void* dx, void* dh_rec, int dtype, int M, int C, void* stream);
-/* dw[4C][2C] (float32) += dz^T [x | h_prev]. */
-int rvt_lstm_wgrad(const void* dz, const void* x, const void* h_prev, float* dw, int dtype, int M, int C, void* stream);
+/* dw[4C][2C] (float32) += dz^T [x | h_prev];  dz_colsum[4C] += column sums of dz if non-NULL (bias gradient). */
+int rvt_lstm_wgrad(const void* dz, const void* x, const void* h_prev, float* dw, float* dz_colsum, int dtype, int M,
+                   int C, void* stream);
 
 /* Zero state rows of samples with mask[b] != 0 (modules/utils/detection.py:96-113).
  * st is [B][per_sample] of float32 (is_f32) or `dtype`. */

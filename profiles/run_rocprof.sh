@@ -9,11 +9,14 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline"
-timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
-timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o fetch -- $BENCH > $OUT/fetch.log 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o write -- $BENCH > $OUT/write.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o fetch -- $BENCH > $OUT/fetch.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o write -- $BENCH > $OUT/write.log 2>&1
 find $OUT -type f | head -50
 # keep only what fits the 64 MiB pull limit: stats + compacted per-kernel aggregates
 python $ROOT/profiles/summarize_rocprof.py $OUT > $OUT/summary_$TAG.txt 2>&1
 cat $OUT/summary_$TAG.txt | head -80
-find $OUT -name '*.csv' -size +8M -delete
+find $OUT -name '*.db' -delete
+find $OUT -name '*.csv' -size +4M -delete
+tail -5 $OUT/trace.log
+du -sh $OUT

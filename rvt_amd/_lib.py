@@ -32,14 +32,14 @@ _SIGS = {
     'rvt_linear_fwd': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     'rvt_linear_scale_res_fwd': [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     'rvt_linear_dgrad': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
-    'rvt_linear_wgrad': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    'rvt_linear_wgrad': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     'rvt_colsum': [_vp, _vp, _i, _i, _i, _vp],
     'rvt_attn_fwd': [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     'rvt_attn_bwd': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     'rvt_lstm_fwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     'rvt_lstm_gates_bwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     'rvt_lstm_dgrad': [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
-    'rvt_lstm_wgrad': [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    'rvt_lstm_wgrad': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     'rvt_state_reset_masked': [_vp, _vp, _i, _i, _sz, _vp],
 }
 EXPORTS = sorted(list(_SIGS) + ['rvt_last_error', 'rvt_is_emulator'])

@@ -177,7 +177,7 @@ int rvt_layernorm_bwd(const void* x, const float* w, const void* dy, const void*
     hipStream_t st = (hipStream_t)stream;
     int G = pow2_ge(C / 8);
     int rows_per_block = 4 * (64 / G);
-    int grid = imin(1024, imax(1, (rows + rows_per_block - 1) / rows_per_block));
+    int grid = imin(512, imax(1, (rows + rows_per_block - 1) / rows_per_block));
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ln_bwd_kernel<T>), dim3(grid), dim3(256), 0, st, (const T*)x, w,
                                              (const T*)dy, (const T*)dres, (T*)dx, dw, db, rows, C, G, eps));
     return check_launch("layernorm_bwd");
@@ -251,8 +251,8 @@ int rvt_linear_dgrad(const void* dy, const void* wt, const void* gelu_pre, const
     return check_launch("linear_dgrad");
 }
 
-int rvt_linear_wgrad(const void* dy, const void* x, float* dw, int dtype, int M, int N, int K, int gelu_in,
-                     void* stream) {
+int rvt_linear_wgrad(const void* dy, const void* x, float* dw, float* dy_colsum, int dtype, int M, int N, int K,
+                     int gelu_in, void* stream) {
     RVT_CHECK(N % 8 == 0 && K % 8 == 0, "linear_wgrad: N=%d K=%d must be multiples of 8", N, K);
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_DTYPE(dtype, {
@@ -261,8 +261,8 @@ int rvt_linear_wgrad(const void* dy, const void* x, float* dw, int dtype, int M,
         EpAtomicF32 ep{dw, K};
         DISPATCH_BN(K, {
             int ks = wgrad_ksplit(N, K, M, BN);
-            if (gelu_in) launch_gemm<T, BN, true>(a, XfNone(), b, XfGelu(), ep, N, K, M, ks, st);
-            else launch_gemm<T, BN, true>(a, XfNone(), b, XfNone(), ep, N, K, M, ks, st);
+            if (gelu_in) launch_gemm<T, BN, true>(a, XfNone(), b, XfGelu(), ep, N, K, M, ks, st, dy_colsum);
+            else launch_gemm<T, BN, true>(a, XfNone(), b, XfNone(), ep, N, K, M, ks, st, dy_colsum);
         });
     });
     return check_launch("linear_wgrad");
@@ -350,7 +350,8 @@ int rvt_lstm_dgrad(const void* dz, const void* wt, void* dx, void* dh_rec, int d
     return check_launch("lstm_dgrad");
 }
 
-int rvt_lstm_wgrad(const void* dz, const void* x, const void* h_prev, float* dw, int dtype, int M, int C, void* stream) {
+int rvt_lstm_wgrad(const void* dz, const void* x, const void* h_prev, float* dw, float* dz_colsum, int dtype, int M,
+                   int C, void* stream) {
     RVT_CHECK(C % 8 == 0, "lstm_wgrad: C=%d must be a multiple of 8", C);
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_DTYPE(dtype, {
@@ -358,7 +359,7 @@ int rvt_lstm_wgrad(const void* dz, const void* x, const void* h_prev, float* dw,
         ConcatSrc<T> b{(const T*)x, (const T*)h_prev, C, M, 2 * C};
         EpAtomicF32 ep{dw, 2 * C};
         DISPATCH_BN(2 * C, (launch_gemm<T, BN, true>(a, XfNone(), b, XfNone(), ep, 4 * C, 2 * C, M,
-                                                     wgrad_ksplit(4 * C, 2 * C, M, BN), st)));
+                                                     wgrad_ksplit(4 * C, 2 * C, M, BN), st, dz_colsum)));
     });
     return check_launch("lstm_wgrad");
 }

@@ -149,6 +149,7 @@ template <class T, int ROWS, class Src, class Xf> struct NTLoader {
             tile_store_frag<T>(tile, u / FPR, u % FPR, r[i]);
         }
     }
+    __device__ __forceinline__ void flush_colsum(float*, int) const {}
 };
 
 // Transposing loader: tile row = source COLUMN (feature), contraction = source ROW (token).
@@ -193,10 +194,13 @@ template <class T, int ROWS, class Src, class Xf, bool HIGH> struct TNLoader {
     int seg, off;
     bool fvalid;
     frag_t<T> r[8];
+    float csum[8];                                        // running sum over tokens of this unit's 8 features
     __device__ __forceinline__ void init(const Src& s, int row0, int tid) {
         u = HIGH ? tid - (256 - NUNITS) : tid;
         if (u >= NUNITS) u = -1;
         seg = 0; off = 0; fvalid = false;
+#pragma unroll
+        for (int f = 0; f < 8; f++) csum[f] = 0.f;
         if (u >= 0) {
             int feat = row0 + (u % FC) * 8;
             fvalid = feat < s.cols;
@@ -217,8 +221,16 @@ template <class T, int ROWS, class Src, class Xf, bool HIGH> struct TNLoader {
                 if (p) v = xf_apply<T>(frag_load<T>(p + off), xf);
             }
             in[j] = v;
+#pragma unroll
+            for (int f = 0; f < 8; f++) csum[f] += (float)v[f];
         }
         Transpose8<T>::run(in, r);
+    }
+    // out[feature] += token sums seen by this thread (bias gradient = column sum of dY); call once at the end
+    __device__ __forceinline__ void flush_colsum(float* out, int row0) const {
+        if (u < 0 || !fvalid) return;
+#pragma unroll
+        for (int f = 0; f < 8; f++) atomicAdd(out + row0 + (u % FC) * 8 + f, csum[f]);
     }
     __device__ __forceinline__ void store(char* tile, int tid) const {
         if (u < 0) return;
@@ -354,7 +366,8 @@ template <int BN> struct GemmSmem {
 
 template <class T, int BN, bool TN, class ASrc, class AXf, class BSrc, class BXf, class Ep>
 __global__ void __launch_bounds__(256)
-gemm_kernel(ASrc as, AXf axf, BSrc bs, BXf bxf, Ep ep, int M, int N, int K, int n_tiles, int ksplit_len) {
+gemm_kernel(ASrc as, AXf axf, BSrc bs, BXf bxf, Ep ep, int M, int N, int K, int n_tiles, int ksplit_len,
+            float* a_colsum) {
     constexpr int BM = 128;
     constexpr int BK = TileGeom<T>::BK;
     constexpr int WN = BN / 64;
@@ -418,6 +431,8 @@ gemm_kernel(ASrc as, AXf axf, BSrc bs, BXf bxf, Ep ep, int M, int N, int K, int 
         __syncthreads();
     }
 
+    if (TN && a_colsum != nullptr && n0 == 0) la.flush_colsum(a_colsum, m0);
+
     // ---- epilogue: accumulators -> LDS (fp32, row pitch BN+4) -> UNIT-wide row segments ----
     float* stage = reinterpret_cast<float*>(smem);
     constexpr int LDS_LD = BN + 4;
@@ -448,7 +463,7 @@ gemm_kernel(ASrc as, AXf axf, BSrc bs, BXf bxf, Ep ep, int M, int N, int K, int 
 
 template <class T, int BN, bool TN, class ASrc, class AXf, class BSrc, class BXf, class Ep>
 inline void launch_gemm(const ASrc& as, const AXf& axf, const BSrc& bs, const BXf& bxf, const Ep& ep,
-                        int M, int N, int K, int ksplit, hipStream_t stream) {
+                        int M, int N, int K, int ksplit, hipStream_t stream, float* a_colsum = nullptr) {
     const int BK = TileGeom<T>::BK;
     int n_tiles = (N + BN - 1) / BN;
     int m_tiles = (M + 127) / 128;
@@ -458,7 +473,7 @@ inline void launch_gemm(const ASrc& as, const AXf& axf, const BSrc& bs, const BX
     int nsplit = (K + klen - 1) / klen;
     if (nsplit < 1) nsplit = 1;
     hipLaunchKernelGGL((gemm_kernel<T, BN, TN, ASrc, AXf, BSrc, BXf, Ep>), dim3(m_tiles * n_tiles, nsplit), dim3(256), 0,
-                       stream, as, axf, bs, bxf, ep, M, N, K, n_tiles, klen);
+                       stream, as, axf, bs, bxf, ep, M, N, K, n_tiles, klen, a_colsum);
 }
 
 }  // namespace rvt

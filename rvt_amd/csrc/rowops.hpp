@@ -108,14 +108,22 @@ ln_bwd_kernel(const T* __restrict__ x, const float* __restrict__ w, const T* __r
             frag_store<T>(dx + (size_t)row * C + cl * 8, frag_from_float<T>(o));
         }
     }
-    // fold the 64/G row-lanes of this wave that own the same columns, then one atomic per column per wave
+    // fold the 64/G row-lanes of a wave that own the same columns, then the 4 waves through LDS:
+    // one atomic per column per WORKGROUP (same-address atomics serialise at the L2)
+    __shared__ float red[4][2][512];
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         for (int m = G; m < 64; m <<= 1) { aw[i] += __shfl_xor(aw[i], m); ab[i] += __shfl_xor(ab[i], m); }
     }
+    const int wave = threadIdx.x >> 6;
     if (cvalid && lane < G) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) { atomicAdd(dw + cl * 8 + i, aw[i]); atomicAdd(db + cl * 8 + i, ab[i]); }
+        for (int i = 0; i < 8; i++) { red[wave][0][cl * 8 + i] = aw[i]; red[wave][1][cl * 8 + i] = ab[i]; }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        atomicAdd(dw + c, red[0][0][c] + red[1][0][c] + red[2][0][c] + red[3][0][c]);
+        atomicAdd(db + c, red[0][1][c] + red[1][1][c] + red[2][1][c] + red[3][1][c]);
     }
 }
 

@@ -116,13 +116,15 @@ def linear_dgrad(dy: Tensor, wt: Tensor, gelu_pre: Optional[Tensor] = None, add:
     return dx
 
 
-def linear_wgrad(dy: Tensor, x: Tensor, dw: Tensor, gelu_in: bool = False) -> None:
+def linear_wgrad(dy: Tensor, x: Tensor, dw: Tensor, gelu_in: bool = False, colsum_out: Optional[Tensor] = None) -> None:
+    """dw += dy^T f(x); colsum_out (fp32 [N]) += column sums of dy when given (bias gradient, same pass)."""
     N = dy.shape[-1]
     K = x.shape[-1]
     M = dy.numel() // N
     assert dw.dtype == torch.float32 and tuple(dw.shape) == (N, K) and x.numel() // K == M
-    L.call('rvt_linear_wgrad', L.ptr(dy), L.ptr(x), L.ptr(dw), L.dtype_code(dy.dtype), M, N, K, int(gelu_in),
-           L.stream_of(dy))
+    assert colsum_out is None or (colsum_out.dtype == torch.float32 and colsum_out.numel() == N)
+    L.call('rvt_linear_wgrad', L.ptr(dy), L.ptr(x), L.ptr(dw), L.ptr(colsum_out), L.dtype_code(dy.dtype), M, N, K,
+           int(gelu_in), L.stream_of(dy))
 
 
 def colsum(x: Tensor, out: Tensor) -> None:
@@ -171,12 +173,12 @@ def lstm_dgrad(dz: Tensor, wt: Tensor, dx: Tensor, dh_rec: Tensor) -> None:
            L.stream_of(dz))
 
 
-def lstm_wgrad(dz: Tensor, x: Tensor, h_prev: Tensor, dw: Tensor) -> None:
+def lstm_wgrad(dz: Tensor, x: Tensor, h_prev: Tensor, dw: Tensor, colsum_out: Optional[Tensor] = None) -> None:
     C = x.shape[-1]
     M = x.numel() // C
     assert dw.dtype == torch.float32 and tuple(dw.shape) == (4 * C, 2 * C)
-    L.call('rvt_lstm_wgrad', L.ptr(dz), L.ptr(x), L.ptr(h_prev), L.ptr(dw), L.dtype_code(dz.dtype), M, C,
-           L.stream_of(dz))
+    L.call('rvt_lstm_wgrad', L.ptr(dz), L.ptr(x), L.ptr(h_prev), L.ptr(dw), L.ptr(colsum_out), L.dtype_code(dz.dtype),
+           M, C, L.stream_of(dz))
 
 
 def state_reset_masked(st: Tensor, mask: Tensor) -> None:

@@ -130,9 +130,8 @@ def stage_seq_backward(sw: StageWeights, g: StageGeom, sv: StageSaved, dH: Optio
         ops.lstm_dgrad(dz[t], sw.lstm_wt, dx[t], nxt)
         dh_rec = nxt
     dwl = zeros(4 * C, 2 * C)
-    ops.lstm_wgrad(dz.view(F_, H, W, 4 * C), sv.x_last, sv.Hall[:T].reshape(F_, H, W, C), dwl)
     dbl = zeros(4 * C)
-    ops.colsum(dz, dbl)
+    ops.lstm_wgrad(dz.view(F_, H, W, 4 * C), sv.x_last, sv.Hall[:T].reshape(F_, H, W, C), dwl, dbl)
     grads[pre + 'lstm.conv1x1.weight'] = dwl.reshape(4 * C, 2 * C, 1, 1)
     grads[pre + 'lstm.conv1x1.bias'] = dbl
     dh0, dc0 = dh_rec, dc_rec
@@ -150,18 +149,16 @@ def stage_seq_backward(sw: StageWeights, g: StageGeom, sv: StageSaved, dH: Optio
             bp = f'{pre}att_blocks.{pi}.{"att_window" if window else "att_grid"}.'
             # MLP branch: xout = xmid + g2 * (gelu(hd) W2^T + b2)
             S2 = zeros(C, 4 * C)
-            ops.linear_wgrad(dx, s['hd'], S2, gelu_in=True)
             cs = zeros(C)
-            ops.colsum(dx, cs)
+            ops.linear_wgrad(dx, s['hd'], S2, gelu_in=True, colsum_out=cs)
             grads[bp + 'mlp.net.2.weight'] = bw['g2'][:, None] * S2
             grads[bp + 'mlp.net.2.bias'] = bw['g2'] * cs
             grads[bp + 'ls2.gamma'] = (bw['fc2_w32'] * S2).sum(1) + p[bp + 'mlp.net.2.bias'].detach().to(f32) * cs
             dhd = ops.linear_dgrad(dx, bw['fc2_wt'], gelu_pre=s['hd'])
             v2 = ops.layernorm_fwd(s['xmid'], bw['n2_w'], bw['n2_b'], g.eps)
             dW1 = zeros(4 * C, C)
-            ops.linear_wgrad(dhd, v2, dW1)
             db1 = zeros(4 * C)
-            ops.colsum(dhd, db1)
+            ops.linear_wgrad(dhd, v2, dW1, colsum_out=db1)
             grads[bp + 'mlp.net.0.0.weight'] = dW1
             grads[bp + 'mlp.net.0.0.bias'] = db1
             dv2 = ops.linear_dgrad(dhd, bw['fc1_wt'])
@@ -173,9 +170,8 @@ def stage_seq_backward(sw: StageWeights, g: StageGeom, sv: StageSaved, dH: Optio
             del dv2
             # attention branch: xmid = xin + g1 * (a Wp^T + bp)
             S1 = zeros(C, C)
-            ops.linear_wgrad(dxmid, s['a'], S1)
             cs1 = zeros(C)
-            ops.colsum(dxmid, cs1)
+            ops.linear_wgrad(dxmid, s['a'], S1, colsum_out=cs1)
             grads[bp + 'self_attn.proj.weight'] = bw['g1'][:, None] * S1
             grads[bp + 'self_attn.proj.bias'] = bw['g1'] * cs1
             grads[bp + 'ls1.gamma'] = (bw['proj_w32'] * S1).sum(1) + p[bp + 'self_attn.proj.bias'].detach().to(f32) * cs1
@@ -184,9 +180,8 @@ def stage_seq_backward(sw: StageWeights, g: StageGeom, sv: StageSaved, dH: Optio
             del da
             u = s['xin'] if bw['n1_w'] is None else ops.layernorm_fwd(s['xin'], bw['n1_w'], bw['n1_b'], g.eps)
             dWq = zeros(3 * C, C)
-            ops.linear_wgrad(dqkv, u, dWq)
             dbq = zeros(3 * C)
-            ops.colsum(dqkv, dbq)
+            ops.linear_wgrad(dqkv, u, dWq, colsum_out=dbq)
             grads[bp + 'self_attn.qkv.weight'] = dWq
             grads[bp + 'self_attn.qkv.bias'] = dbq
             if bw['n1_w'] is None:

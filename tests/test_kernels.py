@@ -89,7 +89,9 @@ def test_linear_dgrad(backend, dt, with_gelu):
 def test_linear_wgrad(backend, dt, M, N, K, gelu):
     dy, x = rnd((M, N), backend, dt, 1), rnd((M, K), backend, dt, 2)
     dw = torch.zeros(N, K, device=backend)
-    ops.linear_wgrad(dy, x, dw, gelu_in=gelu)
+    cs = torch.zeros(N, device=backend)
+    ops.linear_wgrad(dy, x, dw, gelu_in=gelu, colsum_out=cs)
+    close(cs, f64(dy).sum(0), dt, 'linear_wgrad fused column sum', mult=0.2 if dt == torch.bfloat16 else 1.0)
     xa = f64(x)
     if gelu:
         xa = F.gelu(xa)
@@ -211,8 +213,10 @@ def test_lstm_cell(backend, dt, M, C):
     close(dx, xr.grad, dt, 'lstm dx', mult=2.0)
     close(dhp, hr.grad, dt, 'lstm dh_prev', mult=2.0)
     dw = torch.zeros(4 * C, 2 * C, device=backend)
-    ops.lstm_wgrad(dz, x, h, dw)
+    dbias = torch.zeros(4 * C, device=backend)
+    ops.lstm_wgrad(dz, x, h, dw, dbias)
     close(dw, wr.grad, dt, 'lstm dw', mult=2.0)
+    close(dbias, f64(dz).sum(0), dt, 'lstm dbias (fused column sum)', mult=0.2 if dt == torch.bfloat16 else 1.0)
 
 
 CONV_CASES = [  # F, H, W, Cin, Cout, k, s, p
