@@ -91,7 +91,7 @@ def gemm_flops_of_call(name, args):
         M, N, K = args[6], args[7], args[8]
         return linear_flops(M, N, K)
     if name == 'rvt_linear_wgrad':
-        M, N, K = args[4], args[5], args[6]
+        M, N, K = args[5], args[6], args[7]
         return linear_flops(M, N, K)
     if name in ('rvt_lstm_fwd', 'rvt_lstm_dgrad', 'rvt_lstm_wgrad'):
         M, C = args[-3], args[-2]

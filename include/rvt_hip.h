@@ -93,6 +93,16 @@ int rvt_lstm_dgrad(const void* dz, const void* wt, void* dx, void* dh_rec, int d
 int rvt_lstm_wgrad(const void* dz, const void* x, const void* h_prev, float* dw, float* dz_colsum, int dtype, int M,
                    int C, void* stream);
 
+/* Depth-wise k x k conv (k = 3; groups = channels, padding k/2, stride 1) of the DWS-ConvLSTM (rnn.py:25-29,50-54)
+ * on channels-last maps: y[n][y][x][c] = b[c] + sum_taps w[c][ky][kx] x[...][c].  x / y rows have pitch ldx / ldy
+ * elements (so a C-wide slice of a 2C-wide buffer can be addressed).  transpose=1 computes the input gradient
+ * (mirrored taps, bias ignored).  w: float32 [C][k*k], b: float32 [C]. */
+int rvt_dwconv_fwd(const void* x, int ldx, const float* w, const float* b, void* y, int ldy, int dtype, int N, int H,
+                   int W, int C, int k, int transpose, void* stream);
+/* dw[C][k*k] += correlate(x, dy), db[C] += sum dy  (float32). */
+int rvt_dwconv_wgrad(const void* x, int ldx, const void* dy, int ldy, float* dw, float* db, int dtype, int N, int H,
+                     int W, int C, int k, void* stream);
+
 /* Zero state rows of samples with mask[b] != 0 (modules/utils/detection.py:96-113).
  * st is [B][per_sample] of float32 (is_f32) or `dtype`. */
 int rvt_state_reset_masked(void* st, const unsigned char* mask, int dtype, int B, size_t per_sample, void* stream);

@@ -108,12 +108,16 @@ class RNNDetectorStage(_Holder):
             pair.att_grid = _make_attention_block(stage_dim, attention_cfg, skip_first_norm=False)
             blocks.append(pair)
         self.att_blocks = nn.ModuleList(blocks)
-        if lstm_cfg.dws_conv:
-            raise NotImplementedError('dws_conv=True (depth-wise 3x3 in the ConvLSTM, rnn.py:25-29) is not built yet; '
-                                      'every shipped config sets dws_conv: False')
         if _cfg_get(lstm_cfg, 'drop_cell_update', 0) > 0:
             raise NotImplementedError('drop_cell_update > 0 is not built')
         self.lstm = _Holder()
+        if lstm_cfg.dws_conv:                                                    # rnn.py:24-29
+            assert isinstance(lstm_cfg.dws_conv_only_hidden, bool)
+            kk = lstm_cfg.dws_conv_kernel_size
+            if kk != 3:
+                raise NotImplementedError(f'dws_conv_kernel_size={kk}: only 3 is built')
+            cg = stage_dim if lstm_cfg.dws_conv_only_hidden else stage_dim * 2
+            self.lstm.conv3x3_dws = nn.Conv2d(cg, cg, kk, padding=kk // 2, groups=cg)
         self.lstm.conv1x1 = nn.Conv2d(stage_dim * 2, stage_dim * 4, kernel_size=1)
         self.mask_token = nn.Parameter(torch.zeros(1, 1, 1, stage_dim)) if enable_token_masking else None
         if self.mask_token is not None:

@@ -364,6 +364,38 @@ int rvt_lstm_wgrad(const void* dz, const void* x, const void* h_prev, float* dw,
     return check_launch("lstm_wgrad");
 }
 
+// ------------------------------------------------------------------------------------ depth-wise conv
+int rvt_dwconv_fwd(const void* x, int ldx, const float* w, const float* b, void* y, int ldy, int dtype, int N, int H,
+                   int W, int C, int k, int transpose, void* stream) {
+    RVT_CHECK(C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && (k == 1 || k == 3), "dwconv: C=%d k=%d unsupported", C, k);
+    hipStream_t st = (hipStream_t)stream;
+    int grid = grid_for((size_t)N * H * W * (C / 8), 8192);
+    DISPATCH_DTYPE(dtype, {
+        if (transpose)
+            hipLaunchKernelGGL((dwconv_kernel<T, true>), dim3(grid), dim3(256), 0, st, (const T*)x, ldx, w, b, (T*)y, ldy,
+                               N, H, W, C, k);
+        else
+            hipLaunchKernelGGL((dwconv_kernel<T, false>), dim3(grid), dim3(256), 0, st, (const T*)x, ldx, w, b, (T*)y,
+                               ldy, N, H, W, C, k);
+    });
+    return check_launch("dwconv");
+}
+
+int rvt_dwconv_wgrad(const void* x, int ldx, const void* dy, int ldy, float* dw, float* db, int dtype, int N, int H,
+                     int W, int C, int k, void* stream) {
+    RVT_CHECK(C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && (k == 1 || k == 3), "dwconv_wgrad: C=%d k=%d unsupported", C, k);
+    hipStream_t st = (hipStream_t)stream;
+    int NC = C / 8;
+    int CP = imin(256, pow2_ge(NC));
+    int gy = (NC + CP - 1) / CP;
+    int npl = 256 / CP;
+    size_t npix = (size_t)N * H * W;
+    int gx = (int)imin(1024, imax(1, (int)((npix + (size_t)npl * 16 - 1) / ((size_t)npl * 16))));
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dwconv_wgrad_kernel<T>), dim3(gx, gy), dim3(256), 0, st, (const T*)x, ldx,
+                                             (const T*)dy, ldy, dw, db, N, H, W, C, k, CP));
+    return check_launch("dwconv_wgrad");
+}
+
 int rvt_state_reset_masked(void* st_, const unsigned char* mask, int dtype, int B, size_t per_sample, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     int grid = grid_for((size_t)B * per_sample, 4096);

@@ -133,16 +133,40 @@ template <class T> __device__ __forceinline__ frag_t<T> tile_load_frag(const cha
 }
 
 // ---- scalar math -------------------------------------------------------------------------------
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_grad_f(float x) {
-    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+__device__ __forceinline__ float fast_rcp(float x) {
+#ifdef RVT_EMU
+    return 1.0f / x;
+#else
+    return __builtin_amdgcn_rcpf(x);        // v_rcp_f32, 1 ulp
+#endif
 }
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// erf(z) by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. at fp32 round-off): one v_exp, one v_rcp, a
+// 5-term Horner — ~12 VALU ops instead of the ~100-op libm erff.  Also returns e = exp(-z*z), which the GELU
+// derivative needs anyway (exp(-x^2/2) with z = x/sqrt2).
+__device__ __forceinline__ float erf_as(float z, float& e) {
+    const float az = fabsf(z);
+    const float t = fast_rcp(1.0f + 0.3275911f * az);
+    e = __expf(-z * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float r = 1.0f - poly * e;
+    return z < 0.0f ? -r : r;
+}
+// exact-erf GELU of the reference (layers/activations.py:138-145) and its derivative
+__device__ __forceinline__ float gelu_f(float x) {
+    float e;
+    return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f, e));
+}
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    float e;
+    const float er = erf_as(x * 0.70710678118654752f, e);
+    return 0.5f * (1.0f + er) + x * 0.3989422804014327f * e;
+}
+__device__ __forceinline__ float sigmoid_f(float x) { return fast_rcp(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanh_f(float x) {
-    // tanh via exp; exact to ~1e-7 relative, saturates correctly
-    float ax = fabsf(x);
-    float e = __expf(-2.0f * ax);
-    float t = (1.0f - e) / (1.0f + e);
+    // tanh via exp; saturates correctly for large |x|
+    const float ax = fabsf(x);
+    const float e = __expf(-2.0f * ax);
+    const float t = (1.0f - e) * fast_rcp(1.0f + e);
     return x < 0.0f ? -t : t;
 }
 

@@ -240,3 +240,120 @@ state_reset_kernel(S* __restrict__ st, const unsigned char* __restrict__ mask, i
 }
 
 }  // namespace rvt
+
+namespace rvt {
+
+// ---- depth-wise k x k convolution on channels-last maps (reference rnn.py:25-29,50-54: groups = channels,
+// padding k/2, stride 1, with bias).  Not GEMM-shaped (one input channel per output channel): HBM/L2-bound
+// stencil; a thread owns 8 channels of one pixel and walks the k*k taps with 16-byte loads.
+//   FLIP=false: y = dwconv(x) + b           FLIP=true: dx = dwconv^T(dy) (taps mirrored, no bias)
+// x/y are [N][H][W][ld] slices starting at channel offset 0 with Cg channels used (ld >= Cg).
+template <class T, bool FLIP>
+__global__ void __launch_bounds__(256)
+dwconv_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ w, const float* __restrict__ b,
+              T* __restrict__ y, int ldy, int N, int H, int W, int Cg, int k) {
+    const int cpr = Cg / 8;
+    const int pad = k / 2;
+    const size_t total = (size_t)N * H * W * cpr;
+    for (size_t u = (size_t)blockIdx.x * 256 + threadIdx.x; u < total; u += (size_t)gridDim.x * 256) {
+        const int c0 = (int)(u % cpr) * 8;
+        const size_t pix = u / cpr;
+        const int xx = (int)(pix % W);
+        const int yy = (int)((pix / W) % H);
+        const size_t n = pix / ((size_t)W * H);
+        float acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) acc[i] = (b && !FLIP) ? b[c0 + i] : 0.f;
+        for (int ky = 0; ky < k; ky++) {
+            const int iy = yy + ky - pad;
+            if (iy < 0 || iy >= H) continue;
+            for (int kx = 0; kx < k; kx++) {
+                const int ix = xx + kx - pad;
+                if (ix < 0 || ix >= W) continue;
+                float v[8];
+                frag_to_float<T>(frag_load<T>(x + ((n * H + iy) * W + ix) * ldx + c0), v);
+                const int tap = FLIP ? (k - 1 - ky) * k + (k - 1 - kx) : ky * k + kx;
+#pragma unroll
+                for (int i = 0; i < 8; i++) acc[i] += v[i] * w[(size_t)(c0 + i) * k * k + tap];
+            }
+        }
+        frag_store<T>(y + pix * ldy + c0, frag_from_float<T>(acc));
+    }
+}
+
+// dw[c][ky][kx] += sum_pixels x[pix + (ky,kx) - pad][c] * dy[pix][c];  db[c] += sum dy[pix][c]
+// One workgroup walks a strip of pixels; a thread owns (8 channels) and accumulates all k*k taps (k <= 3 -> 9x8 regs);
+// the 256/cpr pixel-lanes of a workgroup are folded through LDS, then one atomic per (channel, tap) per workgroup.
+template <class T>
+__global__ void __launch_bounds__(256)
+dwconv_wgrad_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dy, int ldy, float* __restrict__ dw,
+                    float* __restrict__ db, int N, int H, int W, int Cg, int k, int CP) {
+    // CP = pow2 >= Cg/8 (<= 256): threads tid%CP own a channel chunk, tid/CP are pixel lanes
+    __shared__ float red[256][8];
+    const int tid = threadIdx.x;
+    const int cc = tid % CP + blockIdx.y * CP;
+    const int pl = tid / CP, npl = 256 / CP;
+    const bool cvalid = cc * 8 < Cg;
+    const int c0 = cc * 8;
+    const int pad = k / 2;
+    const size_t npix = (size_t)N * H * W;
+    float aw[9][8], ab[8];
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) aw[t][i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) ab[i] = 0.f;
+    if (cvalid) {
+        for (size_t pix = (size_t)blockIdx.x * npl + pl; pix < npix; pix += (size_t)gridDim.x * npl) {
+            const int xx = (int)(pix % W);
+            const int yy = (int)((pix / W) % H);
+            const size_t n = pix / ((size_t)W * H);
+            float g[8];
+            frag_to_float<T>(frag_load<T>(dy + pix * ldy + c0), g);
+#pragma unroll
+            for (int i = 0; i < 8; i++) ab[i] += g[i];
+#pragma unroll
+            for (int ky = 0; ky < 3; ky++) {
+                if (ky >= k) continue;
+                const int iy = yy + ky - pad;
+                if (iy < 0 || iy >= H) continue;
+#pragma unroll
+                for (int kx = 0; kx < 3; kx++) {
+                    if (kx >= k) continue;
+                    const int ix = xx + kx - pad;
+                    if (ix < 0 || ix >= W) continue;
+                    float v[8];
+                    frag_to_float<T>(frag_load<T>(x + ((n * H + iy) * W + ix) * ldx + c0), v);
+#pragma unroll
+                    for (int i = 0; i < 8; i++) aw[ky * 3 + kx][i] += v[i] * g[i];
+                }
+            }
+        }
+    }
+    for (int t = 0; t <= k * k; t++) {           // t == k*k: the bias sums
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            float v = 0.f;
+            if (t == k * k) v = ab[i];
+            else {
+#pragma unroll
+                for (int q = 0; q < 9; q++) if (q == (t / k) * 3 + (t % k)) v = aw[q][i];
+            }
+            red[tid][i] = v;
+        }
+        __syncthreads();
+        if (pl == 0 && cvalid) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                float s = 0.f;
+                for (int r = 0; r < npl; r++) s += red[r * CP + tid][i];
+                if (t == k * k) atomicAdd(db + c0 + i, s);
+                else atomicAdd(dw + (size_t)(c0 + i) * k * k + t, s);
+            }
+        }
+    }
+}
+
+}  // namespace rvt

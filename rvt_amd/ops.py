@@ -181,6 +181,23 @@ def lstm_wgrad(dz: Tensor, x: Tensor, h_prev: Tensor, dw: Tensor, colsum_out: Op
            M, C, L.stream_of(dz))
 
 
+def dwconv(x: Tensor, w: Tensor, b: Optional[Tensor], k: int, transpose: bool = False, out: Optional[Tensor] = None) -> Tensor:
+    """Depth-wise k x k conv on (N,H,W,C) channels-last (rnn.py:25-29); transpose=True -> input gradient."""
+    N, H, W, C = x.shape
+    assert w.dtype == torch.float32 and tuple(w.shape) == (C, k * k)
+    y = _out(x, x.shape, out=out)
+    L.call('rvt_dwconv_fwd', L.ptr(x), C, L.ptr(w), L.ptr(b), L.ptr(y), C, L.dtype_code(x.dtype), N, H, W, C, k,
+           int(transpose), L.stream_of(x))
+    return y
+
+
+def dwconv_wgrad(x: Tensor, dy: Tensor, dw: Tensor, db: Tensor, k: int) -> None:
+    N, H, W, C = x.shape
+    assert dw.dtype == torch.float32 and tuple(dw.shape) == (C, k * k) and db.numel() == C
+    L.call('rvt_dwconv_wgrad', L.ptr(x), C, L.ptr(dy), C, L.ptr(dw), L.ptr(db), L.dtype_code(x.dtype), N, H, W, C, k,
+           L.stream_of(x))
+
+
 def state_reset_masked(st: Tensor, mask: Tensor) -> None:
     """Zero rows st[b] where mask[b] (modules/utils/detection.py:96-113); st is (B, ...)."""
     B = st.shape[0]

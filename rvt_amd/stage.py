@@ -50,7 +50,7 @@ class StageGeom:
 
 class StageSaved:
     """Activations kept for backward (everything else is recomputed from these)."""
-    __slots__ = ('inp', 'y0', 'blocks', 'x_last', 'Hall', 'Call', 'gates', 'mask')
+    __slots__ = ('inp', 'y0', 'blocks', 'x_last', 'Hall', 'Call', 'gates', 'mask', 'xin_lstm', 'hconv')
 
     def __init__(self):
         self.blocks: List[Dict[str, Tensor]] = []
@@ -94,12 +94,26 @@ def stage_seq_forward(sw: StageWeights, g: StageGeom, inp: Tensor, h0: Optional[
         Hall[0].copy_(h0)
         Call[0].copy_(c0)
     gates = torch.empty((T, B, H, W, 4 * C), dtype=dt, device=dev) if save else None
-    xt = x.view(T, B, H, W, C)
+    # DWS-ConvLSTM (rnn.py:50-54): depth-wise 3x3 on h_{t-1} only, or on cat(x, h_{t-1}) (the x half batched over T)
+    dws = sw.dws
+    x_lstm = x
+    hconv = None
+    if dws is not None:
+        hconv = torch.empty((T if save else 1, B, H, W, C), dtype=dt, device=dev)
+        if not dws['only_hidden']:
+            x_lstm = ops.dwconv(x, dws['w'][:C].contiguous(), dws['b'][:C].contiguous(), dws['k'])
+    xt = x_lstm.view(T, B, H, W, C)
     for t in range(T):                                                            # rnn.py:52-67, one launch per step
-        ops.lstm_fwd(xt[t], Hall[t], Call[t], sw.lstm_w, sw.lstm_b, Hall[t + 1], Call[t + 1],
+        h_in = Hall[t]
+        if dws is not None:
+            wh = dws['w'] if dws['only_hidden'] else dws['w'][C:].contiguous()
+            bh = dws['b'] if dws['only_hidden'] else dws['b'][C:].contiguous()
+            h_in = ops.dwconv(Hall[t], wh, bh, dws['k'], out=hconv[t if save else 0])
+        ops.lstm_fwd(xt[t], h_in, Call[t], sw.lstm_w, sw.lstm_b, Hall[t + 1], Call[t + 1],
                      gates[t] if save else None)
     if save:
         sv.x_last, sv.Hall, sv.Call, sv.gates = x, Hall, Call, gates
+        sv.xin_lstm, sv.hconv = x_lstm, hconv
     return Hall, Call, sv
 
 
@@ -124,18 +138,42 @@ def stage_seq_backward(sw: StageWeights, g: StageGeom, sv: StageSaved, dH: Optio
     dc_rec = zeros(B, H, W, C) if dc_last is None else dc_last.to(f32).contiguous().clone()
     dh_rec = None
     dh_buf = [torch.empty((B, H, W, C), dtype=dt, device=dev) for _ in range(2)]
+    dws = sw.dws
+    dhc = torch.empty((T, B, H, W, C), dtype=dt, device=dev) if dws is not None else None   # d(dwconv(h_{t-1}))
+    if dws is not None:
+        wh = dws['w'] if dws['only_hidden'] else dws['w'][C:].contiguous()
     for t in range(T - 1, -1, -1):
         ops.lstm_gates_bwd(dH[t], dh_rec, dc_rec, sv.gates[t], sv.Call[t + 1], sv.Call[t], dz[t])
         nxt = dh_buf[t & 1]
-        ops.lstm_dgrad(dz[t], sw.lstm_wt, dx[t], nxt)
+        if dws is None:
+            ops.lstm_dgrad(dz[t], sw.lstm_wt, dx[t], nxt)
+        else:
+            ops.lstm_dgrad(dz[t], sw.lstm_wt, dx[t], dhc[t])
+            ops.dwconv(dhc[t], wh, None, dws['k'], transpose=True, out=nxt)
         dh_rec = nxt
     dwl = zeros(4 * C, 2 * C)
     dbl = zeros(4 * C)
-    ops.lstm_wgrad(dz.view(F_, H, W, 4 * C), sv.x_last, sv.Hall[:T].reshape(F_, H, W, C), dwl, dbl)
+    h_seg = sv.Hall[:T].reshape(F_, H, W, C) if dws is None else sv.hconv.view(F_, H, W, C)
+    ops.lstm_wgrad(dz.view(F_, H, W, 4 * C), sv.xin_lstm, h_seg, dwl, dbl)
     grads[pre + 'lstm.conv1x1.weight'] = dwl.reshape(4 * C, 2 * C, 1, 1)
     grads[pre + 'lstm.conv1x1.bias'] = dbl
     dh0, dc0 = dh_rec, dc_rec
     dx = dx.view(F_, H, W, C)
+    if dws is not None:
+        kk = dws['k']
+        cg = dws['w'].shape[0]
+        dwd, dbd = zeros(cg, kk * kk), zeros(cg)
+        hprev = sv.Hall[:T].reshape(F_, H, W, C)
+        if dws['only_hidden']:
+            ops.dwconv_wgrad(hprev, dhc.view(F_, H, W, C), dwd, dbd, kk)
+        else:
+            dwx, dbx, dwh, dbh = zeros(C, kk * kk), zeros(C), zeros(C, kk * kk), zeros(C)
+            ops.dwconv_wgrad(sv.x_last, dx, dwx, dbx, kk)                    # dx here = d(dwconv_x(x))
+            ops.dwconv_wgrad(hprev, dhc.view(F_, H, W, C), dwh, dbh, kk)
+            dwd, dbd = torch.cat([dwx, dwh]), torch.cat([dbx, dbh])
+            dx = ops.dwconv(dx, dws['w'][:C].contiguous(), None, kk, transpose=True)
+        grads[pre + 'lstm.conv3x3_dws.weight'] = dwd.reshape(cg, 1, kk, kk)
+        grads[pre + 'lstm.conv3x3_dws.bias'] = dbd
     del dz
 
     # ---- attention blocks, reversed ---------------------------------------------------------------------

@@ -101,6 +101,13 @@ class StageWeights:
                              proj_w32=wp, fc2_w32=w2)
                 pair.append(d)
             self.blocks.append(tuple(pair))
+        # optional depth-wise 3x3 of the DWS-ConvLSTM (rnn.py:25-29): fp32 [Cg][k*k] + bias, Cg = C (hidden only) or 2C
+        self.dws = None
+        if (pre + 'lstm.conv3x3_dws.weight') in p:
+            wd = g('lstm.conv3x3_dws.weight').to(f32)
+            cg, kk = wd.shape[0], wd.shape[-1]
+            self.dws = dict(only_hidden=(cg == C), k=kk, w=wd.reshape(cg, kk * kk).contiguous(),
+                            b=g('lstm.conv3x3_dws.bias').to(f32).contiguous())
         wl = g('lstm.conv1x1.weight').to(f32).reshape(4 * C, 2 * C)
         perm = lstm_gate_perm(C, wl.device)
         self.lstm_perm = perm

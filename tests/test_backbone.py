@@ -10,8 +10,9 @@ from tests import casegen
 from tests.backends import backend  # noqa: F401
 from tests.harness import compare, load_golden, summarize
 
-UNSUPPORTED = {'micro_dws_hidden', 'micro_dws_xh'}
-EMU_CASES = ['micro', 'micro_default_gamma', 'micro_dh24', 'micro_mask', 'micro_nooverlap']
+UNSUPPORTED = set()
+EMU_CASES = ['micro', 'micro_default_gamma', 'micro_dh24', 'micro_mask', 'micro_nooverlap', 'micro_dws_hidden',
+             'micro_dws_xh']
 ALL_CASES = [c for c in casegen.CASES if c not in UNSUPPORTED]
 
 

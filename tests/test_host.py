@@ -29,8 +29,10 @@ def test_header_and_binding_agree():
 def test_hip_library_loads_and_exports_every_symbol():
     """The gfx950 build must dlopen on a GPU-less host and export everything include/rvt_hip.h declares
     (no compute call is made)."""
-    if not os.path.exists(_lib.LIB_PATH):
-        subprocess.run(['bash', os.path.join(ROOT, 'rvt_amd', 'csrc', 'build.sh')], check=True, capture_output=True)
+    csrc = os.path.join(ROOT, 'rvt_amd', 'csrc')
+    srcs = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [os.path.join(ROOT, 'include', 'rvt_hip.h')]
+    if not os.path.exists(_lib.LIB_PATH) or any(os.path.getmtime(f) > os.path.getmtime(_lib.LIB_PATH) for f in srcs):
+        subprocess.run(['bash', os.path.join(csrc, 'build.sh')], check=True, capture_output=True)
     lib = _lib.load_library()
     for sym in declared_symbols():
         assert hasattr(lib, sym), sym

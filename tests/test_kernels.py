@@ -252,6 +252,25 @@ def test_conv(backend, dt, case):
 
 
 @pytest.mark.parametrize('dt', DTYPES)
+@pytest.mark.parametrize('N,H,W,C', [(2, 5, 7, 16), (1, 6, 4, 48), (3, 3, 3, 8)])
+def test_dwconv(backend, dt, N, H, W, C):
+    x, dy = rnd((N, H, W, C), backend, dt, 1), rnd((N, H, W, C), backend, dt, 2)
+    w, b = rnd((C, 9), backend, torch.float32, 3, 0.3), rnd((C,), backend, torch.float32, 4)
+    y = ops.dwconv(x, w, b, 3)
+    xr = f64(x).permute(0, 3, 1, 2).requires_grad_(True)
+    wr, br = f64(w).reshape(C, 1, 3, 3).requires_grad_(True), f64(b).requires_grad_(True)
+    yr = F.conv2d(xr, wr, br, padding=1, groups=C)
+    close(y, yr.permute(0, 2, 3, 1), dt, 'dwconv fwd')
+    yr.backward(f64(dy).permute(0, 3, 1, 2))
+    dx = ops.dwconv(dy, w, None, 3, transpose=True)
+    close(dx, xr.grad.permute(0, 2, 3, 1), dt, 'dwconv bwd input')
+    dw, db = torch.zeros(C, 9, device=backend), torch.zeros(C, device=backend)
+    ops.dwconv_wgrad(x, dy, dw, db, 3)
+    close(dw, wr.grad.reshape(C, 9), dt, 'dwconv bwd weight')
+    close(db, br.grad, dt, 'dwconv bwd bias')
+
+
+@pytest.mark.parametrize('dt', DTYPES)
 def test_state_reset(backend, dt):
     st = rnd((3, 4, 5, 8), backend, dt, 1)
     ref = st.clone()
