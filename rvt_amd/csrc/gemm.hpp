@@ -123,6 +123,7 @@ template <class T, int ROWS, class Src, class Xf> struct NTLoader {
     static constexpr int NF = ROWS * FPR / 256;
     typename Src::Ctx ctx[NF];
     frag_t<T> r[NF];
+    bool valid[NF];
     __device__ __forceinline__ void init(const Src& s, int row0, int tid) {
 #pragma unroll
         for (int i = 0; i < NF; i++) ctx[i] = s.row_ctx(row0 + (tid + i * 256) / FPR);
@@ -133,20 +134,24 @@ template <class T, int ROWS, class Src, class Xf> struct NTLoader {
             int fc = (tid + i * 256) % FPR;
             int kcol = k0 + fc * 8;
             frag_t<T> v = frag_zero<T>();
+            bool ok = false;
             if (kcol < kend) {
                 int seg, off;
                 s.split(kcol, seg, off);
                 const T* p = s.seg_ptr(ctx[i], seg);
-                if (p) v = xf_apply<T>(frag_load<T>(p + off), xf);
+                if (p) { v = frag_load<T>(p + off); ok = true; }
             }
-            r[i] = v;
+            r[i] = v;                 // raw: nothing consumes the loaded registers until store(), so the
+            valid[i] = ok;            // loads stay in flight across the MFMA phase of the current tile
         }
     }
-    __device__ __forceinline__ void store(char* tile, int tid) const {
+    __device__ __forceinline__ void store(char* tile, const Xf& xf, int tid) {
 #pragma unroll
         for (int i = 0; i < NF; i++) {
             int u = tid + i * 256;
-            tile_store_frag<T>(tile, u / FPR, u % FPR, r[i]);
+            frag_t<T> v = r[i];
+            if (!Xf::identity && valid[i]) v = xf_apply<T>(v, xf);
+            tile_store_frag<T>(tile, u / FPR, u % FPR, v);
         }
     }
     __device__ __forceinline__ void flush_colsum(float*, int) const {}
@@ -190,9 +195,11 @@ template <class T, int ROWS, class Src, class Xf, bool HIGH> struct TNLoader {
     static constexpr int FC = ROWS / 8;                   // feature chunks per tile
     static constexpr int NUNITS = FC * FPR;               // <= 128
     static_assert(NUNITS <= 256, "tile too large for one unit per thread");
+    static constexpr bool WANT_COLSUM = !HIGH;            // only the A (dY) side feeds bias gradients
     int u;                                                // this thread's unit or -1
     int seg, off;
     bool fvalid;
+    unsigned vmask;
     frag_t<T> r[8];
     float csum[8];                                        // running sum over tokens of this unit's 8 features
     __device__ __forceinline__ void init(const Src& s, int row0, int tid) {
@@ -209,8 +216,8 @@ template <class T, int ROWS, class Src, class Xf, bool HIGH> struct TNLoader {
     }
     __device__ __forceinline__ void load(const Src& s, const Xf& xf, int k0, int kend, int tid) {
         if (u < 0) return;
-        frag_t<T> in[8];
         const int tok0 = k0 + (u / FC) * 8;
+        vmask = 0;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             frag_t<T> v = frag_zero<T>();
@@ -218,13 +225,10 @@ template <class T, int ROWS, class Src, class Xf, bool HIGH> struct TNLoader {
             if (fvalid && tok < kend) {
                 typename Src::Ctx c = s.row_ctx(tok);
                 const T* p = s.seg_ptr(c, seg);
-                if (p) v = xf_apply<T>(frag_load<T>(p + off), xf);
+                if (p) { v = frag_load<T>(p + off); vmask |= 1u << j; }
             }
-            in[j] = v;
-#pragma unroll
-            for (int f = 0; f < 8; f++) csum[f] += (float)v[f];
+            r[j] = v;                 // raw rows; transform / column sums / transpose happen in store()
         }
-        Transpose8<T>::run(in, r);
     }
     // out[feature] += token sums seen by this thread (bias gradient = column sum of dY); call once at the end
     __device__ __forceinline__ void flush_colsum(float* out, int row0) const {
@@ -232,10 +236,22 @@ template <class T, int ROWS, class Src, class Xf, bool HIGH> struct TNLoader {
 #pragma unroll
         for (int f = 0; f < 8; f++) atomicAdd(out + row0 + (u % FC) * 8 + f, csum[f]);
     }
-    __device__ __forceinline__ void store(char* tile, int tid) const {
+    __device__ __forceinline__ void store(char* tile, const Xf& xf, int tid) {
         if (u < 0) return;
+        frag_t<T> in[8], out[8];
 #pragma unroll
-        for (int f = 0; f < 8; f++) tile_store_frag<T>(tile, (u % FC) * 8 + f, u / FC, r[f]);
+        for (int j = 0; j < 8; j++) {
+            frag_t<T> v = r[j];
+            if (!Xf::identity && ((vmask >> j) & 1u)) v = xf_apply<T>(v, xf);
+            in[j] = v;
+            if (WANT_COLSUM) {
+#pragma unroll
+                for (int f = 0; f < 8; f++) csum[f] += (float)v[f];
+            }
+        }
+        Transpose8<T>::run(in, out);
+#pragma unroll
+        for (int f = 0; f < 8; f++) tile_store_frag<T>(tile, (u % FC) * 8 + f, u / FC, out[f]);
     }
 };
 
@@ -398,8 +414,8 @@ gemm_kernel(ASrc as, AXf axf, BSrc bs, BXf bxf, Ep ep, int M, int N, int K, int 
     if (nk > 0) {
         la.load(as, axf, kbeg, kend, tid);
         lb.load(bs, bxf, kbeg, kend, tid);
-        la.store(smem, tid);
-        lb.store(smem + BM * 128, tid);
+        la.store(smem, axf, tid);
+        lb.store(smem + BM * 128, bxf, tid);
     }
     __syncthreads();
     for (int kt = 0; kt < nk; kt++) {
@@ -425,8 +441,8 @@ gemm_kernel(ASrc as, AXf axf, BSrc bs, BXf bxf, Ep ep, int M, int N, int K, int 
                 for (int j = 0; j < WN; j++) mma32(acc[i][j], a[i], b[j]);
         }
         if (more) {
-            la.store(smem + (cur ^ 1) * STAGE_BYTES, tid);
-            lb.store(smem + (cur ^ 1) * STAGE_BYTES + BM * 128, tid);
+            la.store(smem + (cur ^ 1) * STAGE_BYTES, axf, tid);
+            lb.store(smem + (cur ^ 1) * STAGE_BYTES + BM * 128, bxf, tid);
         }
         __syncthreads();
     }
