@@ -27,6 +27,12 @@ const char* rvt_last_error(void);
 /* 1 if this library is the CPU SIMT emulator build used by the unit tests, 0 for the gfx950 build */
 int rvt_is_emulator(void);
 
+/* Weight-gradient GEMMs (rvt_*_wgrad) cut the token contraction into K slices.  `ws` is their scratch for the
+ * two-stage reduction: rvt_wgrad_workspace_floats(dtype, out_rows, out_cols, tokens, want_colsum) float32 elements
+ * (out = dw's [rows][cols]; conv: [Cout][k*k*Cin]; lstm: [4C][2C]).  ws == NULL selects direct float atomics, which
+ * are correct but slow on MI355X (device-scope atomics execute memory-side). */
+size_t rvt_wgrad_workspace_floats(int dtype, int out_rows, int out_cols, int tokens, int want_colsum);
+
 /* Event-tensor cast + zero pad (modules/detection.py:133-134, utils/padding.py:29-44) fused with the
  * NCHW -> channels-last repack: src [F][Cin][h][w] (uint8 if src_u8 else float32) ->
  * dst [F][H][W][Cp] (dtype), zero padded to H>=h, W>=w, Cp>=Cin. */
@@ -43,8 +49,8 @@ int rvt_conv_fwd(const void* in, const void* w, void* out, int dtype, int F, int
 int rvt_conv_dgrad(const void* dy, const void* wd, const void* add, void* din, int dtype, int F, int H, int W,
                    int Cin, int Cout, int k, int stride, int pad, void* stream);
 /* Weight gradient: dw[Cout][k*k*Cin] (float32) += dy^T im2col(in). */
-int rvt_conv_wgrad(const void* in, const void* dy, float* dw, int dtype, int F, int H, int W, int Cin, int Cout,
-                   int k, int stride, int pad, void* stream);
+int rvt_conv_wgrad(const void* in, const void* dy, float* dw, float* ws, int dtype, int F, int H, int W, int Cin,
+                   int Cout, int k, int stride, int pad, void* stream);
 
 /* LayerNorm over channels (maxvit.py:172,177,229,241). */
 int rvt_layernorm_fwd(const void* x, const float* w, const float* b, void* y, int dtype, int rows, int C,
@@ -66,8 +72,8 @@ int rvt_linear_dgrad(const void* dy, const void* wt, const void* gelu_pre, const
                      int N, int K, void* stream);
 /* dw[N][K] (float32) += dy[M][N]^T f(x)[M][K];  if dy_colsum != NULL also dy_colsum[N] += column sums of dy
  * (the bias gradient), computed from the tiles the kernel streams anyway. */
-int rvt_linear_wgrad(const void* dy, const void* x, float* dw, float* dy_colsum, int dtype, int M, int N, int K,
-                     int gelu_in, void* stream);
+int rvt_linear_wgrad(const void* dy, const void* x, float* dw, float* dy_colsum, float* ws, int dtype, int M, int N,
+                     int K, int gelu_in, void* stream);
 /* out[N] (float32) += column sums of x[rows][N]. */
 int rvt_colsum(const void* x, float* out, int dtype, int rows, int N, void* stream);
 
@@ -90,8 +96,8 @@ int rvt_lstm_gates_bwd(const void* dh_in, const void* dh_rec, float* dc_rec, con
 /* [dx | dh_rec] = dz W : wt = W^T [2C][4C] natural gate order. */
 int rvt_lstm_dgrad(const void* dz, const void* wt, void* dx, void* dh_rec, int dtype, int M, int C, void* stream);
 /* dw[4C][2C] (float32) += dz^T [x | h_prev];  dz_colsum[4C] += column sums of dz if non-NULL (bias gradient). */
-int rvt_lstm_wgrad(const void* dz, const void* x, const void* h_prev, float* dw, float* dz_colsum, int dtype, int M,
-                   int C, void* stream);
+int rvt_lstm_wgrad(const void* dz, const void* x, const void* h_prev, float* dw, float* dz_colsum, float* ws, int dtype,
+                   int M, int C, void* stream);
 
 /* Depth-wise k x k conv (k = 3; groups = channels, padding k/2, stride 1) of the DWS-ConvLSTM (rnn.py:25-29,50-54)
  * on channels-last maps: y[n][y][x][c] = b[c] + sum_taps w[c][ky][kx] x[...][c].  x / y rows have pitch ldx / ldy

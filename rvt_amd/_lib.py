@@ -26,25 +26,25 @@ _SIGS = {
     'rvt_prepack_input': [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     'rvt_conv_fwd': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     'rvt_conv_dgrad': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
-    'rvt_conv_wgrad': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    'rvt_conv_wgrad': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     'rvt_layernorm_fwd': [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
     'rvt_layernorm_bwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
     'rvt_linear_fwd': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     'rvt_linear_scale_res_fwd': [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     'rvt_linear_dgrad': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
-    'rvt_linear_wgrad': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    'rvt_linear_wgrad': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     'rvt_colsum': [_vp, _vp, _i, _i, _i, _vp],
     'rvt_attn_fwd': [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     'rvt_attn_bwd': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     'rvt_lstm_fwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     'rvt_lstm_gates_bwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     'rvt_lstm_dgrad': [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
-    'rvt_lstm_wgrad': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    'rvt_lstm_wgrad': [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     'rvt_dwconv_fwd': [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     'rvt_dwconv_wgrad': [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     'rvt_state_reset_masked': [_vp, _vp, _i, _i, _sz, _vp],
 }
-EXPORTS = sorted(list(_SIGS) + ['rvt_last_error', 'rvt_is_emulator'])
+EXPORTS = sorted(list(_SIGS) + ['rvt_last_error', 'rvt_is_emulator', 'rvt_wgrad_workspace_floats'])
 
 
 def _bind(lib: ctypes.CDLL) -> ctypes.CDLL:
@@ -56,6 +56,8 @@ def _bind(lib: ctypes.CDLL) -> ctypes.CDLL:
     lib.rvt_last_error.argtypes = []
     lib.rvt_is_emulator.restype = ctypes.c_int
     lib.rvt_is_emulator.argtypes = []
+    lib.rvt_wgrad_workspace_floats.restype = ctypes.c_size_t
+    lib.rvt_wgrad_workspace_floats.argtypes = [_i, _i, _i, _i, _i]
     return lib
 
 

@@ -38,13 +38,42 @@ static inline int grid_for(size_t units, int cap = 2048) {
 // split the token contraction of a weight gradient so that the launch fills the chip
 static inline int wgrad_ksplit(int out_rows, int out_cols, int tokens, int bn) {
     int tiles = ((out_rows + 127) / 128) * ((out_cols + bn - 1) / bn);
-    int want = imax(1, 1024 / imax(1, tiles));
+    int want = imax(1, 768 / imax(1, tiles));
     int maxs = imax(1, tokens / 512);
     return imin(want, maxs);
 }
 }  // namespace rvt
 
 using namespace rvt;
+
+// Two-stage split-K weight gradient: out[Mg][Ng] += A^T B with the token contraction cut into slices whose partial
+// tiles go to `ws` (plain stores) and are folded by splitk_reduce_kernel; the A-side column sums (bias gradient)
+// ride along.  ws must hold rvt_wgrad_workspace_floats(...) floats.
+static inline size_t wgrad_ws_floats(int Mg, int Ng, int tokens, int bn, int bk, int want_colsum) {
+    int ns = gemm_slices(tokens, wgrad_ksplit(Mg, Ng, tokens, bn), bk);
+    return (size_t)ns * ((size_t)Mg * Ng + (want_colsum ? Mg : 0));
+}
+template <class T, int BN, class ASrc, class BSrc, class BXf>
+static void launch_wgrad(const ASrc& a, const BSrc& b, const BXf& bxf, float* out, float* colsum_out, float* ws,
+                         int Mg, int Ng, int tokens, hipStream_t st) {
+    const int BK = TileGeom<T>::BK;
+    const int ks = wgrad_ksplit(Mg, Ng, tokens, BN);
+    const int ns = gemm_slices(tokens, ks, BK);
+    if (ws == nullptr) {                       // no workspace: direct atomics (correct, slow on large split counts)
+        EpAtomicF32 ep{out, Ng};
+        launch_gemm<T, BN, true>(a, XfNone(), b, bxf, ep, Mg, Ng, tokens, ks, st, nullptr);
+        return;
+    }
+    const size_t tile_elems = (size_t)Mg * Ng;
+    float* ws_cs = colsum_out ? ws + (size_t)ns * tile_elems : nullptr;
+    EpPartialStore ep{ws, Ng, tile_elems, 0};
+    launch_gemm<T, BN, true>(a, XfNone(), b, bxf, ep, Mg, Ng, tokens, ks, st, ws_cs);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for(tile_elems, 1024)), dim3(256), 0, st, (const float*)ws, out, ns,
+                       tile_elems);
+    if (colsum_out)
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for((size_t)Mg, 64)), dim3(256), 0, st, (const float*)ws_cs,
+                           colsum_out, ns, (size_t)Mg);
+}
 
 #define DISPATCH_DTYPE(dtype, ...)                                   \
     do {                                                             \
@@ -69,6 +98,12 @@ int rvt_is_emulator(void) {
 #else
     return 0;
 #endif
+}
+
+size_t rvt_wgrad_workspace_floats(int dtype, int out_rows, int out_cols, int tokens, int want_colsum) {
+    int bn = out_cols <= 64 ? 64 : 128;
+    int bk = dtype == RVT_F32 ? TileGeom<float>::BK : TileGeom<bf16>::BK;
+    return wgrad_ws_floats(out_rows, out_cols, tokens, bn, bk, want_colsum);
 }
 
 int rvt_prepack_input(const void* src, int src_u8, void* dst, int dtype, int F, int Cin, int h, int w, int H, int W,
@@ -113,16 +148,14 @@ int rvt_conv_fwd(const void* in, const void* w, void* out, int dtype, int F, int
     return check_launch("conv_fwd");
 }
 
-int rvt_conv_wgrad(const void* in, const void* dy, float* dw, int dtype, int F, int H, int W, int Cin, int Cout, int k,
-                   int stride, int pad, void* stream) {
+int rvt_conv_wgrad(const void* in, const void* dy, float* dw, float* ws, int dtype, int F, int H, int W, int Cin, int Cout,
+                   int k, int stride, int pad, void* stream) {
     RVT_CHECK(Cin % 8 == 0 && Cout % 8 == 0, "conv_wgrad: channels must be multiples of 8");
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_DTYPE(dtype, {
         Im2colSrc<T> b = make_im2col<T>(in, F, H, W, Cin, k, stride, pad);
         PlainSrc<T> a{(const T*)dy, Cout, b.rows, Cout};
-        EpAtomicF32 ep{dw, b.cols};
-        DISPATCH_BN(b.cols, (launch_gemm<T, BN, true>(a, XfNone(), b, XfNone(), ep, Cout, b.cols, b.rows,
-                                                      wgrad_ksplit(Cout, b.cols, b.rows, BN), st)));
+        DISPATCH_BN(b.cols, (launch_wgrad<T, BN>(a, b, XfNone(), dw, nullptr, ws, Cout, b.cols, b.rows, st)));
     });
     return check_launch("conv_wgrad");
 }
@@ -251,18 +284,16 @@ int rvt_linear_dgrad(const void* dy, const void* wt, const void* gelu_pre, const
     return check_launch("linear_dgrad");
 }
 
-int rvt_linear_wgrad(const void* dy, const void* x, float* dw, float* dy_colsum, int dtype, int M, int N, int K,
+int rvt_linear_wgrad(const void* dy, const void* x, float* dw, float* dy_colsum, float* ws, int dtype, int M, int N, int K,
                      int gelu_in, void* stream) {
     RVT_CHECK(N % 8 == 0 && K % 8 == 0, "linear_wgrad: N=%d K=%d must be multiples of 8", N, K);
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_DTYPE(dtype, {
         PlainSrc<T> a{(const T*)dy, N, M, N};
         PlainSrc<T> b{(const T*)x, K, M, K};
-        EpAtomicF32 ep{dw, K};
         DISPATCH_BN(K, {
-            int ks = wgrad_ksplit(N, K, M, BN);
-            if (gelu_in) launch_gemm<T, BN, true>(a, XfNone(), b, XfGelu(), ep, N, K, M, ks, st, dy_colsum);
-            else launch_gemm<T, BN, true>(a, XfNone(), b, XfNone(), ep, N, K, M, ks, st, dy_colsum);
+            if (gelu_in) launch_wgrad<T, BN>(a, b, XfGelu(), dw, dy_colsum, ws, N, K, M, st);
+            else launch_wgrad<T, BN>(a, b, XfNone(), dw, dy_colsum, ws, N, K, M, st);
         });
     });
     return check_launch("linear_wgrad");
@@ -350,16 +381,14 @@ int rvt_lstm_dgrad(const void* dz, const void* wt, void* dx, void* dh_rec, int d
     return check_launch("lstm_dgrad");
 }
 
-int rvt_lstm_wgrad(const void* dz, const void* x, const void* h_prev, float* dw, float* dz_colsum, int dtype, int M,
-                   int C, void* stream) {
+int rvt_lstm_wgrad(const void* dz, const void* x, const void* h_prev, float* dw, float* dz_colsum, float* ws, int dtype,
+                   int M, int C, void* stream) {
     RVT_CHECK(C % 8 == 0, "lstm_wgrad: C=%d must be a multiple of 8", C);
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_DTYPE(dtype, {
         PlainSrc<T> a{(const T*)dz, 4 * C, M, 4 * C};
         ConcatSrc<T> b{(const T*)x, (const T*)h_prev, C, M, 2 * C};
-        EpAtomicF32 ep{dw, 2 * C};
-        DISPATCH_BN(2 * C, (launch_gemm<T, BN, true>(a, XfNone(), b, XfNone(), ep, 4 * C, 2 * C, M,
-                                                     wgrad_ksplit(4 * C, 2 * C, M, BN), st, dz_colsum)));
+        DISPATCH_BN(2 * C, (launch_wgrad<T, BN>(a, b, XfNone(), dw, dz_colsum, ws, 4 * C, 2 * C, M, st)));
     });
     return check_launch("lstm_wgrad");
 }

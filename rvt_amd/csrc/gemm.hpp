@@ -19,6 +19,7 @@
 // (64 x BN/2) = 2 x (BN/64) MFMA 32x32 blocks; K tile = 128 bytes (64 bf16 / 32 f32), register-staged
 // double buffering (global->VGPR for tile k+1 is issued before the MFMAs of tile k).
 #pragma once
+#include <stdlib.h>
 #include <type_traits>
 #include "common.hpp"
 
@@ -154,7 +155,7 @@ template <class T, int ROWS, class Src, class Xf> struct NTLoader {
             tile_store_frag<T>(tile, u / FPR, u % FPR, v);
         }
     }
-    __device__ __forceinline__ void flush_colsum(float*, int) const {}
+    __device__ __forceinline__ void flush_colsum(float*, int, float*, int) const {}
 };
 
 // Transposing loader: tile row = source COLUMN (feature), contraction = source ROW (token).
@@ -230,11 +231,25 @@ template <class T, int ROWS, class Src, class Xf, bool HIGH> struct TNLoader {
             r[j] = v;                 // raw rows; transform / column sums / transpose happen in store()
         }
     }
-    // out[feature] += token sums seen by this thread (bias gradient = column sum of dY); call once at the end
-    __device__ __forceinline__ void flush_colsum(float* out, int row0) const {
-        if (u < 0 || !fvalid) return;
+    // Fold the FPR token-chunk threads that own the same 8 features through LDS and store the block's sums to
+    // out[row0 + feature] (plain store: `out` is this K-slice's private row of the split-K workspace).
+    // Must be called by ALL threads of the workgroup; `scratch` = >= NUNITS*8 floats of free LDS.
+    __device__ __forceinline__ void flush_colsum(float* out, int row0, float* scratch, int n_features) const {
+        if (u >= 0) {
 #pragma unroll
-        for (int f = 0; f < 8; f++) atomicAdd(out + row0 + (u % FC) * 8 + f, csum[f]);
+            for (int f = 0; f < 8; f++) scratch[u * 8 + f] = fvalid ? csum[f] : 0.f;
+        }
+        __syncthreads();
+        if (u >= 0 && u < FC) {
+#pragma unroll
+            for (int f = 0; f < 8; f++) {
+                float a = 0.f;
+                for (int tc = 0; tc < FPR; tc++) a += scratch[(tc * FC + u) * 8 + f];
+                const int feat = row0 + u * 8 + f;
+                if (feat < n_features) out[feat] = a;
+            }
+        }
+        __syncthreads();
     }
     __device__ __forceinline__ void store(char* tile, const Xf& xf, int tid) {
         if (u < 0) return;
@@ -258,7 +273,8 @@ template <class T, int ROWS, class Src, class Xf, bool HIGH> struct TNLoader {
 // ------------------------------------------------------------------------------------------------
 // epilogues: called with UNIT consecutive columns (n0 .. n0+UNIT-1) of row m, both in range
 // ------------------------------------------------------------------------------------------------
-template <class T> struct EpStore {            // out = v (+bias) (+add)
+template <class T> struct EpStore {
+    __device__ __forceinline__ void begin_block(int) {}            // out = v (+bias) (+add)
     static constexpr int UNIT = 8;
     T* out; int ld; const float* bias; const T* add;
     __device__ __forceinline__ void operator()(int m, int n0, float (&v)[8]) const {
@@ -275,7 +291,8 @@ template <class T> struct EpStore {            // out = v (+bias) (+add)
     }
 };
 
-template <class T> struct EpScaleRes {         // out = res + gamma * (v + bias)     (LayerScale + residual)
+template <class T> struct EpScaleRes {
+    __device__ __forceinline__ void begin_block(int) {}         // out = res + gamma * (v + bias)     (LayerScale + residual)
     static constexpr int UNIT = 8;
     T* out; const T* res; int ld; const float* bias; const float* gamma;
     __device__ __forceinline__ void operator()(int m, int n0, float (&v)[8]) const {
@@ -286,7 +303,8 @@ template <class T> struct EpScaleRes {         // out = res + gamma * (v + bias)
     }
 };
 
-template <class T> struct EpGeluBwd {          // out = v * gelu'(pre[m][n])
+template <class T> struct EpGeluBwd {
+    __device__ __forceinline__ void begin_block(int) {}          // out = v * gelu'(pre[m][n])
     static constexpr int UNIT = 8;
     T* out; const T* pre; int ld;
     __device__ __forceinline__ void operator()(int m, int n0, float (&v)[8]) const {
@@ -297,7 +315,8 @@ template <class T> struct EpGeluBwd {          // out = v * gelu'(pre[m][n])
     }
 };
 
-template <class T> struct EpSplit2 {           // columns [0,C) -> out0, [C,2C) -> out1 (both ld = C)
+template <class T> struct EpSplit2 {
+    __device__ __forceinline__ void begin_block(int) {}           // columns [0,C) -> out0, [C,2C) -> out1 (both ld = C)
     static constexpr int UNIT = 8;
     T* out0; T* out1; int C;
     __device__ __forceinline__ void operator()(int m, int n0, float (&v)[8]) const {
@@ -306,8 +325,9 @@ template <class T> struct EpSplit2 {           // columns [0,C) -> out0, [C,2C) 
     }
 };
 
-struct EpAtomicF32 {                           // split-K partial sums of a weight gradient
+struct EpAtomicF32 {                           // direct atomic accumulation (kept for tiny problems / no workspace)
     static constexpr int UNIT = 8;
+    __device__ __forceinline__ void begin_block(int) {}
     float* out; int ld;
     __device__ __forceinline__ void operator()(int m, int n0, float (&v)[8]) const {
 #pragma unroll
@@ -315,8 +335,33 @@ struct EpAtomicF32 {                           // split-K partial sums of a weig
     }
 };
 
+// two-stage split-K: every K-slice stores its partial tile to ws[slice][M][N] with plain stores; a small
+// reduction kernel folds the slices afterwards.  (Device-scope float atomics execute memory-side on the
+// 8-XCD MI355X — ~64 B of fabric traffic and ~0.4 ns each chip-wide — so they are kept off the hot path.)
+struct EpPartialStore {
+    static constexpr int UNIT = 8;
+    float* ws; int ld; size_t slice_elems; int slice;
+    __device__ __forceinline__ void begin_block(int split) { slice = split; }
+    __device__ __forceinline__ void operator()(int m, int n0, float (&v)[8]) const {
+        float* o = ws + (size_t)slice * slice_elems + (size_t)m * ld + n0;
+        *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    }
+};
+
+// out[i] += sum_s ws[s][i]
+__global__ void __launch_bounds__(256)
+splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int nsplit, size_t count) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+        float a = 0.f;
+        for (int s = 0; s < nsplit; s++) a += ws[(size_t)s * count + i];
+        out[i] += a;
+    }
+}
+
 // conv input-gradient of one parity class: row m = (frame, yy, xx) -> pixel (s*yy+py, s*xx+px); out = v + add
 template <class T> struct EpDgradScatter {
+    __device__ __forceinline__ void begin_block(int) {}
     static constexpr int UNIT = 8;
     T* out; const T* add; int H, W, Cin, s, py, px; FastDiv dHcWc, dWc;
     __device__ __forceinline__ void operator()(int m, int n0, float (&v)[8]) const {
@@ -337,6 +382,7 @@ template <class T> struct EpDgradScatter {
 //   n' = (c/8)*32 + gate*8 + (c%8)      (gate order f,i,o,g — reference rnn.py:57-64)
 // i.e. a 32-column unit holds the four gates of 8 consecutive channels.
 template <class T> struct EpLstm {
+    __device__ __forceinline__ void begin_block(int) {}
     static constexpr int UNIT = 32;
     const float* bias;      // permuted like the columns, length 4C
     const float* c_prev;    // [rows][C] fp32
@@ -382,99 +428,137 @@ template <int BN> struct GemmSmem {
 
 template <class T, int BN, bool TN, class ASrc, class AXf, class BSrc, class BXf, class Ep>
 __global__ void __launch_bounds__(256)
-gemm_kernel(ASrc as, AXf axf, BSrc bs, BXf bxf, Ep ep, int M, int N, int K, int n_tiles, int ksplit_len,
-            float* a_colsum) {
+gemm_kernel(ASrc as, AXf axf, BSrc bs, BXf bxf, Ep ep, int M, int N, int K, int m_tiles, int n_tiles, int ksplit_len,
+            float* a_colsum, int panel_major) {
     constexpr int BM = 128;
     constexpr int BK = TileGeom<T>::BK;
     constexpr int WN = BN / 64;
+    constexpr int STAGE_BYTES = (BM + BN) * 128;   // A tile then B tile, two stages
     __shared__ __attribute__((aligned(16))) char smem[GemmSmem<BN>::BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int tile = blockIdx.x;
-    const int m0 = (tile / n_tiles) * BM, n0 = (tile % n_tiles) * BN;
     const int kbeg = blockIdx.y * ksplit_len;
     const int kend = (kbeg + ksplit_len < K) ? kbeg + ksplit_len : K;
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    const int G = gridDim.x;
+
+    // Persistent tile walk (NT GEMMs launch ~2-3 workgroups per CU and stride over the tiles; TN launches one
+    // workgroup per (tile, K-slice)).  panel_major: a workgroup sweeps all N tiles of its 128-row panel so the
+    // A panel comes from HBM once; otherwise tiles are dealt round-robin with N fastest.
+    auto tile_of = [&](int seq, int& mt, int& nt) -> bool {
+        if (panel_major) { mt = blockIdx.x + (seq / n_tiles) * G; nt = seq % n_tiles; return mt < m_tiles; }
+        const int t = blockIdx.x + seq * G;
+        mt = t / n_tiles; nt = t - mt * n_tiles;
+        return t < m_tiles * n_tiles;
+    };
 
     typedef typename std::conditional<TN, TNLoader<T, BM, ASrc, AXf, false>, NTLoader<T, BM, ASrc, AXf>>::type LA;
     typedef typename std::conditional<TN, TNLoader<T, BN, BSrc, BXf, true>, NTLoader<T, BN, BSrc, BXf>>::type LB;
     LA la; LB lb;
-    la.init(as, m0, tid);
-    lb.init(bs, n0, tid);
+    ep.begin_block((int)blockIdx.y);
 
-    f32x16 acc[2][WN];
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < WN; j++) acc_zero(acc[i][j]);
-
-    constexpr int STAGE_BYTES = (BM + BN) * 128;   // A tile then B tile, two stages
-
-    const int nk = (kend - kbeg + BK - 1) / BK;
-    if (nk > 0) {
+    int seq = 0, mt, nt;
+    bool have = tile_of(0, mt, nt);
+    if (have && nk > 0) {
+        la.init(as, mt * BM, tid);
+        lb.init(bs, nt * BN, tid);
         la.load(as, axf, kbeg, kend, tid);
         lb.load(bs, bxf, kbeg, kend, tid);
-        la.store(smem, axf, tid);
-        lb.store(smem + BM * 128, bxf, tid);
     }
-    __syncthreads();
-    for (int kt = 0; kt < nk; kt++) {
-        const int cur = kt & 1;
-        const bool more = kt + 1 < nk;
-        const char* At = smem + cur * STAGE_BYTES;
-        const char* Bt = At + BM * 128;
-        if (more) {
-            la.load(as, axf, kbeg + (kt + 1) * BK, kend, tid);
-            lb.load(bs, bxf, kbeg + (kt + 1) * BK, kend, tid);
-        }
+    while (have) {
+        const int m0 = mt * BM, n0 = nt * BN;
+        f32x16 acc[2][WN];
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ks++) {
-            const int fc = ks * 2 + (lane >> 5);
-            frag_t<T> a[2], b[WN];
+        for (int i = 0; i < 2; i++)
 #pragma unroll
-            for (int i = 0; i < 2; i++) a[i] = tile_load_frag<T>(At, wm * 64 + i * 32 + (lane & 31), fc);
-#pragma unroll
-            for (int j = 0; j < WN; j++) b[j] = tile_load_frag<T>(Bt, wn * (BN / 2) + j * 32 + (lane & 31), fc);
-#pragma unroll
-            for (int i = 0; i < 2; i++)
-#pragma unroll
-                for (int j = 0; j < WN; j++) mma32(acc[i][j], a[i], b[j]);
-        }
-        if (more) {
-            la.store(smem + (cur ^ 1) * STAGE_BYTES, axf, tid);
-            lb.store(smem + (cur ^ 1) * STAGE_BYTES + BM * 128, bxf, tid);
+            for (int j = 0; j < WN; j++) acc_zero(acc[i][j]);
+
+        if (nk > 0) {
+            la.store(smem, axf, tid);
+            lb.store(smem + BM * 128, bxf, tid);
         }
         __syncthreads();
-    }
-
-    if (TN && a_colsum != nullptr && n0 == 0) la.flush_colsum(a_colsum, m0);
-
-    // ---- epilogue: accumulators -> LDS (fp32, row pitch BN+4) -> UNIT-wide row segments ----
-    float* stage = reinterpret_cast<float*>(smem);
-    constexpr int LDS_LD = BN + 4;
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < WN; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-                stage[(wm * 64 + i * 32 + acc_row(r, lane)) * LDS_LD + wn * (BN / 2) + j * 32 + (lane & 31)] = acc[i][j][r];
-    __syncthreads();
-    constexpr int UNIT = Ep::UNIT;
-    constexpr int UPR = BN / UNIT;
-    for (int u = tid; u < BM * UPR; u += 256) {
-        const int row = u / UPR, cu = u % UPR;
-        const int m = m0 + row, n = n0 + cu * UNIT;
-        if (m < M && n < N) {
-            float v[UNIT];
-#pragma unroll
-            for (int q = 0; q < UNIT / 4; q++) {
-                f32x4 t = *reinterpret_cast<const f32x4*>(stage + row * LDS_LD + cu * UNIT + q * 4);
-                v[q * 4 + 0] = t[0]; v[q * 4 + 1] = t[1]; v[q * 4 + 2] = t[2]; v[q * 4 + 3] = t[3];
+        for (int kt = 0; kt < nk; kt++) {
+            const int cur = kt & 1;
+            const bool more = kt + 1 < nk;
+            const char* At = smem + cur * STAGE_BYTES;
+            const char* Bt = At + BM * 128;
+            if (more) {
+                la.load(as, axf, kbeg + (kt + 1) * BK, kend, tid);
+                lb.load(bs, bxf, kbeg + (kt + 1) * BK, kend, tid);
             }
-            ep(m, n, v);
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ks++) {
+                const int fc = ks * 2 + (lane >> 5);
+                frag_t<T> a[2], b[WN];
+#pragma unroll
+                for (int i = 0; i < 2; i++) a[i] = tile_load_frag<T>(At, wm * 64 + i * 32 + (lane & 31), fc);
+#pragma unroll
+                for (int j = 0; j < WN; j++) b[j] = tile_load_frag<T>(Bt, wn * (BN / 2) + j * 32 + (lane & 31), fc);
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int j = 0; j < WN; j++) mma32(acc[i][j], a[i], b[j]);
+            }
+            if (more) {
+                la.store(smem + (cur ^ 1) * STAGE_BYTES, axf, tid);
+                lb.store(smem + (cur ^ 1) * STAGE_BYTES + BM * 128, bxf, tid);
+            }
+            __syncthreads();
         }
+
+        // bias gradient: per-K-slice partial column sums of the A operand -> a_colsum[slice][M]  (workgroup-uniform branch)
+        if (TN && a_colsum != nullptr && n0 == 0)
+            la.flush_colsum(a_colsum + (size_t)blockIdx.y * M, m0, reinterpret_cast<float*>(smem), M);
+
+        // next tile's first K tile: issue its global loads now so they fly during this tile's epilogue
+        int mt2 = 0, nt2 = 0;
+        const bool have2 = tile_of(seq + 1, mt2, nt2);
+        if (have2 && nk > 0) {
+            la.init(as, mt2 * BM, tid);
+            lb.init(bs, nt2 * BN, tid);
+            la.load(as, axf, kbeg, kend, tid);
+            lb.load(bs, bxf, kbeg, kend, tid);
+        }
+
+        // ---- epilogue: accumulators -> LDS (fp32, row pitch BN+4) -> UNIT-wide row segments ----
+        float* stage = reinterpret_cast<float*>(smem);
+        constexpr int LDS_LD = BN + 4;
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < WN; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    stage[(wm * 64 + i * 32 + acc_row(r, lane)) * LDS_LD + wn * (BN / 2) + j * 32 + (lane & 31)] = acc[i][j][r];
+        __syncthreads();
+        constexpr int UNIT = Ep::UNIT;
+        constexpr int UPR = BN / UNIT;
+        for (int u = tid; u < BM * UPR; u += 256) {
+            const int row = u / UPR, cu = u % UPR;
+            const int m = m0 + row, n = n0 + cu * UNIT;
+            if (m < M && n < N) {
+                float v[UNIT];
+#pragma unroll
+                for (int q = 0; q < UNIT / 4; q++) {
+                    f32x4 t = *reinterpret_cast<const f32x4*>(stage + row * LDS_LD + cu * UNIT + q * 4);
+                    v[q * 4 + 0] = t[0]; v[q * 4 + 1] = t[1]; v[q * 4 + 2] = t[2]; v[q * 4 + 3] = t[3];
+                }
+                ep(m, n, v);
+            }
+        }
+        __syncthreads();            // staging buffer is reused by the next tile's operand stores
+        have = have2; mt = mt2; nt = nt2; seq++;
     }
+}
+
+inline int gemm_slices(int K, int ksplit, int BK) {
+    if (ksplit < 1) ksplit = 1;
+    int klen = ((K + ksplit - 1) / ksplit + BK - 1) / BK * BK;
+    if (klen < BK) klen = BK;
+    int nsplit = (K + klen - 1) / klen;
+    return nsplit < 1 ? 1 : nsplit;
 }
 
 template <class T, int BN, bool TN, class ASrc, class AXf, class BSrc, class BXf, class Ep>
@@ -486,10 +570,17 @@ inline void launch_gemm(const ASrc& as, const AXf& axf, const BSrc& bs, const BX
     if (ksplit < 1) ksplit = 1;
     int klen = ((K + ksplit - 1) / ksplit + BK - 1) / BK * BK;
     if (klen < BK) klen = BK;
-    int nsplit = (K + klen - 1) / klen;
-    if (nsplit < 1) nsplit = 1;
-    hipLaunchKernelGGL((gemm_kernel<T, BN, TN, ASrc, AXf, BSrc, BXf, Ep>), dim3(m_tiles * n_tiles, nsplit), dim3(256), 0,
-                       stream, as, axf, bs, bxf, ep, M, N, K, n_tiles, klen, a_colsum);
+    int nsplit = gemm_slices(K, ksplit, BK);
+    int total = m_tiles * n_tiles;
+    int gx = total, panel_major = 0;
+    if (!TN) {                                   // persistent: ~one resident wave of workgroups striding over the tiles
+        static const int resident_override = getenv("RVT_GEMM_RESIDENT") ? atoi(getenv("RVT_GEMM_RESIDENT")) : 0;
+        const int resident = resident_override > 0 ? resident_override : 256 * (BN == 64 ? 3 : 2);
+        if (total > resident) gx = resident;
+        panel_major = (n_tiles > 1 && m_tiles >= 4 * gx) ? 1 : 0;
+    }
+    hipLaunchKernelGGL((gemm_kernel<T, BN, TN, ASrc, AXf, BSrc, BXf, Ep>), dim3(gx, nsplit), dim3(256), 0, stream, as, axf,
+                       bs, bxf, ep, M, N, K, m_tiles, n_tiles, klen, a_colsum, panel_major);
 }
 
 }  // namespace rvt

@@ -18,6 +18,21 @@ def _out(like: Tensor, shape, dtype=None, out: Optional[Tensor] = None) -> Tenso
     return torch.empty(shape, dtype=dtype or like.dtype, device=like.device)
 
 
+_WS = {}
+
+
+def _wgrad_ws(like: Tensor, out_rows: int, out_cols: int, tokens: int, want_colsum: bool) -> Tensor:
+    """Grow-only per-device scratch for the two-stage split-K reduction (kernels on one stream serialise, so a
+    single buffer is safe to share between consecutive weight-gradient launches)."""
+    n = L.get_lib().rvt_wgrad_workspace_floats(L.dtype_code(like.dtype), out_rows, out_cols, tokens, int(want_colsum))
+    key = (like.device.type, like.device.index)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < n:
+        ws = torch.empty(max(n, 1 << 20), dtype=torch.float32, device=like.device)
+        _WS[key] = ws
+    return ws
+
+
 def prepack_input(src: Tensor, H: int, W: int, Cp: int, dtype: torch.dtype, out: Optional[Tensor] = None) -> Tensor:
     """(F,Cin,h,w) uint8/float32 -> (F,H,W,Cp) `dtype`, zero padded (cast+pad of modules/detection.py:133-134)."""
     assert src.dim() == 4 and src.dtype in (torch.uint8, torch.float32)
@@ -57,8 +72,9 @@ def conv_wgrad(x: Tensor, dy: Tensor, dw: Tensor, k: int, stride: int, pad: int)
     F_, H, W, Cin = x.shape
     Cout = dy.shape[-1]
     assert dw.dtype == torch.float32 and tuple(dw.shape) == (Cout, k * k * Cin)
-    L.call('rvt_conv_wgrad', L.ptr(x), L.ptr(dy), L.ptr(dw), L.dtype_code(x.dtype), F_, H, W, Cin, Cout, k, stride, pad,
-           L.stream_of(x))
+    ws = _wgrad_ws(x, Cout, k * k * Cin, dy.numel() // Cout, False)
+    L.call('rvt_conv_wgrad', L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(ws), L.dtype_code(x.dtype), F_, H, W, Cin, Cout, k,
+           stride, pad, L.stream_of(x))
 
 
 def layernorm_fwd(x: Tensor, w: Tensor, b: Tensor, eps: float, out: Optional[Tensor] = None) -> Tensor:
@@ -123,8 +139,9 @@ def linear_wgrad(dy: Tensor, x: Tensor, dw: Tensor, gelu_in: bool = False, colsu
     M = dy.numel() // N
     assert dw.dtype == torch.float32 and tuple(dw.shape) == (N, K) and x.numel() // K == M
     assert colsum_out is None or (colsum_out.dtype == torch.float32 and colsum_out.numel() == N)
-    L.call('rvt_linear_wgrad', L.ptr(dy), L.ptr(x), L.ptr(dw), L.ptr(colsum_out), L.dtype_code(dy.dtype), M, N, K,
-           int(gelu_in), L.stream_of(dy))
+    ws = _wgrad_ws(dy, N, K, M, colsum_out is not None)
+    L.call('rvt_linear_wgrad', L.ptr(dy), L.ptr(x), L.ptr(dw), L.ptr(colsum_out), L.ptr(ws), L.dtype_code(dy.dtype),
+           M, N, K, int(gelu_in), L.stream_of(dy))
 
 
 def colsum(x: Tensor, out: Tensor) -> None:
@@ -177,8 +194,9 @@ def lstm_wgrad(dz: Tensor, x: Tensor, h_prev: Tensor, dw: Tensor, colsum_out: Op
     C = x.shape[-1]
     M = x.numel() // C
     assert dw.dtype == torch.float32 and tuple(dw.shape) == (4 * C, 2 * C)
-    L.call('rvt_lstm_wgrad', L.ptr(dz), L.ptr(x), L.ptr(h_prev), L.ptr(dw), L.ptr(colsum_out), L.dtype_code(dz.dtype),
-           M, C, L.stream_of(dz))
+    ws = _wgrad_ws(dz, 4 * C, 2 * C, M, colsum_out is not None)
+    L.call('rvt_lstm_wgrad', L.ptr(dz), L.ptr(x), L.ptr(h_prev), L.ptr(dw), L.ptr(colsum_out), L.ptr(ws),
+           L.dtype_code(dz.dtype), M, C, L.stream_of(dz))
 
 
 def dwconv(x: Tensor, w: Tensor, b: Optional[Tensor], k: int, transpose: bool = False, out: Optional[Tensor] = None) -> Tensor:

@@ -4,6 +4,9 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# Test-size problems have only a handful of GEMM tiles; shrink the persistent grid (normally ~2-3 workgroups per CU)
+# so that the multi-tile walk + cross-tile prefetch of gemm_kernel is what the tests execute (emulator AND GPU).
+os.environ.setdefault('RVT_GEMM_RESIDENT', '3')
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

@@ -44,7 +44,8 @@ def test_prepack(backend, dt, u8):
 
 
 @pytest.mark.parametrize('dt', DTYPES)
-@pytest.mark.parametrize('M,N,K,gelu', [(200, 72, 40, False), (130, 136, 64, True), (64, 16, 16, False), (257, 264, 136, False)])
+@pytest.mark.parametrize('M,N,K,gelu', [(200, 72, 40, False), (130, 136, 64, True), (64, 16, 16, False), (257, 264, 136, False),
+                                        (1600, 264, 40, False), (1000, 40, 72, True)])
 def test_linear_fwd(backend, dt, M, N, K, gelu):
     x, w = rnd((M, K), backend, dt, 1), rnd((N, K), backend, dt, 2, 0.3)
     b = rnd((N,), backend, torch.float32, 3)
