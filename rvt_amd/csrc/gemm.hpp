@@ -34,6 +34,7 @@ template <class T> struct PlainSrc {
     __device__ __forceinline__ Ctx row_ctx(int m) const { return (m >= 0 && m < rows) ? p + (size_t)m * ld : nullptr; }
     __device__ __forceinline__ void split(int kcol, int& seg, int& off) const { seg = 0; off = kcol; }
     __device__ __forceinline__ const T* seg_ptr(const Ctx& c, int) const { return c; }
+    __device__ __forceinline__ const T* safe() const { return p; }
 };
 
 template <class T> struct ConcatSrc {   // [x | h], both [rows][C]
@@ -42,8 +43,10 @@ template <class T> struct ConcatSrc {   // [x | h], both [rows][C]
     __device__ __forceinline__ Ctx row_ctx(int m) const { return (m >= 0 && m < rows) ? m : -1; }
     __device__ __forceinline__ void split(int kcol, int& seg, int& off) const { seg = kcol >= C; off = kcol - seg * C; }
     __device__ __forceinline__ const T* seg_ptr(const Ctx& c, int seg) const {
-        return c < 0 ? nullptr : (seg ? h : x) + (size_t)c * C;
+        const T* q = (seg ? h : x) + (size_t)(c < 0 ? 0 : c) * C;
+        return c < 0 ? nullptr : q;
     }
+    __device__ __forceinline__ const T* safe() const { return x; }
 };
 
 // rows = output pixels (frame, oy, ox); columns = (ky, kx, cin) with cin fastest; input is [F][H][W][Cin]
@@ -53,23 +56,25 @@ template <class T> struct Im2colSrc {
     struct Ctx { int base; int iy0; int ix0; };
     __device__ __forceinline__ Ctx row_ctx(int m) const {
         Ctx c;
-        if (m < 0 || m >= rows) { c.base = -1; c.iy0 = 0; c.ix0 = 0; return c; }
+        const bool ok = (m >= 0) & (m < rows);
         uint32_t f, rem, oy, ox;
-        dHoWo.divmod((uint32_t)m, f, rem);
+        dHoWo.divmod((uint32_t)(ok ? m : 0), f, rem);
         dWo.divmod(rem, oy, ox);
-        c.base = (int)f * H * W; c.iy0 = (int)oy * stride - pad; c.ix0 = (int)ox * stride - pad;
+        c.base = ok ? (int)f * H * W : -1; c.iy0 = (int)oy * stride - pad; c.ix0 = (int)ox * stride - pad;
         return c;
     }
     __device__ __forceinline__ void split(int kcol, int& seg, int& off) const {
         uint32_t q, r; dCin.divmod((uint32_t)kcol, q, r); seg = (int)q; off = (int)r;
     }
     __device__ __forceinline__ const T* seg_ptr(const Ctx& c, int seg) const {
-        if (c.base < 0) return nullptr;
         uint32_t ky, kx; dkw.divmod((uint32_t)seg, ky, kx);
-        int iy = c.iy0 + (int)ky, ix = c.ix0 + (int)kx;
-        if (iy < 0 || iy >= H || ix < 0 || ix >= W) return nullptr;
-        return p + ((size_t)c.base + (size_t)iy * W + ix) * Cin;
+        const int iy = c.iy0 + (int)ky, ix = c.ix0 + (int)kx;
+        const bool ok = (c.base >= 0) & (iy >= 0) & (iy < H) & (ix >= 0) & (ix < W);
+        const size_t pix = ok ? (size_t)c.base + (size_t)iy * W + ix : 0;      // branch-free: clamp, then select
+        const T* q = p + pix * Cin;
+        return ok ? q : nullptr;
     }
+    __device__ __forceinline__ const T* safe() const { return p; }
 };
 
 // Input-gradient gather of a strided conv for ONE parity class (py,px) of input pixels
@@ -83,25 +88,26 @@ template <class T> struct DgradSrc {
     struct Ctx { int f; int y; int x; };
     __device__ __forceinline__ Ctx row_ctx(int m) const {
         Ctx c;
-        if (m < 0 || m >= rows) { c.f = -1; c.y = 0; c.x = 0; return c; }
+        const bool ok = (m >= 0) & (m < rows);
         uint32_t f, rem, yy, xx;
-        dHcWc.divmod((uint32_t)m, f, rem);
+        dHcWc.divmod((uint32_t)(ok ? m : 0), f, rem);
         dWc.divmod(rem, yy, xx);
-        c.f = (int)f; c.y = (int)yy * s + py; c.x = (int)xx * s + px;
+        c.f = ok ? (int)f : -1; c.y = (int)yy * s + py; c.x = (int)xx * s + px;
         return c;
     }
     __device__ __forceinline__ void split(int kcol, int& seg, int& off) const {
         uint32_t q, r; dCout.divmod((uint32_t)kcol, q, r); seg = (int)q; off = (int)r;
     }
     __device__ __forceinline__ const T* seg_ptr(const Ctx& c, int seg) const {
-        if (c.f < 0) return nullptr;
-        int a = seg / nkx, b = seg - a * nkx;
-        int ny = c.y + pad - ky[a], nx = c.x + pad - kx[b];
-        if (ny < 0 || nx < 0) return nullptr;
-        int oy = ny / s, ox = nx / s;
-        if (oy >= Ho || ox >= Wo) return nullptr;
-        return dy + (((size_t)c.f * Ho + oy) * Wo + ox) * Cout;
+        const int a = nkx == 1 ? seg : (nkx == 2 ? seg >> 1 : seg / nkx), b = seg - a * nkx;
+        const int ny = c.y + pad - ky[a & 3], nx = c.x + pad - kx[b & 3];
+        const int oy = s == 2 ? ny >> 1 : ny / s, ox = s == 2 ? nx >> 1 : nx / s;
+        const bool ok = (c.f >= 0) & (ny >= 0) & (nx >= 0) & (oy < Ho) & (ox < Wo);
+        const size_t pix = ok ? ((size_t)c.f * Ho + oy) * Wo + ox : 0;
+        const T* q = dy + pix * Cout;
+        return ok ? q : nullptr;
     }
+    __device__ __forceinline__ const T* safe() const { return dy; }
 };
 
 // element-wise transforms applied to loaded operand values
@@ -134,16 +140,15 @@ template <class T, int ROWS, class Src, class Xf> struct NTLoader {
         for (int i = 0; i < NF; i++) {
             int fc = (tid + i * 256) % FPR;
             int kcol = k0 + fc * 8;
-            frag_t<T> v = frag_zero<T>();
-            bool ok = false;
-            if (kcol < kend) {
-                int seg, off;
-                s.split(kcol, seg, off);
-                const T* p = s.seg_ptr(ctx[i], seg);
-                if (p) { v = frag_load<T>(p + off); ok = true; }
-            }
-            r[i] = v;                 // raw: nothing consumes the loaded registers until store(), so the
-            valid[i] = ok;            // loads stay in flight across the MFMA phase of the current tile
+            // Branch-free: always issue the load (from a clamped, always-valid address) and remember whether the
+            // element is real; padding is zeroed by a select in store().  Nothing consumes the loaded registers
+            // until store(), so the loads stay in flight across the MFMA phase of the current tile.
+            int seg, off;
+            s.split(kcol < kend ? kcol : 0, seg, off);
+            const T* p = s.seg_ptr(ctx[i], seg);
+            const bool ok = (kcol < kend) & (p != nullptr);
+            r[i] = frag_load<T>(ok ? p + off : s.safe());
+            valid[i] = ok;
         }
     }
     __device__ __forceinline__ void store(char* tile, const Xf& xf, int tid) {
@@ -151,7 +156,9 @@ template <class T, int ROWS, class Src, class Xf> struct NTLoader {
         for (int i = 0; i < NF; i++) {
             int u = tid + i * 256;
             frag_t<T> v = r[i];
-            if (!Xf::identity && valid[i]) v = xf_apply<T>(v, xf);
+            if (!Xf::identity) v = xf_apply<T>(v, xf);
+            const frag_t<T> z = frag_zero<T>();
+            v = valid[i] ? v : z;
             tile_store_frag<T>(tile, u / FPR, u % FPR, v);
         }
     }
@@ -221,14 +228,12 @@ template <class T, int ROWS, class Src, class Xf, bool HIGH> struct TNLoader {
         vmask = 0;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            frag_t<T> v = frag_zero<T>();
             const int tok = tok0 + j;
-            if (fvalid && tok < kend) {
-                typename Src::Ctx c = s.row_ctx(tok);
-                const T* p = s.seg_ptr(c, seg);
-                if (p) { v = frag_load<T>(p + off); vmask |= 1u << j; }
-            }
-            r[j] = v;                 // raw rows; transform / column sums / transpose happen in store()
+            typename Src::Ctx c = s.row_ctx(tok < kend ? tok : -1);
+            const T* p = s.seg_ptr(c, seg);
+            const bool ok = fvalid & (tok < kend) & (p != nullptr);
+            r[j] = frag_load<T>(ok ? p + off : s.safe());     // branch-free; raw rows, post-processing in store()
+            vmask |= ok ? (1u << j) : 0u;
         }
     }
     // Fold the FPR token-chunk threads that own the same 8 features through LDS and store the block's sums to
@@ -257,7 +262,9 @@ template <class T, int ROWS, class Src, class Xf, bool HIGH> struct TNLoader {
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             frag_t<T> v = r[j];
-            if (!Xf::identity && ((vmask >> j) & 1u)) v = xf_apply<T>(v, xf);
+            if (!Xf::identity) v = xf_apply<T>(v, xf);
+            const frag_t<T> z = frag_zero<T>();
+            v = ((vmask >> j) & 1u) ? v : z;
             in[j] = v;
             if (WANT_COLSUM) {
 #pragma unroll
