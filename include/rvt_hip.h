@@ -63,13 +63,17 @@ int rvt_layernorm_bwd(const void* x, const float* w, const void* dy, const void*
  * (maxvit.py:347,353 and the MLP 100-118). */
 int rvt_linear_fwd(const void* x, const void* w, const float* bias, void* y, int dtype, int M, int N, int K,
                    int gelu_in, void* stream);
+/* MLP fc1 with its activation (maxvit.py:100-112): g = GELU(x W^T + bias) and, if gp != NULL, gp = GELU'(x W^T + bias)
+ * (saved for backward so that no kernel re-evaluates erf). */
+int rvt_linear_gelu_fwd(const void* x, const void* w, const float* bias, void* g, void* gp, int dtype, int M, int N, int K,
+                        void* stream);
 /* y = res + gamma * (f(x) W^T + bias)   — LayerScale + residual (maxvit.py:51-53,268-269). */
 int rvt_linear_scale_res_fwd(const void* x, const void* w, const float* bias, const float* gamma, const void* res,
                              void* y, int dtype, int M, int N, int K, int gelu_in, void* stream);
-/* dx[M][K] = dy[M][N] Wt[K][N]^T, optionally * gelu'(pre[M][K]) (pre nullable), optionally + add[M][K]
- * (add nullable; not combinable with gelu_pre). */
-int rvt_linear_dgrad(const void* dy, const void* wt, const void* gelu_pre, const void* add, void* dx, int dtype, int M,
-                     int N, int K, void* stream);
+/* dx[M][K] = dy[M][N] Wt[K][N]^T, then at most one of:  * gelu'(gelu_pre[M][K]),  + add[M][K],  * mul[M][K]
+ * (all nullable). */
+int rvt_linear_dgrad(const void* dy, const void* wt, const void* gelu_pre, const void* add, const void* mul, void* dx,
+                     int dtype, int M, int N, int K, void* stream);
 /* dw[N][K] (float32) += dy[M][N]^T f(x)[M][K];  if dy_colsum != NULL also dy_colsum[N] += column sums of dy
  * (the bias gradient), computed from the tiles the kernel streams anyway. */
 int rvt_linear_wgrad(const void* dy, const void* x, float* dw, float* dy_colsum, float* ws, int dtype, int M, int N,

@@ -31,7 +31,8 @@ _SIGS = {
     'rvt_layernorm_bwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
     'rvt_linear_fwd': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     'rvt_linear_scale_res_fwd': [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
-    'rvt_linear_dgrad': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    'rvt_linear_dgrad': [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    'rvt_linear_gelu_fwd': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     'rvt_linear_wgrad': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     'rvt_colsum': [_vp, _vp, _i, _i, _i, _vp],
     'rvt_attn_fwd': [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],

@@ -167,7 +167,7 @@ attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, AttnGeom g) {
 }
 
 template <class T, int NB>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, 2)      // <= 256 VGPR+AGPR: two waves per SIMD instead of one
 attn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ dout, T* __restrict__ dqkv, AttnGeom g) {
     constexpr int LP = 32 * NB, PITCH = LP + 8, PSP = 40;
     __shared__ __attribute__((aligned(16))) T Qt[32 * PITCH];

@@ -38,7 +38,7 @@ static inline int grid_for(size_t units, int cap = 2048) {
 // split the token contraction of a weight gradient so that the launch fills the chip
 static inline int wgrad_ksplit(int out_rows, int out_cols, int tokens, int bn) {
     int tiles = ((out_rows + 127) / 128) * ((out_cols + bn - 1) / bn);
-    int want = imax(1, 768 / imax(1, tiles));
+    int want = imax(1, (256 * (bn == 64 ? 3 : 2)) / imax(1, tiles));     // one resident wave of workgroups
     int maxs = imax(1, tokens / 512);
     return imin(want, maxs);
 }
@@ -246,6 +246,19 @@ int rvt_linear_fwd(const void* x, const void* w, const float* bias, void* y, int
     return check_launch("linear_fwd");
 }
 
+int rvt_linear_gelu_fwd(const void* x, const void* w, const float* bias, void* g, void* gp, int dtype, int M, int N, int K,
+                        void* stream) {
+    RVT_CHECK(N % 8 == 0 && K % 8 == 0 && bias, "linear_gelu_fwd: N=%d K=%d must be multiples of 8, bias required", N, K);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_DTYPE(dtype, {
+        PlainSrc<T> a{(const T*)x, K, M, K};
+        PlainSrc<T> b{(const T*)w, K, N, K};
+        EpGeluDual<T> ep{(T*)g, (T*)gp, N, bias};
+        DISPATCH_BN(N, (launch_gemm<T, BN, false>(a, XfNone(), b, XfNone(), ep, M, N, K, 1, st)));
+    });
+    return check_launch("linear_gelu_fwd");
+}
+
 int rvt_linear_scale_res_fwd(const void* x, const void* w, const float* bias, const float* gamma, const void* res,
                              void* y, int dtype, int M, int N, int K, int gelu_in, void* stream) {
     RVT_CHECK(N % 8 == 0 && K % 8 == 0, "linear_scale_res_fwd: N=%d K=%d must be multiples of 8", N, K);
@@ -263,10 +276,11 @@ int rvt_linear_scale_res_fwd(const void* x, const void* w, const float* bias, co
     return check_launch("linear_scale_res_fwd");
 }
 
-int rvt_linear_dgrad(const void* dy, const void* wt, const void* gelu_pre, const void* add, void* dx, int dtype, int M,
-                     int N, int K, void* stream) {
+int rvt_linear_dgrad(const void* dy, const void* wt, const void* gelu_pre, const void* add, const void* mul, void* dx,
+                     int dtype, int M, int N, int K, void* stream) {
     RVT_CHECK(N % 8 == 0 && K % 8 == 0, "linear_dgrad: N=%d K=%d must be multiples of 8", N, K);
-    RVT_CHECK(!(gelu_pre && add), "linear_dgrad: gelu_pre and add are mutually exclusive");
+    RVT_CHECK((gelu_pre != nullptr) + (add != nullptr) + (mul != nullptr) <= 1,
+              "linear_dgrad: gelu_pre, add and mul are mutually exclusive");
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_DTYPE(dtype, {
         PlainSrc<T> a{(const T*)dy, N, M, N};
@@ -274,6 +288,9 @@ int rvt_linear_dgrad(const void* dy, const void* wt, const void* gelu_pre, const
         DISPATCH_BN(K, {
             if (gelu_pre) {
                 EpGeluBwd<T> ep{(T*)dx, (const T*)gelu_pre, K};
+                launch_gemm<T, BN, false>(a, XfNone(), b, XfNone(), ep, M, K, N, 1, st);
+            } else if (mul) {
+                EpMul<T> ep{(T*)dx, (const T*)mul, K};
                 launch_gemm<T, BN, false>(a, XfNone(), b, XfNone(), ep, M, K, N, 1, st);
             } else {
                 EpStore<T> ep{(T*)dx, K, nullptr, (const T*)add};

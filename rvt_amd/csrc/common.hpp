@@ -132,6 +132,13 @@ template <class T> __device__ __forceinline__ frag_t<T> tile_load_frag(const cha
     return v;
 }
 
+// keep the instruction scheduler from moving anything across this point (used to pin prefetch loads early)
+__device__ __forceinline__ void sched_fence() {
+#ifndef RVT_EMU
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
 // ---- scalar math -------------------------------------------------------------------------------
 __device__ __forceinline__ float fast_rcp(float x) {
 #ifdef RVT_EMU
@@ -160,6 +167,13 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     float e;
     const float er = erf_as(x * 0.70710678118654752f, e);
     return 0.5f * (1.0f + er) + x * 0.3989422804014327f * e;
+}
+// both at once (one erf/exp evaluation): used by the fc1 epilogue that saves GELU(x) and GELU'(x)
+__device__ __forceinline__ void gelu_both_f(float x, float& g, float& gp) {
+    float e;
+    const float c = 0.5f * (1.0f + erf_as(x * 0.70710678118654752f, e));
+    g = x * c;
+    gp = c + x * 0.3989422804014327f * e;
 }
 __device__ __forceinline__ float sigmoid_f(float x) { return fast_rcp(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanh_f(float x) {

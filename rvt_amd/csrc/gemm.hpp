@@ -322,6 +322,31 @@ template <class T> struct EpGeluBwd {
     }
 };
 
+template <class T> struct EpGeluDual {         // g = gelu(v + bias), gp = gelu'(v + bias)  (gp nullable)
+    __device__ __forceinline__ void begin_block(int) {}
+    static constexpr int UNIT = 8;
+    T* g; T* gp; int ld; const float* bias;
+    __device__ __forceinline__ void operator()(int m, int n0, float (&v)[8]) const {
+        float a[8], b[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) gelu_both_f(v[i] + bias[n0 + i], a[i], b[i]);
+        frag_store<T>(g + (size_t)m * ld + n0, frag_from_float<T>(a));
+        if (gp) frag_store<T>(gp + (size_t)m * ld + n0, frag_from_float<T>(b));
+    }
+};
+
+template <class T> struct EpMul {              // out = v * mul[m][n]
+    __device__ __forceinline__ void begin_block(int) {}
+    static constexpr int UNIT = 8;
+    T* out; const T* mul; int ld;
+    __device__ __forceinline__ void operator()(int m, int n0, float (&v)[8]) const {
+        float a[8]; frag_to_float<T>(frag_load<T>(mul + (size_t)m * ld + n0), a);
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] *= a[i];
+        frag_store<T>(out + (size_t)m * ld + n0, frag_from_float<T>(v));
+    }
+};
+
 template <class T> struct EpSplit2 {
     __device__ __forceinline__ void begin_block(int) {}           // columns [0,C) -> out0, [C,2C) -> out1 (both ld = C)
     static constexpr int UNIT = 8;
@@ -528,6 +553,7 @@ gemm_kernel(ASrc as, AXf axf, BSrc bs, BXf bxf, Ep ep, int M, int N, int K, int 
             la.load(as, axf, kbeg, kend, tid);
             lb.load(bs, bxf, kbeg, kend, tid);
         }
+        sched_fence();      // the prefetch must be ISSUED here, not sunk below the epilogue
 
         // ---- epilogue: accumulators -> LDS (fp32, row pitch BN+4) -> UNIT-wide row segments ----
         float* stage = reinterpret_cast<float*>(smem);

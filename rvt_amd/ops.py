@@ -119,16 +119,29 @@ def linear_scale_res_fwd(x: Tensor, w: Tensor, bias: Tensor, gamma: Tensor, res:
     return y
 
 
+def linear_gelu_fwd(x: Tensor, w: Tensor, bias: Tensor, want_grad: bool):
+    """g = GELU(x W^T + b), gp = GELU'(x W^T + b) (None unless want_grad)."""
+    K = x.shape[-1]
+    M = x.numel() // K
+    N = w.shape[0]
+    g = torch.empty((*x.shape[:-1], N), dtype=x.dtype, device=x.device)
+    gp = torch.empty_like(g) if want_grad else None
+    L.call('rvt_linear_gelu_fwd', L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(g), L.ptr(gp), L.dtype_code(x.dtype), M, N, K,
+           L.stream_of(x))
+    return g, gp
+
+
 def linear_dgrad(dy: Tensor, wt: Tensor, gelu_pre: Optional[Tensor] = None, add: Optional[Tensor] = None,
-                 out: Optional[Tensor] = None) -> Tensor:
-    """dx = dy @ wt.T with wt = W^T stored [K][N] (optionally folded with LayerScale), * gelu'(gelu_pre) or + add."""
+                 mul: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
+    """dx = dy @ wt.T with wt = W^T stored [K][N] (optionally folded with LayerScale), then * gelu'(gelu_pre),
+    + add or * mul."""
     N = dy.shape[-1]
     M = dy.numel() // N
     K = wt.shape[0]
     assert wt.shape[1] == N
     dx = _out(dy, (*dy.shape[:-1], K), out=out)
-    L.call('rvt_linear_dgrad', L.ptr(dy), L.ptr(wt), L.ptr(gelu_pre), L.ptr(add), L.ptr(dx), L.dtype_code(dy.dtype),
-           M, N, K, L.stream_of(dy))
+    L.call('rvt_linear_dgrad', L.ptr(dy), L.ptr(wt), L.ptr(gelu_pre), L.ptr(add), L.ptr(mul), L.ptr(dx),
+           L.dtype_code(dy.dtype), M, N, K, L.stream_of(dy))
     return dx
 
 

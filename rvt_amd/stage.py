@@ -79,10 +79,11 @@ def stage_seq_forward(sw: StageWeights, g: StageGeom, inp: Tensor, h0: Optional[
             a = ops.attn_fwd(qkv, F_, H, W, C, g.dim_head, g.ph, g.pw, window)    # maxvit.py:349-352
             xmid = ops.linear_scale_res_fwd(a, bw['proj_w'], bw['proj_b'], bw['g1'], x)        # :353, :268
             v2 = ops.layernorm_fwd(xmid, bw['n2_w'], bw['n2_b'], g.eps)
-            hd = ops.linear_fwd(v2, bw['fc1_w'], bw['fc1_b'])                     # MLP fc1 (pre-GELU)
-            xout = ops.linear_scale_res_fwd(hd, bw['fc2_w'], bw['fc2_b'], bw['g2'], xmid, gelu_in=True)  # :269
+            # MLP fc1 + exact GELU; GELU' is saved too so backward never re-evaluates erf (maxvit.py:100-112)
+            hg, hgp = ops.linear_gelu_fwd(v2, bw['fc1_w'], bw['fc1_b'], want_grad=save)
+            xout = ops.linear_scale_res_fwd(hg, bw['fc2_w'], bw['fc2_b'], bw['g2'], xmid)                # :269
             if save:
-                sv.blocks.append(dict(xin=x, qkv=qkv, a=a, xmid=xmid, hd=hd))
+                sv.blocks.append(dict(xin=x, qkv=qkv, a=a, xmid=xmid, hg=hg, hgp=hgp))
             x = xout
 
     Hall = torch.empty((T + 1, B, H, W, C), dtype=dt, device=dev)
@@ -188,11 +189,11 @@ def stage_seq_backward(sw: StageWeights, g: StageGeom, sv: StageSaved, dH: Optio
             # MLP branch: xout = xmid + g2 * (gelu(hd) W2^T + b2)
             S2 = zeros(C, 4 * C)
             cs = zeros(C)
-            ops.linear_wgrad(dx, s['hd'], S2, gelu_in=True, colsum_out=cs)
+            ops.linear_wgrad(dx, s['hg'], S2, colsum_out=cs)
             grads[bp + 'mlp.net.2.weight'] = bw['g2'][:, None] * S2
             grads[bp + 'mlp.net.2.bias'] = bw['g2'] * cs
             grads[bp + 'ls2.gamma'] = (bw['fc2_w32'] * S2).sum(1) + p[bp + 'mlp.net.2.bias'].detach().to(f32) * cs
-            dhd = ops.linear_dgrad(dx, bw['fc2_wt'], gelu_pre=s['hd'])
+            dhd = ops.linear_dgrad(dx, bw['fc2_wt'], mul=s['hgp'])
             v2 = ops.layernorm_fwd(s['xmid'], bw['n2_w'], bw['n2_b'], g.eps)
             dW1 = zeros(4 * C, C)
             db1 = zeros(4 * C)

@@ -59,6 +59,23 @@ def test_linear_fwd(backend, dt, M, N, K, gelu):
 
 
 @pytest.mark.parametrize('dt', DTYPES)
+def test_linear_gelu_and_mul(backend, dt):
+    M, N, K = 150, 136, 40
+    x, w, b = rnd((M, K), backend, dt, 1), rnd((N, K), backend, dt, 2, 0.4), rnd((N,), backend, torch.float32, 3)
+    g, gp = ops.linear_gelu_fwd(x, w, b, want_grad=True)
+    pre = (f64(x) @ f64(w).t() + f64(b)).requires_grad_(True)
+    gr = F.gelu(pre)
+    gr.sum().backward()
+    close(g, gr, dt, 'linear_gelu_fwd g')
+    close(gp, pre.grad, dt, 'linear_gelu_fwd gp')
+    g2, none = ops.linear_gelu_fwd(x, w, b, want_grad=False)
+    assert none is None and torch.equal(g2.cpu(), g.cpu())
+    dy, wt = rnd((M, 72), backend, dt, 4), rnd((N, 72), backend, dt, 5, 0.2)
+    dx = ops.linear_dgrad(dy, wt, mul=gp)
+    close(dx, (f64(dy) @ f64(wt).t()) * f64(gp), dt, 'linear_dgrad mul')
+
+
+@pytest.mark.parametrize('dt', DTYPES)
 def test_linear_scale_res(backend, dt):
     M, N, K = 150, 48, 192
     x, w, res = rnd((M, K), backend, dt, 1), rnd((N, K), backend, dt, 2, 0.2), rnd((M, N), backend, dt, 5)
