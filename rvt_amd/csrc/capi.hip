@@ -110,7 +110,7 @@ int rvt_prepack_input(const void* src, int src_u8, void* dst, int dtype, int F, 
                       int Cp, void* stream) {
     RVT_CHECK(Cp % 8 == 0 && Cp >= Cin && H >= h && W >= w, "prepack: bad shape Cp=%d Cin=%d", Cp, Cin);
     hipStream_t st = (hipStream_t)stream;
-    int grid = grid_for((size_t)F * H * W, 8192);
+    int grid = grid_for((size_t)F * H * W * (Cp / 8), 8192);
     DISPATCH_DTYPE(dtype, {
         if (src_u8)
             hipLaunchKernelGGL((prepack_kernel<T, unsigned char>), dim3(grid), dim3(256), 0, st,
@@ -210,7 +210,7 @@ int rvt_layernorm_bwd(const void* x, const float* w, const void* dy, const void*
     hipStream_t st = (hipStream_t)stream;
     int G = pow2_ge(C / 8);
     int rows_per_block = 4 * (64 / G);
-    int grid = imin(512, imax(1, (rows + rows_per_block - 1) / rows_per_block));
+    int grid = imin(1024, imax(1, (rows + rows_per_block - 1) / rows_per_block));
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ln_bwd_kernel<T>), dim3(grid), dim3(256), 0, st, (const T*)x, w,
                                              (const T*)dy, (const T*)dres, (T*)dx, dw, db, rows, C, G, eps));
     return check_launch("layernorm_bwd");

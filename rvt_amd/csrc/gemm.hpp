@@ -35,6 +35,8 @@ template <class T> struct PlainSrc {
     __device__ __forceinline__ void split(int kcol, int& seg, int& off) const { seg = 0; off = kcol; }
     __device__ __forceinline__ const T* seg_ptr(const Ctx& c, int) const { return c; }
     __device__ __forceinline__ const T* safe() const { return p; }
+    // context of row m+1 given the (valid) context of row m
+    __device__ __forceinline__ Ctx advance(const Ctx& c) const { return c + ld; }
 };
 
 template <class T> struct ConcatSrc {   // [x | h], both [rows][C]
@@ -47,6 +49,7 @@ template <class T> struct ConcatSrc {   // [x | h], both [rows][C]
         return c < 0 ? nullptr : q;
     }
     __device__ __forceinline__ const T* safe() const { return x; }
+    __device__ __forceinline__ Ctx advance(const Ctx& c) const { return c + 1; }
 };
 
 // rows = output pixels (frame, oy, ox); columns = (ky, kx, cin) with cin fastest; input is [F][H][W][Cin]
@@ -75,6 +78,18 @@ template <class T> struct Im2colSrc {
         return ok ? q : nullptr;
     }
     __device__ __forceinline__ const T* safe() const { return p; }
+    // next output pixel in raster order: x+1, wrapping to the next row / frame (no divisions)
+    __device__ __forceinline__ Ctx advance(const Ctx& c) const {
+        Ctx n = c;
+        n.ix0 += stride;
+        const bool wrap_x = n.ix0 >= Wo * stride - pad;
+        n.ix0 = wrap_x ? -pad : n.ix0;
+        n.iy0 += wrap_x ? stride : 0;
+        const bool wrap_y = n.iy0 >= Ho * stride - pad;
+        n.iy0 = wrap_y ? -pad : n.iy0;
+        n.base += wrap_y ? H * W : 0;
+        return n;
+    }
 };
 
 // Input-gradient gather of a strided conv for ONE parity class (py,px) of input pixels
@@ -108,6 +123,17 @@ template <class T> struct DgradSrc {
         return ok ? q : nullptr;
     }
     __device__ __forceinline__ const T* safe() const { return dy; }
+    __device__ __forceinline__ Ctx advance(const Ctx& c) const {
+        Ctx n = c;
+        n.x += s;
+        const bool wrap_x = n.x >= Wc * s + px;                          // x = s*xx+px with xx < Wc
+        n.x = wrap_x ? px : n.x;
+        n.y += wrap_x ? s : 0;
+        const bool wrap_y = n.y >= Hc * s + py;
+        n.y = wrap_y ? py : n.y;
+        n.f += wrap_y ? 1 : 0;
+        return n;
+    }
 };
 
 // element-wise transforms applied to loaded operand values
@@ -226,14 +252,17 @@ template <class T, int ROWS, class Src, class Xf, bool HIGH> struct TNLoader {
         if (u < 0) return;
         const int tok0 = k0 + (u / FC) * 8;
         vmask = 0;
+        // tokens tok0..tok0+7 are consecutive source rows: decode the first, step the rest (validity is by index,
+        // so stepping past the last real row is harmless: those loads go to the clamped address)
+        typename Src::Ctx c = s.row_ctx(tok0 < kend ? tok0 : 0);
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const int tok = tok0 + j;
-            typename Src::Ctx c = s.row_ctx(tok < kend ? tok : -1);
             const T* p = s.seg_ptr(c, seg);
             const bool ok = fvalid & (tok < kend) & (p != nullptr);
             r[j] = frag_load<T>(ok ? p + off : s.safe());     // branch-free; raw rows, post-processing in store()
             vmask |= ok ? (1u << j) : 0u;
+            c = s.advance(c);
         }
     }
     // Fold the FPR token-chunk threads that own the same 8 features through LDS and store the block's sums to

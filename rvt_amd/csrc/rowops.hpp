@@ -164,22 +164,24 @@ colsum_kernel(const T* __restrict__ x, float* __restrict__ out, int rows, int N,
 template <class T, class S>
 __global__ void __launch_bounds__(256)
 prepack_kernel(const S* __restrict__ src, T* __restrict__ dst, int F, int Cin, int h, int w, int H, int W, int Cp) {
-    const size_t total = (size_t)F * H * W;
-    for (size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x; pix < total; pix += (size_t)gridDim.x * 256) {
+    // one thread = one 8-channel chunk of one pixel; consecutive lanes = consecutive 16-byte chunks of dst, so every
+    // store instruction writes whole cache lines (a thread-per-pixel layout writes 16 B out of every 48 B per store)
+    const int cpp = Cp / 8;
+    const size_t total = (size_t)F * H * W * cpp;
+    for (size_t u = (size_t)blockIdx.x * 256 + threadIdx.x; u < total; u += (size_t)gridDim.x * 256) {
+        const int c0 = (int)(u % cpp) * 8;
+        const size_t pix = u / cpp;
         const int x = (int)(pix % W);
         const int y = (int)((pix / W) % H);
         const int f = (int)(pix / ((size_t)W * H));
         const bool in = (y < h) && (x < w);
-        T* o = dst + pix * Cp;
-        for (int c0 = 0; c0 < Cp; c0 += 8) {
-            float v[8];
+        float v[8];
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                int c = c0 + i;
-                v[i] = (in && c < Cin) ? (float)src[(((size_t)f * Cin + c) * h + y) * w + x] : 0.f;
-            }
-            frag_store<T>(o + c0, frag_from_float<T>(v));
+        for (int i = 0; i < 8; i++) {
+            const int c = c0 + i;
+            v[i] = (in && c < Cin) ? (float)src[(((size_t)f * Cin + c) * h + y) * w + x] : 0.f;
         }
+        frag_store<T>(dst + pix * Cp + c0, frag_from_float<T>(v));
     }
 }
 
