@@ -481,13 +481,15 @@ template <class T> struct EpLstm {
 // ------------------------------------------------------------------------------------------------
 // the kernel
 // ------------------------------------------------------------------------------------------------
-template <int BN> struct GemmSmem {
-    static constexpr int MAIN = 2 * (128 + BN) * 128;
-    static constexpr int EPI = 128 * (BN + 4) * 4;
+// LDS: operand stages (one when the whole K fits a single K tile, else two) overlaid with the fp32 epilogue staging of
+// 64 rows at a time.  128x128 tile: 64 KiB double-buffered, 33.8 KiB when ONE_K (=> 3-4 workgroups per CU).
+template <int BN, bool ONE_K> struct GemmSmem {
+    static constexpr int MAIN = (ONE_K ? 1 : 2) * (128 + BN) * 128;
+    static constexpr int EPI = 64 * (BN + 4) * 4;
     static constexpr int BYTES = MAIN > EPI ? MAIN : EPI;
 };
 
-template <class T, int BN, bool TN, class ASrc, class AXf, class BSrc, class BXf, class Ep>
+template <class T, int BN, bool TN, bool ONE_K, class ASrc, class AXf, class BSrc, class BXf, class Ep>
 __global__ void __launch_bounds__(256)
 gemm_kernel(ASrc as, AXf axf, BSrc bs, BXf bxf, Ep ep, int M, int N, int K, int m_tiles, int n_tiles, int ksplit_len,
             float* a_colsum, int panel_major) {
@@ -495,7 +497,7 @@ gemm_kernel(ASrc as, AXf axf, BSrc bs, BXf bxf, Ep ep, int M, int N, int K, int 
     constexpr int BK = TileGeom<T>::BK;
     constexpr int WN = BN / 64;
     constexpr int STAGE_BYTES = (BM + BN) * 128;   // A tile then B tile, two stages
-    __shared__ __attribute__((aligned(16))) char smem[GemmSmem<BN>::BYTES];
+    __shared__ __attribute__((aligned(16))) char smem[GemmSmem<BN, ONE_K>::BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -584,30 +586,33 @@ gemm_kernel(ASrc as, AXf axf, BSrc bs, BXf bxf, Ep ep, int M, int N, int K, int 
         }
         sched_fence();      // the prefetch must be ISSUED here, not sunk below the epilogue
 
-        // ---- epilogue: accumulators -> LDS (fp32, row pitch BN+4) -> UNIT-wide row segments ----
+        // ---- epilogue: accumulators -> LDS (fp32, row pitch BN+4) -> UNIT-wide row segments, 64 tile rows per pass
+        // (pass i = MFMA row block i of every wave: stage row wm*32+r <-> tile row wm*64+i*32+r) ----
         float* stage = reinterpret_cast<float*>(smem);
         constexpr int LDS_LD = BN + 4;
+        constexpr int UNIT = Ep::UNIT;
+        constexpr int UPR = BN / UNIT;
 #pragma unroll
-        for (int i = 0; i < 2; i++)
+        for (int i = 0; i < 2; i++) {
+            if (i) __syncthreads();
 #pragma unroll
             for (int j = 0; j < WN; j++)
 #pragma unroll
                 for (int r = 0; r < 16; r++)
-                    stage[(wm * 64 + i * 32 + acc_row(r, lane)) * LDS_LD + wn * (BN / 2) + j * 32 + (lane & 31)] = acc[i][j][r];
-        __syncthreads();
-        constexpr int UNIT = Ep::UNIT;
-        constexpr int UPR = BN / UNIT;
-        for (int u = tid; u < BM * UPR; u += 256) {
-            const int row = u / UPR, cu = u % UPR;
-            const int m = m0 + row, n = n0 + cu * UNIT;
-            if (m < M && n < N) {
-                float v[UNIT];
+                    stage[(wm * 32 + acc_row(r, lane)) * LDS_LD + wn * (BN / 2) + j * 32 + (lane & 31)] = acc[i][j][r];
+            __syncthreads();
+            for (int u = tid; u < 64 * UPR; u += 256) {
+                const int srow = u / UPR, cu = u % UPR;
+                const int m = m0 + (srow >> 5) * 64 + i * 32 + (srow & 31), n = n0 + cu * UNIT;
+                if (m < M && n < N) {
+                    float v[UNIT];
 #pragma unroll
-                for (int q = 0; q < UNIT / 4; q++) {
-                    f32x4 t = *reinterpret_cast<const f32x4*>(stage + row * LDS_LD + cu * UNIT + q * 4);
-                    v[q * 4 + 0] = t[0]; v[q * 4 + 1] = t[1]; v[q * 4 + 2] = t[2]; v[q * 4 + 3] = t[3];
+                    for (int q = 0; q < UNIT / 4; q++) {
+                        f32x4 t = *reinterpret_cast<const f32x4*>(stage + srow * LDS_LD + cu * UNIT + q * 4);
+                        v[q * 4 + 0] = t[0]; v[q * 4 + 1] = t[1]; v[q * 4 + 2] = t[2]; v[q * 4 + 3] = t[3];
+                    }
+                    ep(m, n, v);
                 }
-                ep(m, n, v);
             }
         }
         __syncthreads();            // staging buffer is reused by the next tile's operand stores
@@ -637,12 +642,18 @@ inline void launch_gemm(const ASrc& as, const AXf& axf, const BSrc& bs, const BX
     int gx = total, panel_major = 0;
     if (!TN) {                                   // persistent: ~one resident wave of workgroups striding over the tiles
         static const int resident_override = getenv("RVT_GEMM_RESIDENT") ? atoi(getenv("RVT_GEMM_RESIDENT")) : 0;
-        const int resident = resident_override > 0 ? resident_override : 256 * (BN == 64 ? 3 : 2);
+        // workgroups per CU: LDS-bound (2 x 64 KiB) when double buffered; register-bound (~3) when K fits one tile
+        const int per_cu = (K <= BK) ? 3 : (BN == 64 ? 3 : 2);
+        const int resident = resident_override > 0 ? resident_override : 256 * per_cu;
         if (total > resident) gx = resident;
         panel_major = (n_tiles > 1 && m_tiles >= 4 * gx) ? 1 : 0;
     }
-    hipLaunchKernelGGL((gemm_kernel<T, BN, TN, ASrc, AXf, BSrc, BXf, Ep>), dim3(gx, nsplit), dim3(256), 0, stream, as, axf,
-                       bs, bxf, ep, M, N, K, m_tiles, n_tiles, klen, a_colsum, panel_major);
+    if (!TN && K <= BK)       // whole contraction in one K tile: single operand stage, more workgroups per CU
+        hipLaunchKernelGGL((gemm_kernel<T, BN, TN, true, ASrc, AXf, BSrc, BXf, Ep>), dim3(gx, nsplit), dim3(256), 0, stream,
+                           as, axf, bs, bxf, ep, M, N, K, m_tiles, n_tiles, klen, a_colsum, panel_major);
+    else
+        hipLaunchKernelGGL((gemm_kernel<T, BN, TN, false, ASrc, AXf, BSrc, BXf, Ep>), dim3(gx, nsplit), dim3(256), 0, stream,
+                           as, axf, bs, bxf, ep, M, N, K, m_tiles, n_tiles, klen, a_colsum, panel_major);
 }
 
 }  // namespace rvt
