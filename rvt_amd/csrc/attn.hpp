@@ -42,8 +42,19 @@ __device__ __forceinline__ int attn_token(const AttnGeom& g, int f, int p, int l
 }
 
 template <class T> __device__ __forceinline__ frag_t<T> load_chunk(const T* row, int chunk, int dh, bool valid) {
-    if (valid && chunk * 8 < dh) return frag_load<T>(row + chunk * 8);
-    return frag_zero<T>();
+    // branch-free: padded rows point at token 0 (always mapped); the select zeroes what is not real
+    const bool ok = valid & (chunk * 8 < dh);
+    const frag_t<T> v = frag_load<T>(row + (ok ? chunk * 8 : 0));
+    const frag_t<T> z = frag_zero<T>();
+    return ok ? v : z;
+}
+
+// store 4 consecutive channels of one token row as ONE 8-byte (bf16) / 16-byte (f32) write
+template <class T> __device__ __forceinline__ void store4(T* dst, float a, float b, float c, float d) {
+    typedef __attribute__((ext_vector_type(4))) T vec4;
+    vec4 v;
+    v[0] = (T)a; v[1] = (T)b; v[2] = (T)c; v[3] = (T)d;
+    *reinterpret_cast<vec4*>(dst) = v;
 }
 
 // write an 8-element chunk transposed: dst[(chunk*8+e)*pitch + col] = v[e]
@@ -157,10 +168,7 @@ attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, AttnGeom g) {
 #pragma unroll
             for (int gq = 0; gq < 4; gq++) {
                 int d0 = 8 * gq + 4 * half;
-                if (d0 < dh) {
-#pragma unroll
-                    for (int e = 0; e < 4; e++) orow[d0 + e] = (T)o[4 * gq + e];
-                }
+                if (d0 < dh) store4<T>(orow + d0, o[4 * gq], o[4 * gq + 1], o[4 * gq + 2], o[4 * gq + 3]);
             }
         }
     }
@@ -276,29 +284,32 @@ attn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ dout, T* __rest
 #pragma unroll
             for (int gq = 0; gq < 4; gq++) {
                 int d0 = 8 * gq + 4 * half;
-                if (d0 < dh) {
-#pragma unroll
-                    for (int e = 0; e < 4; e++) qrow[d0 + e] = (T)dq[4 * gq + e];
-                }
+                if (d0 < dh) store4<T>(qrow + d0, dq[4 * gq], dq[4 * gq + 1], dq[4 * gq + 2], dq[4 * gq + 3]);
             }
         }
         __syncthreads();   // PS is rewritten by the next query block
     }
-    // dK, dV: rows = keys, col = d = lane&31
-    // lanes of one half-wave write 32 consecutive channels of one token row
+    // dK, dV: accumulator rows = keys, col = d = lane&31.  Stage each through LDS (the P^T buffer, [key][40]) so that the
+    // global writes are 16-byte row segments instead of 2-byte scalars.
+    constexpr int CPR = 32 / 8;                       // 8-channel chunks per key row (dh <= 32)
 #pragma unroll
-    for (int bj = 0; bj < NB; bj++)
+    for (int which = 0; which < 2; which++) {
+        __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            int j = 32 * bj + acc_row(r, lane);
-            // token of key j: recompute (tok[] is indexed by this lane's own li)
-            if (j < g.L && li < dh) {
-                int t = attn_token(g, (int)f, (int)p, j);
-                T* row = dqkv + (size_t)t * C3;
-                row[koff + li] = (T)dk[bj][r];
-                row[voff + li] = (T)dv[bj][r];
+        for (int bj = 0; bj < NB; bj++)
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                PS[(32 * bj + acc_row(r, lane)) * PSP + li] = (T)(which == 0 ? dk[bj][r] : dv[bj][r]);
+        __syncthreads();
+        const int off = which == 0 ? koff : voff;
+        for (int u = lane; u < LP * CPR; u += 64) {
+            const int j = u / CPR, c = u % CPR;
+            if (j < g.L && c * 8 < dh) {
+                const int t = attn_token(g, (int)f, (int)p, j);
+                frag_store<T>(dqkv + (size_t)t * C3 + off + c * 8, frag_load<T>(PS + j * PSP + c * 8));
             }
         }
+    }
 }
 
 }  // namespace rvt

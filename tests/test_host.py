@@ -132,3 +132,55 @@ def test_stage_grad_reducer_world2_gloo(tmp_path):
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count('OK') == 2
+
+
+DDP_BACKBONE_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+root = sys.argv[1]
+sys.path.insert(0, root)
+os.environ.setdefault('RVT_GEMM_RESIDENT', '3')
+from rvt_amd import _lib
+from rvt_amd.dist import StageGradReducer
+from tests.backends import emu_library
+from tests.test_backbone import build_model
+from tests import casegen
+_lib._install_test_library(emu_library())          # CPU SIMT-emulator build of the HIP kernels (tests only)
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+dist.init_process_group('gloo')
+torch.set_num_threads(2)
+name = 'micro'
+def run(model, seed, reducer):
+    xs = torch.from_numpy(casegen.make_inputs(name, seed=seed))
+    cots = [torch.from_numpy(a) for a in casegen.make_cotangents(name, seed=seed + 10)]
+    feats, _ = model.forward_sequence(xs, None)
+    model.zero_grad()
+    torch.autograd.backward([feats[s + 1] for s in range(4)], cots)
+    if reducer is not None:
+        reducer.finish()
+    return {k: p.grad.clone() for k, p in model.named_parameters()}
+m = build_model(name, torch.device('cpu'), torch.float32)
+red = StageGradReducer().attach(m)
+mine = run(m, 100 + rank, red)                      # each rank: its own shard of sequences
+m._stage_grad_hook = None
+ref = [run(m, 100 + r, None) for r in range(world)]  # what every rank should end up with: the mean over shards
+for k in mine:
+    want = sum(g[k] for g in ref) / world
+    err = (mine[k] - want).abs().max().item() / max(want.abs().max().item(), 1e-12)
+    assert err < 1e-5, (k, err)
+dist.destroy_process_group()
+print('OK', rank)
+'''
+
+
+def test_backbone_data_parallel_world2_gloo(tmp_path):
+    """Two processes, gloo, the real backward (HIP kernel sources on the CPU emulator): per-stage bucketed
+    all-reduce launched from inside the stage-major backward must leave the mean gradient on every rank."""
+    from tests.backends import emu_library
+    emu_library()                                   # build once here, not concurrently in both workers
+    script = tmp_path / 'ddp.py'
+    script.write_text(DDP_BACKBONE_WORKER)
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+                        '--master-addr', '127.0.0.1', '--master-port', '29733', str(script), ROOT],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count('OK') == 2
