@@ -81,6 +81,13 @@ int rvt_linear_wgrad(const void* dy, const void* x, float* dw, float* dy_colsum,
 /* out[N] (float32) += column sums of x[rows][N]. */
 int rvt_colsum(const void* x, float* out, int dtype, int rows, int N, void* stream);
 
+/* Fused MLP half of a block (maxvit.py:269 + :100-118):  xout = xmid + gamma * (GELU(LN(xmid) W1^T + b1) W2^T + b2)
+ * in one pass; hidden activations never reach HBM.  w1 [4C][C], w2 [C][4C] (dtype), ln/bias/gamma float32.
+ * Built for the HBM-bound stages: rvt_mlp_fused_supported(dtype, C) != 0  (bf16: C in {64,128}; f32: C == 64). */
+int rvt_mlp_fused_supported(int dtype, int C);
+int rvt_mlp_fwd(const void* xmid, void* xout, const float* ln_w, const float* ln_b, const void* w1, const float* b1,
+                const void* w2, const float* b2, const float* gamma, int dtype, int M, int C, float eps, void* stream);
+
 /* Partitioned multi-head attention core (maxvit.py:252-265,273-304,343-354 minus the two linears):
  * qkv [F*H*W][3C] in image token order, per-head layout [q|k|v]; out [F*H*W][C].  window=1: ph x pw
  * windows; window=0: dilated grid with grid size (ph,pw). */

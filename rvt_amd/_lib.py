@@ -35,6 +35,7 @@ _SIGS = {
     'rvt_linear_gelu_fwd': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     'rvt_linear_wgrad': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     'rvt_colsum': [_vp, _vp, _i, _i, _i, _vp],
+    'rvt_mlp_fwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
     'rvt_attn_fwd': [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     'rvt_attn_bwd': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     'rvt_lstm_fwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
@@ -45,7 +46,8 @@ _SIGS = {
     'rvt_dwconv_wgrad': [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     'rvt_state_reset_masked': [_vp, _vp, _i, _i, _sz, _vp],
 }
-EXPORTS = sorted(list(_SIGS) + ['rvt_last_error', 'rvt_is_emulator', 'rvt_wgrad_workspace_floats'])
+EXPORTS = sorted(list(_SIGS) + ['rvt_last_error', 'rvt_is_emulator', 'rvt_wgrad_workspace_floats',
+                               'rvt_mlp_fused_supported'])
 
 
 def _bind(lib: ctypes.CDLL) -> ctypes.CDLL:
@@ -57,6 +59,8 @@ def _bind(lib: ctypes.CDLL) -> ctypes.CDLL:
     lib.rvt_last_error.argtypes = []
     lib.rvt_is_emulator.restype = ctypes.c_int
     lib.rvt_is_emulator.argtypes = []
+    lib.rvt_mlp_fused_supported.restype = ctypes.c_int
+    lib.rvt_mlp_fused_supported.argtypes = [_i, _i]
     lib.rvt_wgrad_workspace_floats.restype = ctypes.c_size_t
     lib.rvt_wgrad_workspace_floats.argtypes = [_i, _i, _i, _i, _i]
     return lib

@@ -9,6 +9,7 @@
 #include "gemm.hpp"
 #include "rowops.hpp"
 #include "attn.hpp"
+#include "mlp.hpp"
 #include "../../include/rvt_hip.h"
 
 namespace rvt {
@@ -314,6 +315,31 @@ int rvt_linear_wgrad(const void* dy, const void* x, float* dw, float* dy_colsum,
         });
     });
     return check_launch("linear_wgrad");
+}
+
+// ------------------------------------------------------------------------------------------ fused MLP
+int rvt_mlp_fused_supported(int dtype, int C) {
+    if (dtype == RVT_BF16) return C == 64 || C == 128;
+    if (dtype == RVT_F32) return C == 64;
+    return 0;
+}
+
+int rvt_mlp_fwd(const void* xmid, void* xout, const float* ln_w, const float* ln_b, const void* w1, const float* b1,
+                const void* w2, const float* b2, const float* gamma, int dtype, int M, int C, float eps, void* stream) {
+    RVT_CHECK(rvt_mlp_fused_supported(dtype, C), "mlp_fwd: fused MLP not built for dtype=%d C=%d", dtype, C);
+    hipStream_t st = (hipStream_t)stream;
+    static const int resident_override = getenv("RVT_GEMM_RESIDENT") ? atoi(getenv("RVT_GEMM_RESIDENT")) : 0;
+    const int n_tiles = (M + 127) / 128;
+    const int per_cu = (dtype == RVT_BF16 && C == 64) ? 2 : 1;
+    const int grid = imax(1, imin(n_tiles, resident_override > 0 ? resident_override : 256 * per_cu));
+#define RVT_MLP_FWD(TT, CC)                                                                                          \
+    hipLaunchKernelGGL((mlp_fwd_kernel<TT, CC>), dim3(grid), dim3(256), 0, st, (const TT*)xmid, (TT*)xout, ln_w, ln_b, \
+                       (const TT*)w1, b1, (const TT*)w2, b2, gamma, M, eps)
+    if (dtype == RVT_BF16 && C == 64) RVT_MLP_FWD(bf16, 64);
+    else if (dtype == RVT_BF16 && C == 128) RVT_MLP_FWD(bf16, 128);
+    else RVT_MLP_FWD(float, 64);
+#undef RVT_MLP_FWD
+    return check_launch("mlp_fwd");
 }
 
 // ----------------------------------------------------------------------------------------- attention

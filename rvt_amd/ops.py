@@ -131,6 +131,21 @@ def linear_gelu_fwd(x: Tensor, w: Tensor, bias: Tensor, want_grad: bool):
     return g, gp
 
 
+def mlp_fused_supported(dtype: torch.dtype, C: int) -> bool:
+    return bool(L.get_lib().rvt_mlp_fused_supported(L.dtype_code(dtype), C))
+
+
+def mlp_fwd(xmid: Tensor, ln_w: Tensor, ln_b: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, gamma: Tensor,
+            eps: float, out: Optional[Tensor] = None) -> Tensor:
+    """xout = xmid + gamma*(GELU(LN(xmid) W1^T + b1) W2^T + b2), one fused kernel (hidden never hits HBM)."""
+    C = xmid.shape[-1]
+    M = xmid.numel() // C
+    y = _out(xmid, xmid.shape, out=out)
+    L.call('rvt_mlp_fwd', L.ptr(xmid), L.ptr(y), L.ptr(ln_w), L.ptr(ln_b), L.ptr(w1), L.ptr(b1), L.ptr(w2), L.ptr(b2),
+           L.ptr(gamma), L.dtype_code(xmid.dtype), M, C, float(eps), L.stream_of(xmid))
+    return y
+
+
 def linear_dgrad(dy: Tensor, wt: Tensor, gelu_pre: Optional[Tensor] = None, add: Optional[Tensor] = None,
                  mul: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
     """dx = dy @ wt.T with wt = W^T stored [K][N] (optionally folded with LayerScale), then * gelu'(gelu_pre),

@@ -75,6 +75,31 @@ def test_linear_gelu_and_mul(backend, dt):
     close(dx, (f64(dy) @ f64(wt).t()) * f64(gp), dt, 'linear_dgrad mul')
 
 
+@pytest.mark.parametrize('dt,C', [(torch.float32, 64), (torch.bfloat16, 64), (torch.bfloat16, 128)])
+@pytest.mark.parametrize('M', [300, 1000])
+def test_mlp_fused_fwd(backend, dt, C, M):
+    assert ops.mlp_fused_supported(dt, C)
+    x = rnd((M, C), backend, dt, 1, 1.5)
+    lw, lb = rnd((C,), backend, torch.float32, 2) * 0.3 + 1.0, rnd((C,), backend, torch.float32, 3, 0.2)
+    w1, b1 = rnd((4 * C, C), backend, dt, 4, 0.2), rnd((4 * C,), backend, torch.float32, 5, 0.2)
+    w2, b2 = rnd((C, 4 * C), backend, dt, 6, 0.1), rnd((C,), backend, torch.float32, 7, 0.2)
+    gam = rnd((C,), backend, torch.float32, 8)
+    y = ops.mlp_fwd(x, lw, lb, w1, b1, w2, b2, gam, 1e-5)
+    v2 = F.layer_norm(f64(x), (C,), f64(lw), f64(lb), 1e-5)
+    if dt == torch.bfloat16:
+        v2 = v2.to(dt).double()
+    h = F.gelu(v2 @ f64(w1).t() + f64(b1))
+    if dt == torch.bfloat16:
+        h = h.to(dt).double()
+    want = f64(x) + f64(gam) * (h @ f64(w2).t() + f64(b2))
+    close(y, want, dt, 'mlp_fwd fused')
+    # and against the op-by-op HIP chain it replaces
+    v2h = ops.layernorm_fwd(x, lw, lb, 1e-5)
+    g, _ = ops.linear_gelu_fwd(v2h, w1, b1, want_grad=False)
+    y2 = ops.linear_scale_res_fwd(g, w2, b2, gam, x)
+    close(y, y2.double(), dt, 'mlp_fwd fused vs chain')
+
+
 @pytest.mark.parametrize('dt', DTYPES)
 def test_linear_scale_res(backend, dt):
     M, N, K = 150, 48, 192
