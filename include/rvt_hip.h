@@ -120,6 +120,11 @@ int rvt_dwconv_fwd(const void* x, int ldx, const float* w, const float* b, void*
 int rvt_dwconv_wgrad(const void* x, int ldx, const void* dy, int ldy, float* dw, float* db, int dtype, int N, int H,
                      int W, int C, int k, void* stream);
 
+/* Token masking of stage 1 (maxvit_rnn.py:174-176): rows of x[M][C] with mask[m] != 0 are overwritten by the float32
+ * mask token;  backward: dtoken[C] += sum of dx over masked rows, and those rows of dx are zeroed in place. */
+int rvt_token_mask_fwd(void* x, const unsigned char* mask, const float* token, int dtype, int M, int C, void* stream);
+int rvt_token_mask_bwd(void* dx, const unsigned char* mask, float* dtoken, int dtype, int M, int C, void* stream);
+
 /* Zero state rows of samples with mask[b] != 0 (modules/utils/detection.py:96-113).
  * st is [B][per_sample] of float32 (is_f32) or `dtype`. */
 int rvt_state_reset_masked(void* st, const unsigned char* mask, int dtype, int B, size_t per_sample, void* stream);

@@ -44,6 +44,8 @@ _SIGS = {
     'rvt_lstm_wgrad': [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     'rvt_dwconv_fwd': [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     'rvt_dwconv_wgrad': [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    'rvt_token_mask_fwd': [_vp, _vp, _vp, _i, _i, _i, _vp],
+    'rvt_token_mask_bwd': [_vp, _vp, _vp, _i, _i, _i, _vp],
     'rvt_state_reset_masked': [_vp, _vp, _i, _i, _sz, _vp],
 }
 EXPORTS = sorted(list(_SIGS) + ['rvt_last_error', 'rvt_is_emulator', 'rvt_wgrad_workspace_floats',

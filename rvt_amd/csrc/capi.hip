@@ -468,6 +468,28 @@ int rvt_dwconv_wgrad(const void* x, int ldx, const void* dy, int ldy, float* dw,
     return check_launch("dwconv_wgrad");
 }
 
+// ---------------------------------------------------------------------------------------- token mask
+int rvt_token_mask_fwd(void* x, const unsigned char* mask, const float* token, int dtype, int M, int C, void* stream) {
+    RVT_CHECK(C % 8 == 0, "token_mask: C=%d must be a multiple of 8", C);
+    hipStream_t st = (hipStream_t)stream;
+    int grid = grid_for((size_t)M * (C / 8), 4096);
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((token_mask_fwd_kernel<T>), dim3(grid), dim3(256), 0, st, (T*)x, mask, token, M, C));
+    return check_launch("token_mask_fwd");
+}
+
+int rvt_token_mask_bwd(void* dx, const unsigned char* mask, float* dtoken, int dtype, int M, int C, void* stream) {
+    RVT_CHECK(C % 8 == 0, "token_mask: C=%d must be a multiple of 8", C);
+    hipStream_t st = (hipStream_t)stream;
+    int NC = C / 8;
+    int NCP = imin(256, pow2_ge(NC));
+    int gy = (NC + NCP - 1) / NCP;
+    int nrl = 256 / NCP;
+    int gx = imin(512, imax(1, (M + nrl * 8 - 1) / (nrl * 8)));
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((token_mask_bwd_kernel<T>), dim3(gx, gy), dim3(256), 0, st, (T*)dx, mask, dtoken,
+                                             M, C, NCP));
+    return check_launch("token_mask_bwd");
+}
+
 int rvt_state_reset_masked(void* st_, const unsigned char* mask, int dtype, int B, size_t per_sample, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     int grid = grid_for((size_t)B * per_sample, 4096);

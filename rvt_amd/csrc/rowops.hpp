@@ -359,3 +359,59 @@ dwconv_wgrad_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dy, 
 }
 
 }  // namespace rvt
+
+namespace rvt {
+
+// ---- token masking (reference maxvit_rnn.py:174-176: x[token_mask] = mask_token) -------------------------------
+// forward: rows flagged in mask[M] are overwritten with the (fp32) mask token.
+template <class T>
+__global__ void __launch_bounds__(256)
+token_mask_fwd_kernel(T* __restrict__ x, const unsigned char* __restrict__ mask, const float* __restrict__ token, int M, int C) {
+    const int cpr = C / 8;
+    const size_t total = (size_t)M * cpr;
+    for (size_t u = (size_t)blockIdx.x * 256 + threadIdx.x; u < total; u += (size_t)gridDim.x * 256) {
+        const size_t m = u / cpr;
+        if (!mask[m]) continue;
+        const int c0 = (int)(u % cpr) * 8;
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = token[c0 + i];
+        frag_store<T>(x + m * C + c0, frag_from_float<T>(v));
+    }
+}
+
+// backward: dtoken[c] += sum over masked rows of dx[m][c]; dx of masked rows is zeroed (the conv path gets no gradient there)
+template <class T>
+__global__ void __launch_bounds__(256)
+token_mask_bwd_kernel(T* __restrict__ dx, const unsigned char* __restrict__ mask, float* __restrict__ dtoken, int M, int C, int NCP) {
+    __shared__ float red[256 * 8];
+    const int tid = threadIdx.x;
+    const int c = tid % NCP + blockIdx.y * NCP;
+    const int rl = tid / NCP, nrl = 256 / NCP;
+    const bool cvalid = c * 8 < C;
+    float a[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) a[i] = 0.f;
+    if (cvalid) {
+        for (int row = blockIdx.x * nrl + rl; row < M; row += gridDim.x * nrl) {
+            if (!mask[row]) continue;
+            T* p = dx + (size_t)row * C + c * 8;
+            float v[8]; frag_to_float<T>(frag_load<T>(p), v);
+#pragma unroll
+            for (int i = 0; i < 8; i++) a[i] += v[i];
+            frag_store<T>(p, frag_zero<T>());
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) red[tid * 8 + i] = a[i];
+    __syncthreads();
+    if (rl == 0 && cvalid) {
+        for (int r = 1; r < nrl; r++)
+#pragma unroll
+            for (int i = 0; i < 8; i++) a[i] += red[(r * NCP + tid) * 8 + i];
+#pragma unroll
+        for (int i = 0; i < 8; i++) atomicAdd(dtoken + c * 8 + i, a[i]);
+    }
+}
+
+}  // namespace rvt

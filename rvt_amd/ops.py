@@ -244,6 +244,19 @@ def dwconv_wgrad(x: Tensor, dy: Tensor, dw: Tensor, db: Tensor, k: int) -> None:
            L.stream_of(x))
 
 
+def token_mask_fwd(x: Tensor, mask_u8: Tensor, token: Tensor) -> None:
+    """x[mask] = token in place (maxvit_rnn.py:174-176); x (…,C), mask_u8 uint8 over the leading dims, token fp32 [C]."""
+    C = x.shape[-1]
+    L.call('rvt_token_mask_fwd', L.ptr(x), L.ptr(mask_u8), L.ptr(token), L.dtype_code(x.dtype), x.numel() // C, C,
+           L.stream_of(x))
+
+
+def token_mask_bwd(dx: Tensor, mask_u8: Tensor, dtoken: Tensor) -> None:
+    C = dx.shape[-1]
+    L.call('rvt_token_mask_bwd', L.ptr(dx), L.ptr(mask_u8), L.ptr(dtoken), L.dtype_code(dx.dtype), dx.numel() // C, C,
+           L.stream_of(dx))
+
+
 def state_reset_masked(st: Tensor, mask: Tensor) -> None:
     """Zero rows st[b] where mask[b] (modules/utils/detection.py:96-113); st is (B, ...)."""
     B = st.shape[0]

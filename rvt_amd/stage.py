@@ -67,10 +67,12 @@ def stage_seq_forward(sw: StageWeights, g: StageGeom, inp: Tensor, h0: Optional[
 
     y0 = ops.conv_fwd(inp, sw.conv_w, g.k, g.stride, g.pad)                      # maxvit.py:175
     x = ops.layernorm_fwd(y0, sw.ln_w, sw.ln_b, g.eps)                            # maxvit.py:177
+    mask_u8 = None
     if token_mask is not None:                                                    # maxvit_rnn.py:174-176
-        x = torch.where(token_mask.reshape(F_, H, W, 1), mask_token.reshape(1, 1, 1, C).to(dt), x)
+        mask_u8 = token_mask.reshape(F_ * H * W).to(torch.uint8).contiguous()
+        ops.token_mask_fwd(x, mask_u8, mask_token.reshape(C).to(torch.float32).contiguous())
     if save:
-        sv.inp, sv.y0, sv.mask = inp, y0, token_mask
+        sv.inp, sv.y0, sv.mask = inp, y0, mask_u8
 
     for pair in sw.blocks:
         for bw, window in ((pair[0], True), (pair[1], False)):
@@ -236,9 +238,9 @@ def stage_seq_backward(sw: StageWeights, g: StageGeom, sv: StageSaved, dH: Optio
 
     # ---- token mask, down-sampling LayerNorm + conv ---------------------------------------------------------
     if sv.mask is not None:
-        m = sv.mask.reshape(F_, H, W, 1)
-        grads[pre + 'mask_token'] = (dx.to(f32) * m).sum((0, 1, 2)).reshape(1, 1, 1, C)
-        dx = torch.where(m, torch.zeros((), dtype=dt, device=dev), dx)
+        dtok = zeros(C)
+        ops.token_mask_bwd(dx, sv.mask, dtok)                                     # also zeroes dx on masked tokens
+        grads[pre + 'mask_token'] = dtok.reshape(1, 1, 1, C)
     dlw, dlb = zeros(C), zeros(C)
     dy0 = ops.layernorm_bwd(sv.y0, sw.ln_w, dx, None, dlw, dlb, g.eps)
     grads[pre + 'downsample_cf2cl.norm.weight'] = dlw
