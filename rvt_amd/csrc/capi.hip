@@ -38,8 +38,9 @@ static inline int grid_for(size_t units, int cap = 2048) {
 }
 // split the token contraction of a weight gradient so that the launch fills the chip
 static inline int wgrad_ksplit(int out_rows, int out_cols, int tokens, int bn) {
+    static const int split_override = getenv("RVT_WGRAD_BLOCKS") ? atoi(getenv("RVT_WGRAD_BLOCKS")) : 0;   // tuning knob
     int tiles = ((out_rows + 127) / 128) * ((out_cols + bn - 1) / bn);
-    int want = imax(1, (256 * (bn == 64 ? 3 : 2)) / imax(1, tiles));     // one resident wave of workgroups
+    int want = imax(1, (split_override > 0 ? split_override : 256 * (bn == 64 ? 3 : 2)) / imax(1, tiles));   // one resident wave
     int maxs = imax(1, tokens / 512);
     return imin(want, maxs);
 }
