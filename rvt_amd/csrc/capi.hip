@@ -40,7 +40,7 @@ static inline int grid_for(size_t units, int cap = 2048) {
 static inline int wgrad_ksplit(int out_rows, int out_cols, int tokens, int bn) {
     static const int split_override = getenv("RVT_WGRAD_BLOCKS") ? atoi(getenv("RVT_WGRAD_BLOCKS")) : 0;   // tuning knob
     int tiles = ((out_rows + 127) / 128) * ((out_cols + bn - 1) / bn);
-    int want = imax(1, (split_override > 0 ? split_override : 256 * (bn == 64 ? 3 : 2)) / imax(1, tiles));   // one resident wave
+    int want = imax(1, (split_override > 0 ? split_override : 256) / imax(1, tiles));   // ~one workgroup per CU (measured best)
     int maxs = imax(1, tokens / 512);
     return imin(want, maxs);
 }

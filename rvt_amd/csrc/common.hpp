@@ -110,8 +110,11 @@ struct FastDiv {
 // ds_read_b128 of one logical chunk from 32 different rows would hit two 16-B slots of the 256-B
 // bank row (8-way); XOR-ing the chunk index with (row>>1)&7 spreads each 16-lane read group over all
 // 16 slots (MI355X guide: LDS banks for b128 = (addr/4)%64, 16-lane groups).
+// The second term, (row>>4)&7, is for the TRANSPOSING loader: its lanes write rows 8*fc+f (stride 8), which the
+// first term alone maps onto only two 16-B slots (8-way conflict on ds_write_b128); with it a 16-lane write group
+// spreads over all eight slots (2-way).  MFMA fragment reads (32 consecutive rows) stay conflict-free.
 __device__ __forceinline__ int lds_chunk_off(int row, int chunk16) {
-    return row * 128 + ((chunk16 ^ ((row >> 1) & 7)) << 4);
+    return row * 128 + ((chunk16 ^ ((row >> 1) & 7) ^ ((row >> 4) & 7)) << 4);
 }
 template <class T> struct TileGeom;
 template <> struct TileGeom<bf16> { static constexpr int BK = 64, FPR = 8, CPF = 1; };   // frags/row, 16B-chunks/frag
