@@ -80,23 +80,29 @@ class OpTimer:
 
 
 def gemm_flops_of_call(name, args):
-    """Algorithmic FLOPs of one launch of a GEMM-family entry point, from its own arguments."""
-    if name in ('rvt_linear_fwd',):
-        M, N, K = args[5], args[6], args[7]
+    """Algorithmic FLOPs of one launch of a GEMM-family entry point, from its own (trailing) arguments:
+    every signature ends  ..., dtype, M, N, K[, gelu_in], stream  (LSTM: ..., dtype, M, C, stream)."""
+    if name in ('rvt_linear_fwd', 'rvt_linear_scale_res_fwd', 'rvt_linear_wgrad'):
+        M, N, K = args[-5], args[-4], args[-3]
         return linear_flops(M, N, K)
-    if name == 'rvt_linear_scale_res_fwd':
-        M, N, K = args[7], args[8], args[9]
-        return linear_flops(M, N, K)
-    if name == 'rvt_linear_dgrad':
-        M, N, K = args[6], args[7], args[8]
-        return linear_flops(M, N, K)
-    if name == 'rvt_linear_wgrad':
-        M, N, K = args[5], args[6], args[7]
+    if name in ('rvt_linear_dgrad', 'rvt_linear_gelu_fwd'):
+        M, N, K = args[-4], args[-3], args[-2]
         return linear_flops(M, N, K)
     if name in ('rvt_lstm_fwd', 'rvt_lstm_dgrad', 'rvt_lstm_wgrad'):
         M, C = args[-3], args[-2]
         return linear_flops(M, 4 * C, 2 * C)
     return None
+
+
+def measured_traffic(entry_point):
+    """HBM bytes per launch of `entry_point` from the committed rocprofv3 PMC passes (profiles/latest_traffic.json,
+    written by profiles/summarize_rocprof.py: 2*FETCH_SIZE + WRITE_SIZE KiB, the gfx950 correction of the guide)."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'latest_traffic.json')) as f:
+            t = json.load(f)
+        return t[entry_point]['traffic_bytes_per_launch']
+    except Exception:
+        return None
 
 
 def build_model(wl, dtype, device):
@@ -297,7 +303,7 @@ def main():
             'mfma_roofline_frac_whole_step': round(path_tflops / peak, 4),
             'algorithmic_tflops_per_gpu': round(path_tflops, 2),
             'roofline': {'bound': 'mfma', 'kernel': dominant, 'achieved': round(achieved, 2), 'peak': peak,
-                         'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4), 'traffic': None,
+                         'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4), 'traffic': measured_traffic(dominant),
                          'launches': len(recs), 'avg_launch_ms': round(dom_ms / len(recs), 4),
                          'share_of_step': round(dom_ms / (ms_per_step * args.steps), 3)},
         }

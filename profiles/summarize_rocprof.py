@@ -42,3 +42,32 @@ for what in ('fetch', 'write'):
         print(f'== {what.upper()}_SIZE per kernel ({os.path.relpath(f, out)}); counter unit = KiB, raw (uncorrected) ==')
         for k, (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
             print(f'{k:90s} dispatches={n:6d} sum={v / 1024 / 1024:10.3f} GiB avg={v / n / 1024:10.3f} MiB')
+
+
+# ---- per-entry-point HBM traffic (bytes per launch) for bench.py's `roofline.traffic` --------------------------------
+# gfx950 correction (MI355X_MICROARCH.md §HBM): FETCH_SIZE under-reports wide coalesced reads by exactly 2x; WRITE_SIZE was
+# calibrated here on ln_fwd (equal read and write bytes) and matches the byte count 1:1.  Counter unit: KiB.
+import json
+
+ENTRY = {   # kernel-name predicate -> C entry point
+    'rvt_linear_wgrad': lambda k: 'gemm_kernel' in k and 'Lb1ELb0' in k and 'PlainSrc' in k and 'ConcatSrc' not in k and 'Im2colSrc' not in k,
+    'rvt_linear_dgrad': lambda k: False,
+}
+raw = {}
+for what in ('fetch', 'write'):
+    for f in glob.glob(os.path.join(out, what, '**', '*counter_collection.csv'), recursive=True):
+        for r in csv.DictReader(open(f)):
+            for ep, pred in ENTRY.items():
+                if pred(r['Kernel_Name']):
+                    e = raw.setdefault(ep, {'fetch': 0.0, 'write': 0.0, 'n_fetch': 0, 'n_write': 0})
+                    e[what] += float(r['Counter_Value'])
+                    e['n_' + what] += 1
+res = {}
+for ep, e in raw.items():
+    if e['n_fetch'] and e['n_write']:
+        res[ep] = {'launches_profiled': e['n_fetch'],
+                   'fetch_size_kib_raw_per_launch': e['fetch'] / e['n_fetch'],
+                   'write_size_kib_raw_per_launch': e['write'] / e['n_write'],
+                   'traffic_bytes_per_launch': int(1024 * (2 * e['fetch'] / e['n_fetch'] + e['write'] / e['n_write']))}
+json.dump(res, open(os.path.join(out, 'traffic.json'), 'w'), indent=1)
+print('== traffic per launch ==', json.dumps(res))

@@ -42,7 +42,9 @@ static inline int wgrad_ksplit(int out_rows, int out_cols, int tokens, int bn) {
     int tiles = ((out_rows + 127) / 128) * ((out_cols + bn - 1) / bn);
     int want = imax(1, (split_override > 0 ? split_override : 256) / imax(1, tiles));   // ~one workgroup per CU (measured best)
     int maxs = imax(1, tokens / 512);
-    return imin(want, maxs);
+    int ks = imin(want, maxs);
+    if (ks >= 16) ks = ks / 8 * 8;             // multiple of 8 slices: tiles of one slice can share an XCD's L2
+    return ks;
 }
 }  // namespace rvt
 

@@ -501,7 +501,16 @@ gemm_kernel(ASrc as, AXf axf, BSrc bs, BXf bxf, Ep ep, int M, int N, int K, int 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int kbeg = blockIdx.y * ksplit_len;
+    // TN (split-K) launches: workgroups are dispatched round-robin over the 8 XCDs (private L2s).  The tiles of one
+    // K slice share an operand, so deal them to ids that differ by a multiple of 8 (same XCD, adjacent in time): the
+    // second reader then hits L2 instead of HBM.  Pure speed: any placement is correct.
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (TN && (gridDim.y % 8) == 0 && gridDim.x > 1) {
+        const int L = blockIdx.y * gridDim.x + blockIdx.x, span = 8 * gridDim.x;
+        by = (L / span) * 8 + (L % 8);
+        bx = (L % span) / 8;
+    }
+    const int kbeg = by * ksplit_len;
     const int kend = (kbeg + ksplit_len < K) ? kbeg + ksplit_len : K;
     const int nk = (kend - kbeg + BK - 1) / BK;
     const int G = gridDim.x;
@@ -510,8 +519,8 @@ gemm_kernel(ASrc as, AXf axf, BSrc bs, BXf bxf, Ep ep, int M, int N, int K, int 
     // workgroup per (tile, K-slice)).  panel_major: a workgroup sweeps all N tiles of its 128-row panel so the
     // A panel comes from HBM once; otherwise tiles are dealt round-robin with N fastest.
     auto tile_of = [&](int seq, int& mt, int& nt) -> bool {
-        if (panel_major) { mt = blockIdx.x + (seq / n_tiles) * G; nt = seq % n_tiles; return mt < m_tiles; }
-        const int t = blockIdx.x + seq * G;
+        if (panel_major) { mt = bx + (seq / n_tiles) * G; nt = seq % n_tiles; return mt < m_tiles; }
+        const int t = bx + seq * G;
         mt = t / n_tiles; nt = t - mt * n_tiles;
         return t < m_tiles * n_tiles;
     };
@@ -519,7 +528,7 @@ gemm_kernel(ASrc as, AXf axf, BSrc bs, BXf bxf, Ep ep, int M, int N, int K, int 
     typedef typename std::conditional<TN, TNLoader<T, BM, ASrc, AXf, false>, NTLoader<T, BM, ASrc, AXf>>::type LA;
     typedef typename std::conditional<TN, TNLoader<T, BN, BSrc, BXf, true>, NTLoader<T, BN, BSrc, BXf>>::type LB;
     LA la; LB lb;
-    ep.begin_block((int)blockIdx.y);
+    ep.begin_block(by);
 
     int seq = 0, mt, nt;
     bool have = tile_of(0, mt, nt);
@@ -573,7 +582,7 @@ gemm_kernel(ASrc as, AXf axf, BSrc bs, BXf bxf, Ep ep, int M, int N, int K, int 
 
         // bias gradient: per-K-slice partial column sums of the A operand -> a_colsum[slice][M]  (workgroup-uniform branch)
         if (TN && a_colsum != nullptr && n0 == 0)
-            la.flush_colsum(a_colsum + (size_t)blockIdx.y * M, m0, reinterpret_cast<float*>(smem), M);
+            la.flush_colsum(a_colsum + (size_t)by * M, m0, reinterpret_cast<float*>(smem), M);
 
         // next tile's first K tile: issue its global loads now so they fly during this tile's epilogue
         int mt2 = 0, nt2 = 0;

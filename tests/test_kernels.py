@@ -128,7 +128,8 @@ def test_linear_dgrad(backend, dt, with_gelu):
 
 
 @pytest.mark.parametrize('dt', DTYPES)
-@pytest.mark.parametrize('M,N,K,gelu', [(300, 24, 40, False), (1100, 136, 72, True), (70, 264, 16, False)])
+@pytest.mark.parametrize('M,N,K,gelu', [(300, 24, 40, False), (1100, 136, 72, True), (70, 264, 16, False),
+                                        (8200, 136, 72, False)])     # >= 16 K slices: XCD-dealt tile order
 def test_linear_wgrad(backend, dt, M, N, K, gelu):
     dy, x = rnd((M, N), backend, dt, 1), rnd((M, K), backend, dt, 2)
     dw = torch.zeros(N, K, device=backend)
