@@ -327,22 +327,43 @@ int rvt_mlp_fused_supported(int dtype, int C) {
     return 0;
 }
 
-int rvt_mlp_fwd(const void* xmid, void* xout, const float* ln_w, const float* ln_b, const void* w1, const float* b1,
-                const void* w2, const float* b2, const float* gamma, int dtype, int M, int C, float eps, void* stream) {
-    RVT_CHECK(rvt_mlp_fused_supported(dtype, C), "mlp_fwd: fused MLP not built for dtype=%d C=%d", dtype, C);
-    hipStream_t st = (hipStream_t)stream;
+static int mlp_grid(int dtype, int C, int M) {
     static const int resident_override = getenv("RVT_GEMM_RESIDENT") ? atoi(getenv("RVT_GEMM_RESIDENT")) : 0;
     const int n_tiles = (M + 127) / 128;
-    const int per_cu = (dtype == RVT_BF16 && C == 64) ? 2 : 1;
-    const int grid = imax(1, imin(n_tiles, resident_override > 0 ? resident_override : 256 * per_cu));
-#define RVT_MLP_FWD(TT, CC)                                                                                          \
-    hipLaunchKernelGGL((mlp_fwd_kernel<TT, CC>), dim3(grid), dim3(256), 0, st, (const TT*)xmid, (TT*)xout, ln_w, ln_b, \
-                       (const TT*)w1, b1, (const TT*)w2, b2, gamma, M, eps)
+    return imax(1, imin(n_tiles, resident_override > 0 ? resident_override : 256));     // ~97-129 KiB LDS: one per CU
+}
+
+int rvt_mlp_fwd(const void* xmid, void* xout, void* g_out, void* gp_out, const float* ln_w, const float* ln_b,
+                const void* w1, const float* b1, const void* w2, const float* b2, const float* gamma, int dtype, int M,
+                int C, float eps, void* stream) {
+    RVT_CHECK(rvt_mlp_fused_supported(dtype, C), "mlp_fwd: fused MLP not built for dtype=%d C=%d", dtype, C);
+    RVT_CHECK((g_out == nullptr) == (gp_out == nullptr), "mlp_fwd: g_out and gp_out go together");
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = mlp_grid(dtype, C, M);
+#define RVT_MLP_FWD(TT, CC)                                                                                           \
+    hipLaunchKernelGGL((mlp_fwd_kernel<TT, CC>), dim3(grid), dim3(256), 0, st, (const TT*)xmid, (TT*)xout, (TT*)g_out, \
+                       (TT*)gp_out, ln_w, ln_b, (const TT*)w1, b1, (const TT*)w2, b2, gamma, M, eps)
     if (dtype == RVT_BF16 && C == 64) RVT_MLP_FWD(bf16, 64);
     else if (dtype == RVT_BF16 && C == 128) RVT_MLP_FWD(bf16, 128);
     else RVT_MLP_FWD(float, 64);
 #undef RVT_MLP_FWD
     return check_launch("mlp_fwd");
+}
+
+int rvt_mlp_bwd_dgrad(const void* dxout, const void* gp, const void* xmid, void* dh, void* dxmid, const float* ln_w,
+                      const void* w2g_t, const void* w1_t, float* dln_w, float* dln_b, int dtype, int M, int C, float eps,
+                      void* stream) {
+    RVT_CHECK(rvt_mlp_fused_supported(dtype, C), "mlp_bwd_dgrad: fused MLP not built for dtype=%d C=%d", dtype, C);
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = mlp_grid(dtype, C, M);
+#define RVT_MLP_BWD(TT, CC)                                                                                            \
+    hipLaunchKernelGGL((mlp_bwd_dgrad_kernel<TT, CC>), dim3(grid), dim3(256), 0, st, (const TT*)dxout, (const TT*)gp,     \
+                       (const TT*)xmid, (TT*)dh, (TT*)dxmid, ln_w, (const TT*)w2g_t, (const TT*)w1_t, dln_w, dln_b, M, eps)
+    if (dtype == RVT_BF16 && C == 64) RVT_MLP_BWD(bf16, 64);
+    else if (dtype == RVT_BF16 && C == 128) RVT_MLP_BWD(bf16, 128);
+    else RVT_MLP_BWD(float, 64);
+#undef RVT_MLP_BWD
+    return check_launch("mlp_bwd_dgrad");
 }
 
 // ----------------------------------------------------------------------------------------- attention

@@ -2,18 +2,22 @@
 //
 //     xout = xmid + gamma2 * ( GELU( LN2(xmid) W1^T + b1 ) W2^T + b2 )
 //
-// in ONE kernel per 128-token tile: the normalised tile, the 4C-wide hidden activations and both weight panels
-// live in LDS / registers only.  HBM traffic is one read of xmid and one write of xout (2*C*sizeof(T) per token)
-// instead of the ~17*C*sizeof(T) of the op-by-op chain (LayerNorm r/w, fc1 r + hidden w, fc2 hidden r + res r + w).
-// For C <= 128 (stages 1-2 of RVT, where the unfused chain is HBM-bound) this turns the MLP MFMA-bound:
-// per tile 2*(4C/JC)*... MFMAs vs 2*128*C*sizeof(T) bytes.
+// Op-by-op this chain moves ~17 (forward) + ~18 (input-gradient path of backward) activation rows of C elements per
+// token through HBM; at C <= 128 (RVT stages 1-2) every one of those kernels is HBM-bound.  The two kernels here
+// keep the LayerNorm output and the data flow between the two linears on chip:
 //
-// Structure per workgroup (256 threads = 4 waves as 2x2, persistent over token tiles):
-//   1. load the [128][C] tile (16-byte vectors, G=C/8 lanes per row), LayerNorm it in registers (wave shuffles,
-//      fp32 statistics), store v2 into a swizzled LDS A operand; the raw tile stays in registers as the residual.
-//   2. for each hidden chunk j of JC columns:  stage W1_j -> LDS;  H = GELU(v2 W1_j^T + b1_j) (MFMA, epilogue in
-//      registers) -> LDS as the next A operand;  stage W2[:, j] -> LDS;  acc += H W2_j^T.
-//   3. acc -> fp32 LDS staging -> out = residual + gamma*(acc + b2), 16-byte stores.
+//   mlp_fwd_kernel       reads xmid, writes xout and (training) g = GELU(h), gp = GELU'(h)           1 + 8 + 1 rows
+//   mlp_bwd_dgrad_kernel reads dxout, gp, xmid; writes dh (needed by the fc1 weight gradient) and
+//                        dxmid = dxout + LN2'(dh W1)   — fc2 dgrad * gp, fc1 dgrad and LayerNorm backward in one pass
+//
+// (weight gradients stay with the split-K TN GEMMs, which read g / dh.)
+//
+// Structure per workgroup (256 threads = 4 waves as 2x2, persistent over 128-token tiles):
+//   tile load in a (row, 8-channel chunk) thread layout -> LayerNorm statistics with wave shuffles -> swizzled LDS A
+//   operand; per hidden chunk of JC columns: weight panels -> LDS, MFMA, accumulators -> fp32 LDS staging (64 rows per
+//   pass) -> back to the (row, chunk) layout where bias/GELU/gp are applied on 16-byte vectors that go to HBM and, as
+//   the next A operand, to LDS; second MFMA; final epilogue (LayerScale+residual / LayerNorm backward) in the same
+//   (row, chunk) layout, with the raw input tile still in registers.
 // JC = 128 (bf16) / 64 (f32) so that all operands fit the 160 KiB LDS.
 #pragma once
 #include "common.hpp"
@@ -24,21 +28,18 @@ namespace rvt {
 // ---- LDS operand matrix: [rows][K] stored as K/BK sub-tiles of [rows][128 bytes], XOR-swizzled like GEMM tiles ----
 template <class T> __device__ __forceinline__ char* opm_subtile(char* base, int rows, int kt) { return base + (size_t)kt * rows * 128; }
 
-// element address (for scattered 1-element writes from accumulator layout)
-template <class T> __device__ __forceinline__ T* opm_elem(char* base, int rows, int row, int kcol) {
-    constexpr int BK = TileGeom<T>::BK;
-    const int kt = kcol / BK, kin = kcol % BK;
-    const int byte = kin * (int)sizeof(T);
-    return reinterpret_cast<T*>(opm_subtile<T>(base, rows, kt) + lds_chunk_off(row, byte >> 4) + (byte & 15));
+// store an 8-element fragment at (row, kcol0 = 8*fcg)
+template <class T> __device__ __forceinline__ void opm_store_frag(char* base, int rows, int row, int fcg, const frag_t<T>& v) {
+    constexpr int FPR = TileGeom<T>::FPR;
+    tile_store_frag<T>(opm_subtile<T>(base, rows, fcg / FPR), row, fcg % FPR, v);
 }
 
 // stage a row-major global block [rows][kcols] (leading dimension ld elements) into an operand matrix; all 256 threads
 template <class T> __device__ __forceinline__ void opm_stage(char* base, const T* g, int ld, int rows, int kcols, int tid) {
-    constexpr int FPR = TileGeom<T>::FPR;
     const int fpr_g = kcols / 8;
     for (int f = tid; f < rows * fpr_g; f += 256) {
         const int row = f / fpr_g, fcg = f % fpr_g;
-        tile_store_frag<T>(opm_subtile<T>(base, rows, fcg / FPR), row, fcg % FPR, frag_load<T>(g + (size_t)row * ld + fcg * 8));
+        opm_store_frag<T>(base, rows, row, fcg, frag_load<T>(g + (size_t)row * ld + fcg * 8));
     }
 }
 
@@ -67,65 +68,95 @@ __device__ __forceinline__ void opm_mma(f32x16 (&acc)[MI][NJ], const char* A, in
     }
 }
 
+// one 64-row pass of a 2x2-wave accumulator (wave tile 64 x 32*NJ) into fp32 staging [64][ld]:
+// MFMA row block i of every wave: stage row wm*32+r  <->  tile row wm*64+i*32+r
+template <int NJ>
+__device__ __forceinline__ void stage_pass(float* stage, int ld, const f32x16 (&acc)[2][NJ], int i, int wm, int wn, int lane) {
+#pragma unroll
+    for (int j = 0; j < NJ; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            stage[(wm * 32 + acc_row(r, lane)) * ld + wn * (32 * NJ) + j * 32 + (lane & 31)] = acc[i][j][r];
+}
+__device__ __forceinline__ int stage_row_to_tile_row(int srow, int pass) { return (srow >> 5) * 64 + pass * 32 + (srow & 31); }
+__device__ __forceinline__ void stage_read8(const float* stage, int ld, int srow, int col0, float (&v)[8]) {
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(stage + srow * ld + col0 + h * 4);
+        v[h * 4 + 0] = t[0]; v[h * 4 + 1] = t[1]; v[h * 4 + 2] = t[2]; v[h * 4 + 3] = t[3];
+    }
+}
+
 template <class T> struct MlpGeom { static constexpr int JC = sizeof(T) == 2 ? 128 : 64; };
 
-template <class T, int C> struct MlpFwdSmem {
+template <class T, int C> struct MlpSmem {
     static constexpr int JC = MlpGeom<T>::JC;
-    static constexpr int ROWB = 128;                                   // bytes per operand row
     static constexpr int KT_C = C / TileGeom<T>::BK, KT_J = JC / TileGeom<T>::BK;
-    static constexpr int A_V2 = KT_C * 128 * ROWB;                     // [128 tokens][C]
-    static constexpr int B_W1 = KT_C * JC * ROWB;                      // [JC hidden][C]
-    static constexpr int A_H = KT_J * 128 * ROWB;                      // [128 tokens][JC]
-    static constexpr int B_W2 = KT_J * C * ROWB;                       // [C out][JC]
-    static constexpr int OFF_W1 = A_V2, OFF_H = OFF_W1 + B_W1, OFF_W2 = OFF_H + A_H;
-    static constexpr int BYTES = OFF_W2 + B_W2;
-    static_assert(64 * (C + 4) * 4 <= A_H + B_W2, "epilogue staging overlays the (contiguous) H and W2 tiles");
+    static constexpr int A_X = KT_C * 128 * 128;                       // [128 tokens][C]   (v2 in fwd, dxout in bwd)
+    static constexpr int B_1 = KT_C * JC * 128;                        // [JC][C]           (W1_j / (W2 gamma)^T_j)
+    static constexpr int STG_A = 64 * (JC + 4) * 4, STG_B = 64 * (C + 4) * 4;
+    static constexpr int STG = STG_A > STG_B ? STG_A : STG_B;          // fp32 staging, overlays B_1 (+ pad)
+    static constexpr int R1 = B_1 > STG ? B_1 : STG;
+    static constexpr int A_H = KT_J * 128 * 128;                       // [128 tokens][JC]  (g in fwd, dh in bwd)
+    static constexpr int B_2 = KT_J * C * 128;                         // [C][JC]           (W2[:, j] / W1^T[:, j])
+    static constexpr int OFF_1 = A_X, OFF_H = OFF_1 + R1, OFF_2 = OFF_H + A_H;
+    static constexpr int BYTES = OFF_2 + B_2;
+    static_assert(BYTES <= 160 * 1024, "fused MLP tile does not fit the LDS");
 };
 
+// (row, 8-channel chunk) thread layout of a [128][C] tile: slot q of thread tid is frag f = tid + 256 q, row f/G, chunk f%G
+template <class T, int C> struct TileSlots {
+    static constexpr int G = C / 8;
+    static constexpr int NFX = 128 * G / 256;
+};
+
+// ===================================================================================================== forward
 template <class T, int C>
 __global__ void __launch_bounds__(256)
-mlp_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, const float* __restrict__ ln_w, const float* __restrict__ ln_b,
-               const T* __restrict__ W1, const float* __restrict__ b1, const T* __restrict__ W2, const float* __restrict__ b2,
+mlp_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, T* __restrict__ g_out, T* __restrict__ gp_out,
+               const float* __restrict__ ln_w, const float* __restrict__ ln_b, const T* __restrict__ W1,
+               const float* __restrict__ b1, const T* __restrict__ W2, const float* __restrict__ b2,
                const float* __restrict__ gamma, int M, float eps) {
-    typedef MlpFwdSmem<T, C> S;
+    typedef MlpSmem<T, C> S;
     constexpr int JC = S::JC, HID = 4 * C;
-    constexpr int G = C / 8;                       // lanes per row (8 or 16: power of two)
-    constexpr int NFX = 128 * G / 256;             // tile frags per thread
-    constexpr int NJ1 = JC / 64;                   // fc1 MFMA column blocks per wave (wave tile 64 x JC/2)
-    constexpr int NJ2 = C / 64;                    // fc2 MFMA column blocks per wave (wave tile 64 x C/2)
+    constexpr int G = TileSlots<T, C>::G, NFX = TileSlots<T, C>::NFX;
+    constexpr int NJ1 = JC / 64, NJ2 = C / 64;
+    constexpr int LD1 = JC + 4, LD2 = C + 4;
+    constexpr int UPR1 = JC / 8;                           // 8-column units per staged row (fc1 side)
     __shared__ __attribute__((aligned(16))) char smem[S::BYTES];
-    char* const Av2 = smem;
-    char* const Bw1 = smem + S::OFF_W1;
+    char* const Ax = smem;
+    char* const B1 = smem + S::OFF_1;
+    float* const stage = reinterpret_cast<float*>(smem + S::OFF_1);
     char* const Ah = smem + S::OFF_H;
-    char* const Bw2 = smem + S::OFF_W2;
+    char* const B2 = smem + S::OFF_2;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1, li = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
     const int n_tiles = (M + 127) / 128;
 
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int m0 = tile * 128;
-        // ---- 1. load + LayerNorm (reference maxvit.py:241; biased variance, eps inside the sqrt) ----
+        // ---- load + LayerNorm (maxvit.py:241) ----
         frag_t<T> raw[NFX];
 #pragma unroll
-        for (int i = 0; i < NFX; i++) {
-            const int f = tid + i * 256, row = f / G, cl = f % G;
+        for (int q = 0; q < NFX; q++) {
+            const int f = tid + q * 256, row = f / G, cl = f % G;
             const bool ok = m0 + row < M;
             float v[8];
-            raw[i] = frag_load<T>(xmid + (size_t)(ok ? m0 + row : 0) * C + cl * 8);
-            frag_to_float<T>(raw[i], v);
+            raw[q] = frag_load<T>(xmid + (size_t)(ok ? m0 + row : 0) * C + cl * 8);
+            frag_to_float<T>(raw[q], v);
             float s = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; e++) s += v[e];
             const float mean = group_sum(s, G) / (float)C;
-            float q = 0.f;
+            float qq = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; e++) { const float d = v[e] - mean; q += d * d; }
-            const float rstd = 1.0f / sqrtf(group_sum(q, G) / (float)C + eps);
+            for (int e = 0; e < 8; e++) { const float d = v[e] - mean; qq += d * d; }
+            const float rstd = 1.0f / sqrtf(group_sum(qq, G) / (float)C + eps);
             float o[8];
 #pragma unroll
             for (int e = 0; e < 8; e++) o[e] = ok ? (v[e] - mean) * rstd * ln_w[cl * 8 + e] + ln_b[cl * 8 + e] : 0.f;
-            tile_store_frag<T>(opm_subtile<T>(Av2, 128, cl / TileGeom<T>::FPR), row, cl % TileGeom<T>::FPR, frag_from_float<T>(o));
+            opm_store_frag<T>(Ax, 128, row, cl, frag_from_float<T>(o));
         }
 
         f32x16 acc2[2][NJ2];
@@ -134,67 +165,214 @@ mlp_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, const float* __
 #pragma unroll
             for (int j = 0; j < NJ2; j++) acc_zero(acc2[i][j]);
 
-        // ---- 2. hidden chunks ----
         for (int j0 = 0; j0 < HID; j0 += JC) {
-            opm_stage<T>(Bw1, W1 + (size_t)j0 * C, C, JC, C, tid);              // W1 rows j0..j0+JC-1, all C columns
-            opm_stage<T>(Bw2, W2 + j0, HID, C, JC, tid);                        // W2[:, j0..j0+JC-1]
-            __syncthreads();                                                     // v2, W1_j, W2_j visible; previous H consumed
+            opm_stage<T>(B1, W1 + (size_t)j0 * C, C, JC, C, tid);               // W1 rows j0.., all C columns
+            opm_stage<T>(B2, W2 + j0, HID, C, JC, tid);                         // W2[:, j0..j0+JC)
+            __syncthreads();
             f32x16 acc1[2][NJ1];
 #pragma unroll
             for (int i = 0; i < 2; i++)
 #pragma unroll
                 for (int j = 0; j < NJ1; j++) acc_zero(acc1[i][j]);
-            opm_mma<T, 2, NJ1>(acc1, Av2, 128, wm * 64, Bw1, JC, wn * (JC / 2), C, lane);
-            // GELU epilogue in registers -> H as the A operand of fc2
+            opm_mma<T, 2, NJ1>(acc1, Ax, 128, wm * 64, B1, JC, wn * (JC / 2), C, lane);
+            __syncthreads();                                                     // B1 consumed -> staging may overlay it
 #pragma unroll
-            for (int jb = 0; jb < NJ1; jb++) {
-                const int n = wn * (JC / 2) + jb * 32 + li;
-                const float bias = b1[j0 + n];
+            for (int i = 0; i < 2; i++) {
+                if (i) __syncthreads();
+                stage_pass<NJ1>(stage, LD1, acc1, i, wm, wn, lane);
+                __syncthreads();
+                for (int u = tid; u < 64 * UPR1; u += 256) {
+                    const int srow = u / UPR1, cu = u % UPR1;
+                    const int row = stage_row_to_tile_row(srow, i);
+                    float v[8], a[8], b[8];
+                    stage_read8(stage, LD1, srow, cu * 8, v);
 #pragma unroll
-                for (int i = 0; i < 2; i++)
-#pragma unroll
-                    for (int r = 0; r < 16; r++)
-                        *opm_elem<T>(Ah, 128, wm * 64 + i * 32 + acc_row(r, lane), n) = (T)gelu_f(acc1[i][jb][r] + bias);
+                    for (int e = 0; e < 8; e++) gelu_both_f(v[e] + b1[j0 + cu * 8 + e], a[e], b[e]);
+                    const frag_t<T> gf = frag_from_float<T>(a);
+                    opm_store_frag<T>(Ah, 128, row, cu, gf);
+                    if (g_out != nullptr && m0 + row < M) {
+                        const size_t o = (size_t)(m0 + row) * HID + j0 + cu * 8;
+                        frag_store<T>(g_out + o, gf);
+                        frag_store<T>(gp_out + o, frag_from_float<T>(b));
+                    }
+                }
             }
             __syncthreads();
-            opm_mma<T, 2, NJ2>(acc2, Ah, 128, wm * 64, Bw2, C, wn * (C / 2), JC, lane);
-            __syncthreads();                                                     // H / W tiles free for the next chunk
+            opm_mma<T, 2, NJ2>(acc2, Ah, 128, wm * 64, B2, C, wn * (C / 2), JC, lane);
+            __syncthreads();                                                     // Ah / B2 / staging free for the next chunk
         }
 
-        // ---- 3. epilogue: LayerScale + residual (maxvit.py:51-53,269), 64 tile rows per staging pass ----
-        float* stage = reinterpret_cast<float*>(Ah);
-        constexpr int LDS_LD = C + 4;
+        // ---- LayerScale + residual (maxvit.py:51-53,269) in the load layout: the residual is still in registers ----
 #pragma unroll
         for (int i = 0; i < 2; i++) {
             if (i) __syncthreads();
-#pragma unroll
-            for (int jb = 0; jb < NJ2; jb++)
-#pragma unroll
-                for (int r = 0; r < 16; r++)
-                    stage[(wm * 32 + acc_row(r, lane)) * LDS_LD + wn * (C / 2) + jb * 32 + li] = acc2[i][jb][r];
+            stage_pass<NJ2>(stage, LD2, acc2, i, wm, wn, lane);
             __syncthreads();
-            // thread (row, chunk) mapping of step 1: frag slot q of this thread is tile row (tid + 256 q)/G — the rows of
-            // pass i are those with ((row>>5)&1) == i, i.e. every thread owns NFX/2 of them
 #pragma unroll
             for (int q = 0; q < NFX; q++) {
                 const int f = tid + q * 256, row = f / G, cl = f % G;
                 if (((row >> 5) & 1) != i) continue;
-                const int srow = (row >> 6) * 32 + (row & 31);
                 if (m0 + row < M) {
                     float v[8], res[8];
                     frag_to_float<T>(raw[q], res);
-#pragma unroll
-                    for (int h = 0; h < 2; h++) {
-                        const f32x4 t = *reinterpret_cast<const f32x4*>(stage + srow * LDS_LD + cl * 8 + h * 4);
-                        v[h * 4 + 0] = t[0]; v[h * 4 + 1] = t[1]; v[h * 4 + 2] = t[2]; v[h * 4 + 3] = t[3];
-                    }
+                    stage_read8(stage, LD2, (row >> 6) * 32 + (row & 31), cl * 8, v);
 #pragma unroll
                     for (int e = 0; e < 8; e++) v[e] = res[e] + gamma[cl * 8 + e] * (v[e] + b2[cl * 8 + e]);
                     frag_store<T>(xout + (size_t)(m0 + row) * C + cl * 8, frag_from_float<T>(v));
                 }
             }
         }
-        __syncthreads();            // staging (Ah) and Av2 are rewritten by the next tile
+        __syncthreads();
+    }
+}
+
+// ================================================================================ backward: input-gradient chain
+// dh[m][4C]   = (dxout W2g)[m][:] * gp[m][:]              W2g^T = (W2 * gamma)^T stored [4C][C]  ("fc2_wt")
+// dv2[m][C]   = dh W1                                      W1^T stored [C][4C]                    ("fc1_wt")
+// dxmid       = dxout + LN2'(dv2; xmid)                    dln_w += dv2 * xhat, dln_b += dv2
+template <class T, int C>
+__global__ void __launch_bounds__(256)
+mlp_bwd_dgrad_kernel(const T* __restrict__ dxout, const T* __restrict__ gp, const T* __restrict__ xmid, T* __restrict__ dh,
+                     T* __restrict__ dxmid, const float* __restrict__ ln_w, const T* __restrict__ W2gT,
+                     const T* __restrict__ W1T, float* __restrict__ dln_w, float* __restrict__ dln_b, int M, float eps) {
+    typedef MlpSmem<T, C> S;
+    constexpr int JC = S::JC, HID = 4 * C;
+    constexpr int G = TileSlots<T, C>::G, NFX = TileSlots<T, C>::NFX;
+    constexpr int NJ1 = JC / 64, NJ2 = C / 64;
+    constexpr int LD1 = JC + 4, LD2 = C + 4;
+    constexpr int UPR1 = JC / 8;
+    __shared__ __attribute__((aligned(16))) char smem[S::BYTES];
+    char* const Ax = smem;                                  // dxout tile
+    char* const B1 = smem + S::OFF_1;                       // W2g^T rows j0..: [JC][C]
+    float* const stage = reinterpret_cast<float*>(smem + S::OFF_1);
+    char* const Ah = smem + S::OFF_H;                       // dh chunk
+    char* const B2 = smem + S::OFF_2;                       // W1^T[:, j0..]: [C][JC]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n_tiles = (M + 127) / 128;
+    const int cl_own = tid % G;                             // every slot of this thread has the same channel chunk
+    float aw[8], ab[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) { aw[e] = 0.f; ab[e] = 0.f; }
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int m0 = tile * 128;
+        frag_t<T> rawdx[NFX], rawx[NFX];
+        float mean[NFX], rstd[NFX];
+#pragma unroll
+        for (int q = 0; q < NFX; q++) {
+            const int f = tid + q * 256, row = f / G, cl = f % G;
+            const bool ok = m0 + row < M;
+            const size_t o = (size_t)(ok ? m0 + row : 0) * C + cl * 8;
+            rawdx[q] = frag_load<T>(dxout + o);
+            rawx[q] = frag_load<T>(xmid + o);
+            const frag_t<T> z = frag_zero<T>();
+            opm_store_frag<T>(Ax, 128, row, cl, ok ? rawdx[q] : z);
+            float v[8];
+            frag_to_float<T>(rawx[q], v);
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; e++) s += v[e];
+            mean[q] = group_sum(s, G) / (float)C;
+            float qq = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; e++) { const float d = v[e] - mean[q]; qq += d * d; }
+            rstd[q] = 1.0f / sqrtf(group_sum(qq, G) / (float)C + eps);
+        }
+
+        f32x16 acc2[2][NJ2];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < NJ2; j++) acc_zero(acc2[i][j]);
+
+        for (int j0 = 0; j0 < HID; j0 += JC) {
+            opm_stage<T>(B1, W2gT + (size_t)j0 * C, C, JC, C, tid);             // rows j0.. of (W2 gamma)^T
+            opm_stage<T>(B2, W1T + j0, HID, C, JC, tid);                        // W1^T[:, j0..j0+JC)
+            __syncthreads();
+            f32x16 acc1[2][NJ1];
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < NJ1; j++) acc_zero(acc1[i][j]);
+            opm_mma<T, 2, NJ1>(acc1, Ax, 128, wm * 64, B1, JC, wn * (JC / 2), C, lane);
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                if (i) __syncthreads();
+                stage_pass<NJ1>(stage, LD1, acc1, i, wm, wn, lane);
+                __syncthreads();
+                for (int u = tid; u < 64 * UPR1; u += 256) {
+                    const int srow = u / UPR1, cu = u % UPR1;
+                    const int row = stage_row_to_tile_row(srow, i);
+                    const bool ok = m0 + row < M;
+                    const size_t o = (size_t)(ok ? m0 + row : 0) * HID + j0 + cu * 8;
+                    float v[8], p[8];
+                    stage_read8(stage, LD1, srow, cu * 8, v);
+                    frag_to_float<T>(frag_load<T>(gp + o), p);
+#pragma unroll
+                    for (int e = 0; e < 8; e++) v[e] = ok ? v[e] * p[e] : 0.f;
+                    const frag_t<T> df = frag_from_float<T>(v);
+                    opm_store_frag<T>(Ah, 128, row, cu, df);
+                    if (ok) frag_store<T>(dh + o, df);
+                }
+            }
+            __syncthreads();
+            opm_mma<T, 2, NJ2>(acc2, Ah, 128, wm * 64, B2, C, wn * (C / 2), JC, lane);
+            __syncthreads();
+        }
+
+        // ---- LayerNorm backward + residual, in the load layout (all lanes of a row group take part in the shuffles) ----
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            if (i) __syncthreads();
+            stage_pass<NJ2>(stage, LD2, acc2, i, wm, wn, lane);
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < NFX; q++) {
+                const int f = tid + q * 256, row = f / G, cl = f % G;
+                const bool mine = ((row >> 5) & 1) == i;          // uniform over the G lanes of a row
+                const bool ok = mine && (m0 + row < M);
+                float d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, xv[8], dxv[8], xh[8];
+                if (mine) stage_read8(stage, LD2, (row >> 6) * 32 + (row & 31), cl * 8, d);
+                frag_to_float<T>(rawx[q], xv);
+                frag_to_float<T>(rawdx[q], dxv);
+                float gsum = 0.f, gxsum = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    d[e] = ok ? d[e] : 0.f;
+                    xh[e] = ok ? (xv[e] - mean[q]) * rstd[q] : 0.f;
+                    const float g_ = d[e] * ln_w[cl * 8 + e];
+                    gsum += g_; gxsum += g_ * xh[e];
+                    aw[e] += d[e] * xh[e]; ab[e] += d[e];
+                }
+                const float m1 = group_sum(gsum, G) / (float)C;
+                const float m2 = group_sum(gxsum, G) / (float)C;
+                if (ok) {
+                    float o[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e++) o[e] = dxv[e] + rstd[q] * (d[e] * ln_w[cl * 8 + e] - m1 - xh[e] * m2);
+                    frag_store<T>(dxmid + (size_t)(m0 + row) * C + cl * 8, frag_from_float<T>(o));
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // LayerNorm parameter gradients: fold the 256/G threads that own the same channel chunk, one atomic per channel per WG
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int e = 0; e < 8; e++) { red[tid * 16 + e] = aw[e]; red[tid * 16 + 8 + e] = ab[e]; }
+    __syncthreads();
+    if (tid < G) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            float sw = 0.f, sb = 0.f;
+            for (int t = tid; t < 256; t += G) { sw += red[t * 16 + e]; sb += red[t * 16 + 8 + e]; }
+            atomicAdd(dln_w + cl_own * 8 + e, sw);
+            atomicAdd(dln_b + cl_own * 8 + e, sb);
+        }
     }
 }
 

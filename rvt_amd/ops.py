@@ -136,14 +136,31 @@ def mlp_fused_supported(dtype: torch.dtype, C: int) -> bool:
 
 
 def mlp_fwd(xmid: Tensor, ln_w: Tensor, ln_b: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, gamma: Tensor,
-            eps: float, out: Optional[Tensor] = None) -> Tensor:
-    """xout = xmid + gamma*(GELU(LN(xmid) W1^T + b1) W2^T + b2), one fused kernel (hidden never hits HBM)."""
+            eps: float, want_grad: bool = False, out: Optional[Tensor] = None):
+    """xout = xmid + gamma*(GELU(LN(xmid) W1^T + b1) W2^T + b2) in one fused kernel; with want_grad also returns
+    g = GELU(h), gp = GELU'(h) (the only intermediates backward needs).  Returns (xout, g, gp)."""
     C = xmid.shape[-1]
     M = xmid.numel() // C
     y = _out(xmid, xmid.shape, out=out)
-    L.call('rvt_mlp_fwd', L.ptr(xmid), L.ptr(y), L.ptr(ln_w), L.ptr(ln_b), L.ptr(w1), L.ptr(b1), L.ptr(w2), L.ptr(b2),
-           L.ptr(gamma), L.dtype_code(xmid.dtype), M, C, float(eps), L.stream_of(xmid))
-    return y
+    g = gp = None
+    if want_grad:
+        g = torch.empty((*xmid.shape[:-1], 4 * C), dtype=xmid.dtype, device=xmid.device)
+        gp = torch.empty_like(g)
+    L.call('rvt_mlp_fwd', L.ptr(xmid), L.ptr(y), L.ptr(g), L.ptr(gp), L.ptr(ln_w), L.ptr(ln_b), L.ptr(w1), L.ptr(b1),
+           L.ptr(w2), L.ptr(b2), L.ptr(gamma), L.dtype_code(xmid.dtype), M, C, float(eps), L.stream_of(xmid))
+    return y, g, gp
+
+
+def mlp_bwd_dgrad(dxout: Tensor, gp: Tensor, xmid: Tensor, ln_w: Tensor, w2g_t: Tensor, w1_t: Tensor, dln_w: Tensor,
+                  dln_b: Tensor, eps: float):
+    """dh = (dxout (W2*gamma)) * gp;  dxmid = dxout + LN'(dh W1; xmid);  dln_w/dln_b += …  Returns (dh, dxmid)."""
+    C = xmid.shape[-1]
+    M = xmid.numel() // C
+    dh = torch.empty_like(gp)
+    dxmid = torch.empty_like(xmid)
+    L.call('rvt_mlp_bwd_dgrad', L.ptr(dxout), L.ptr(gp), L.ptr(xmid), L.ptr(dh), L.ptr(dxmid), L.ptr(ln_w), L.ptr(w2g_t),
+           L.ptr(w1_t), L.ptr(dln_w), L.ptr(dln_b), L.dtype_code(xmid.dtype), M, C, float(eps), L.stream_of(xmid))
+    return dh, dxmid
 
 
 def linear_dgrad(dy: Tensor, wt: Tensor, gelu_pre: Optional[Tensor] = None, add: Optional[Tensor] = None,

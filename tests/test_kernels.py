@@ -77,27 +77,48 @@ def test_linear_gelu_and_mul(backend, dt):
 
 @pytest.mark.parametrize('dt,C', [(torch.float32, 64), (torch.bfloat16, 64), (torch.bfloat16, 128)])
 @pytest.mark.parametrize('M', [300, 1000])
-def test_mlp_fused_fwd(backend, dt, C, M):
+def test_mlp_fused(backend, dt, C, M):
+    """Fused MLP forward (+ saved GELU/GELU') and fused backward dgrad chain vs fp64 autograd and vs the op-by-op chain."""
     assert ops.mlp_fused_supported(dt, C)
     x = rnd((M, C), backend, dt, 1, 1.5)
     lw, lb = rnd((C,), backend, torch.float32, 2) * 0.3 + 1.0, rnd((C,), backend, torch.float32, 3, 0.2)
     w1, b1 = rnd((4 * C, C), backend, dt, 4, 0.2), rnd((4 * C,), backend, torch.float32, 5, 0.2)
     w2, b2 = rnd((C, 4 * C), backend, dt, 6, 0.1), rnd((C,), backend, torch.float32, 7, 0.2)
     gam = rnd((C,), backend, torch.float32, 8)
-    y = ops.mlp_fwd(x, lw, lb, w1, b1, w2, b2, gam, 1e-5)
-    v2 = F.layer_norm(f64(x), (C,), f64(lw), f64(lb), 1e-5)
-    if dt == torch.bfloat16:
-        v2 = v2.to(dt).double()
-    h = F.gelu(v2 @ f64(w1).t() + f64(b1))
-    if dt == torch.bfloat16:
-        h = h.to(dt).double()
-    want = f64(x) + f64(gam) * (h @ f64(w2).t() + f64(b2))
-    close(y, want, dt, 'mlp_fwd fused')
-    # and against the op-by-op HIP chain it replaces
+    dy = rnd((M, C), backend, dt, 9)
+    y, g, gp = ops.mlp_fwd(x, lw, lb, w1, b1, w2, b2, gam, 1e-5, want_grad=True)
+    y_inf, g_none, _ = ops.mlp_fwd(x, lw, lb, w1, b1, w2, b2, gam, 1e-5, want_grad=False)
+    assert g_none is None and torch.equal(y.cpu(), y_inf.cpu())
+
+    xr = f64(x).requires_grad_(True)
+    lwr, lbr = f64(lw).requires_grad_(True), f64(lb).requires_grad_(True)
+    v2 = F.layer_norm(xr, (C,), lwr, lbr, 1e-5)
+    pre = v2 @ f64(w1).t() + f64(b1)
+    pre.retain_grad()
+    h = F.gelu(pre)
+    want = xr + f64(gam) * (h @ f64(w2).t() + f64(b2))
+    want.backward(f64(dy))
+    mult = 1.0 if dt == torch.float32 else 2.0
+    close(y, want, dt, 'mlp_fwd fused', mult=mult)
+    close(g, h, dt, 'mlp_fwd g', mult=mult)
+    hp = f64(pre.detach()).requires_grad_(True)
+    F.gelu(hp).sum().backward()
+    close(gp, hp.grad, dt, 'mlp_fwd gp', mult=mult)
+    # against the op-by-op HIP chain it replaces
     v2h = ops.layernorm_fwd(x, lw, lb, 1e-5)
-    g, _ = ops.linear_gelu_fwd(v2h, w1, b1, want_grad=False)
-    y2 = ops.linear_scale_res_fwd(g, w2, b2, gam, x)
-    close(y, y2.double(), dt, 'mlp_fwd fused vs chain')
+    g2, gp2 = ops.linear_gelu_fwd(v2h, w1, b1, want_grad=True)
+    y2 = ops.linear_scale_res_fwd(g2, w2, b2, gam, x)
+    close(y, y2.double(), dt, 'mlp_fwd fused vs chain', mult=mult)
+
+    # backward dgrad chain: dh (grad of the pre-activation), dxmid, LayerNorm parameter grads
+    w2g_t = (f64(w2) * f64(gam)[:, None]).t().to(dt).contiguous().to(backend)
+    w1_t = f64(w1).t().to(dt).contiguous().to(backend)
+    dlw, dlb = torch.zeros(C, device=backend), torch.zeros(C, device=backend)
+    dh, dxm = ops.mlp_bwd_dgrad(dy, gp, x, lw, w2g_t, w1_t, dlw, dlb, 1e-5)
+    close(dh, pre.grad, dt, 'mlp_bwd dh', mult=2 * mult)
+    close(dxm, xr.grad, dt, 'mlp_bwd dxmid', mult=2 * mult)
+    close(dlw, lwr.grad, dt, 'mlp_bwd dln_w', mult=2 * mult)
+    close(dlb, lbr.grad, dt, 'mlp_bwd dln_b', mult=2 * mult)
 
 
 @pytest.mark.parametrize('dt', DTYPES)
