@@ -18,10 +18,52 @@ from typing import Dict, List, Optional, Tuple
 
 import torch
 
+import os
+
 from . import ops
 from .weights import StageWeights, unpack_conv_wgrad
 
+
+def use_fused_mlp(dtype, C: int) -> bool:
+    """Opt-in (RVT_FUSED_MLP=1): route the MLP half of the blocks through the fused kernels of csrc/mlp.hpp where they
+    are built (C in {64,128}).  Off by default: on MI355X they are still slower than the op-by-op chain (one workgroup
+    per CU, un-pipelined phases — see DESIGN.md §5), so the measured default stays the chain."""
+    return os.environ.get('RVT_FUSED_MLP', '0') == '1' and ops.mlp_fused_supported(dtype, C)
+
 Tensor = torch.Tensor
+
+
+class SideStream:
+    """Weight-gradient GEMMs are off the critical path of backward (nothing downstream reads dW until the optimizer) and
+    are read-only streams, while the input-gradient chain they hang off is write-heavy; running them on a second HIP
+    stream lets the two share the chip.  Event-ordered after the producers of their operands; operands are
+    record_stream()-ed so the caching allocator does not recycle them early; join() orders the consumer after them."""
+    _streams = {}
+
+    def __init__(self, like: Tensor):
+        self.enabled = like.is_cuda and os.environ.get('RVT_WGRAD_STREAM', '1') == '1'
+        if self.enabled:
+            key = like.device.index
+            if key not in SideStream._streams:
+                SideStream._streams[key] = torch.cuda.Stream(device=like.device)
+            self.stream = SideStream._streams[key]
+            self.main = torch.cuda.current_stream(like.device)
+
+    def run(self, fn, *operands):
+        if not self.enabled:
+            return fn()
+        ev = torch.cuda.Event()
+        ev.record(self.main)
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ev)
+            for t in operands:
+                if t is not None:
+                    t.record_stream(self.stream)
+            return fn()
+
+    def join(self):
+        if self.enabled:
+            self.main.wait_stream(self.stream)
 
 
 @dataclass
@@ -80,10 +122,14 @@ def stage_seq_forward(sw: StageWeights, g: StageGeom, inp: Tensor, h0: Optional[
             qkv = ops.linear_fwd(u, bw['qkv_w'], bw['qkv_b'])                     # maxvit.py:347
             a = ops.attn_fwd(qkv, F_, H, W, C, g.dim_head, g.ph, g.pw, window)    # maxvit.py:349-352
             xmid = ops.linear_scale_res_fwd(a, bw['proj_w'], bw['proj_b'], bw['g1'], x)        # :353, :268
-            v2 = ops.layernorm_fwd(xmid, bw['n2_w'], bw['n2_b'], g.eps)
-            # MLP fc1 + exact GELU; GELU' is saved too so backward never re-evaluates erf (maxvit.py:100-112)
-            hg, hgp = ops.linear_gelu_fwd(v2, bw['fc1_w'], bw['fc1_b'], want_grad=save)
-            xout = ops.linear_scale_res_fwd(hg, bw['fc2_w'], bw['fc2_b'], bw['g2'], xmid)                # :269
+            if use_fused_mlp(dt, C):
+                xout, hg, hgp = ops.mlp_fwd(xmid, bw['n2_w'], bw['n2_b'], bw['fc1_w'], bw['fc1_b'], bw['fc2_w'],
+                                            bw['fc2_b'], bw['g2'], g.eps, want_grad=save)
+            else:
+                v2 = ops.layernorm_fwd(xmid, bw['n2_w'], bw['n2_b'], g.eps)
+                # MLP fc1 + exact GELU; GELU' is saved too so backward never re-evaluates erf (maxvit.py:100-112)
+                hg, hgp = ops.linear_gelu_fwd(v2, bw['fc1_w'], bw['fc1_b'], want_grad=save)
+                xout = ops.linear_scale_res_fwd(hg, bw['fc2_w'], bw['fc2_b'], bw['g2'], xmid)            # :269
             if save:
                 sv.blocks.append(dict(xin=x, qkv=qkv, a=a, xmid=xmid, hg=hg, hgp=hgp))
             x = xout
@@ -154,12 +200,16 @@ def stage_seq_backward(sw: StageWeights, g: StageGeom, sv: StageSaved, dH: Optio
             ops.lstm_dgrad(dz[t], sw.lstm_wt, dx[t], dhc[t])
             ops.dwconv(dhc[t], wh, None, dws['k'], transpose=True, out=nxt)
         dh_rec = nxt
-    dwl = zeros(4 * C, 2 * C)
-    dbl = zeros(4 * C)
+    side = SideStream(dz)
     h_seg = sv.Hall[:T].reshape(F_, H, W, C) if dws is None else sv.hconv.view(F_, H, W, C)
-    ops.lstm_wgrad(dz.view(F_, H, W, 4 * C), sv.xin_lstm, h_seg, dwl, dbl)
-    grads[pre + 'lstm.conv1x1.weight'] = dwl.reshape(4 * C, 2 * C, 1, 1)
-    grads[pre + 'lstm.conv1x1.bias'] = dbl
+
+    def lstm_wgrad_fn():
+        dwl = zeros(4 * C, 2 * C)
+        dbl = zeros(4 * C)
+        ops.lstm_wgrad(dz.view(F_, H, W, 4 * C), sv.xin_lstm, h_seg, dwl, dbl)
+        grads[pre + 'lstm.conv1x1.weight'] = dwl.reshape(4 * C, 2 * C, 1, 1)
+        grads[pre + 'lstm.conv1x1.bias'] = dbl
+    side.run(lstm_wgrad_fn, dz, sv.xin_lstm, h_seg)
     dh0, dc0 = dh_rec, dc_rec
     dx = dx.view(F_, H, W, C)
     if dws is not None:
@@ -189,42 +239,56 @@ def stage_seq_backward(sw: StageWeights, g: StageGeom, sv: StageSaved, dH: Optio
             s = sv.blocks[bi_flat]
             bp = f'{pre}att_blocks.{pi}.{"att_window" if window else "att_grid"}.'
             # MLP branch: xout = xmid + g2 * (gelu(hd) W2^T + b2)
-            S2 = zeros(C, 4 * C)
-            cs = zeros(C)
-            ops.linear_wgrad(dx, s['hg'], S2, colsum_out=cs)
-            grads[bp + 'mlp.net.2.weight'] = bw['g2'][:, None] * S2
-            grads[bp + 'mlp.net.2.bias'] = bw['g2'] * cs
-            grads[bp + 'ls2.gamma'] = (bw['fc2_w32'] * S2).sum(1) + p[bp + 'mlp.net.2.bias'].detach().to(f32) * cs
-            dhd = ops.linear_dgrad(dx, bw['fc2_wt'], mul=s['hgp'])
-            v2 = ops.layernorm_fwd(s['xmid'], bw['n2_w'], bw['n2_b'], g.eps)
-            dW1 = zeros(4 * C, C)
-            db1 = zeros(4 * C)
-            ops.linear_wgrad(dhd, v2, dW1, colsum_out=db1)
-            grads[bp + 'mlp.net.0.0.weight'] = dW1
-            grads[bp + 'mlp.net.0.0.bias'] = db1
-            dv2 = ops.linear_dgrad(dhd, bw['fc1_wt'])
-            del dhd, v2
+            def fc2_wgrad_fn(dx=dx, s=s, bw=bw, bp=bp):
+                S2 = zeros(C, 4 * C)
+                cs = zeros(C)
+                ops.linear_wgrad(dx, s['hg'], S2, colsum_out=cs)
+                grads[bp + 'mlp.net.2.weight'] = bw['g2'][:, None] * S2
+                grads[bp + 'mlp.net.2.bias'] = bw['g2'] * cs
+                grads[bp + 'ls2.gamma'] = (bw['fc2_w32'] * S2).sum(1) + p[bp + 'mlp.net.2.bias'].detach().to(f32) * cs
+            side.run(fc2_wgrad_fn, dx, s['hg'])
             dn2w, dn2b = zeros(C), zeros(C)
-            dxmid = ops.layernorm_bwd(s['xmid'], bw['n2_w'], dv2, dx, dn2w, dn2b, g.eps)
+            fused = use_fused_mlp(dt, C)
+            if fused:       # fc2 dgrad * gp, fc1 dgrad and LayerNorm-2 backward (+ residual) in one kernel
+                dhd, dxmid = ops.mlp_bwd_dgrad(dx, s['hgp'], s['xmid'], bw['n2_w'], bw['fc2_wt'], bw['fc1_wt'], dn2w, dn2b,
+                                               g.eps)
+            else:
+                dhd = ops.linear_dgrad(dx, bw['fc2_wt'], mul=s['hgp'])
+            def fc1_wgrad_fn(dhd=dhd, s=s, bw=bw, bp=bp):
+                v2 = ops.layernorm_fwd(s['xmid'], bw['n2_w'], bw['n2_b'], g.eps)
+                dW1 = zeros(4 * C, C)
+                db1 = zeros(4 * C)
+                ops.linear_wgrad(dhd, v2, dW1, colsum_out=db1)
+                grads[bp + 'mlp.net.0.0.weight'] = dW1
+                grads[bp + 'mlp.net.0.0.bias'] = db1
+            side.run(fc1_wgrad_fn, dhd, s['xmid'])
+            if not fused:
+                dv2 = ops.linear_dgrad(dhd, bw['fc1_wt'])
+                dxmid = ops.layernorm_bwd(s['xmid'], bw['n2_w'], dv2, dx, dn2w, dn2b, g.eps)
+                del dv2
+            del dhd
             grads[bp + 'norm2.weight'] = dn2w
             grads[bp + 'norm2.bias'] = dn2b
-            del dv2
             # attention branch: xmid = xin + g1 * (a Wp^T + bp)
-            S1 = zeros(C, C)
-            cs1 = zeros(C)
-            ops.linear_wgrad(dxmid, s['a'], S1, colsum_out=cs1)
-            grads[bp + 'self_attn.proj.weight'] = bw['g1'][:, None] * S1
-            grads[bp + 'self_attn.proj.bias'] = bw['g1'] * cs1
-            grads[bp + 'ls1.gamma'] = (bw['proj_w32'] * S1).sum(1) + p[bp + 'self_attn.proj.bias'].detach().to(f32) * cs1
+            def proj_wgrad_fn(dxmid=dxmid, s=s, bw=bw, bp=bp):
+                S1 = zeros(C, C)
+                cs1 = zeros(C)
+                ops.linear_wgrad(dxmid, s['a'], S1, colsum_out=cs1)
+                grads[bp + 'self_attn.proj.weight'] = bw['g1'][:, None] * S1
+                grads[bp + 'self_attn.proj.bias'] = bw['g1'] * cs1
+                grads[bp + 'ls1.gamma'] = (bw['proj_w32'] * S1).sum(1) + p[bp + 'self_attn.proj.bias'].detach().to(f32) * cs1
+            side.run(proj_wgrad_fn, dxmid, s['a'])
             da = ops.linear_dgrad(dxmid, bw['proj_wt'])
             dqkv = ops.attn_bwd(s['qkv'], da, F_, H, W, C, g.dim_head, g.ph, g.pw, window)
             del da
-            u = s['xin'] if bw['n1_w'] is None else ops.layernorm_fwd(s['xin'], bw['n1_w'], bw['n1_b'], g.eps)
-            dWq = zeros(3 * C, C)
-            dbq = zeros(3 * C)
-            ops.linear_wgrad(dqkv, u, dWq, colsum_out=dbq)
-            grads[bp + 'self_attn.qkv.weight'] = dWq
-            grads[bp + 'self_attn.qkv.bias'] = dbq
+            def qkv_wgrad_fn(dqkv=dqkv, s=s, bw=bw, bp=bp):
+                u = s['xin'] if bw['n1_w'] is None else ops.layernorm_fwd(s['xin'], bw['n1_w'], bw['n1_b'], g.eps)
+                dWq = zeros(3 * C, C)
+                dbq = zeros(3 * C)
+                ops.linear_wgrad(dqkv, u, dWq, colsum_out=dbq)
+                grads[bp + 'self_attn.qkv.weight'] = dWq
+                grads[bp + 'self_attn.qkv.bias'] = dbq
+            side.run(qkv_wgrad_fn, dqkv, s['xin'])
             if bw['n1_w'] is None:
                 dx = ops.linear_dgrad(dqkv, bw['qkv_wt'], add=dxmid)
             else:
@@ -234,7 +298,7 @@ def stage_seq_backward(sw: StageWeights, g: StageGeom, sv: StageSaved, dH: Optio
                 grads[bp + 'norm1.weight'] = dn1w
                 grads[bp + 'norm1.bias'] = dn1b
                 del du
-            del dqkv, dxmid, u
+            del dqkv, dxmid
 
     # ---- token mask, down-sampling LayerNorm + conv ---------------------------------------------------------
     if sv.mask is not None:
@@ -245,10 +309,13 @@ def stage_seq_backward(sw: StageWeights, g: StageGeom, sv: StageSaved, dH: Optio
     dy0 = ops.layernorm_bwd(sv.y0, sw.ln_w, dx, None, dlw, dlb, g.eps)
     grads[pre + 'downsample_cf2cl.norm.weight'] = dlw
     grads[pre + 'downsample_cf2cl.norm.bias'] = dlb
-    dwc = zeros(C, g.k * g.k * sw.cin_pad)
-    ops.conv_wgrad(sv.inp, dy0, dwc, g.k, g.stride, g.pad)
-    grads[pre + 'downsample_cf2cl.conv.weight'] = unpack_conv_wgrad(dwc, g.Cin, g.k)
+    def conv_wgrad_fn():
+        dwc = zeros(C, g.k * g.k * sw.cin_pad)
+        ops.conv_wgrad(sv.inp, dy0, dwc, g.k, g.stride, g.pad)
+        grads[pre + 'downsample_cf2cl.conv.weight'] = unpack_conv_wgrad(dwc, g.Cin, g.k)
+    side.run(conv_wgrad_fn, sv.inp, dy0)
     d_in = None
     if need_input_grad:
         d_in = ops.conv_dgrad(dy0, sw.conv_wd, prev_cot, g.H_in, g.W_in, g.Cin, g.k, g.stride, g.pad)
+    side.join()                 # every parameter gradient of this stage is final from here on (DDP hook, optimizer)
     return d_in, dh0, dc0, grads
