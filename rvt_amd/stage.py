@@ -168,7 +168,8 @@ def stage_seq_forward(sw: StageWeights, g: StageGeom, inp: Tensor, h0: Optional[
 
 def stage_seq_backward(sw: StageWeights, g: StageGeom, sv: StageSaved, dH: Optional[Tensor], dc_last: Optional[Tensor],
                        T: int, B: int, need_input_grad: bool, prev_cot: Optional[Tensor],
-                       p: Dict[str, Tensor], pre: str) -> Tuple[Optional[Tensor], Tensor, Tensor, Dict[str, Tensor]]:
+                       p: Dict[str, Tensor], pre: str, side: Optional[SideStream] = None,
+                       join: bool = True) -> Tuple[Optional[Tensor], Tensor, Tensor, Dict[str, Tensor]]:
     """dH: (T,B,H,W,C) cotangent of Hall[1:] (None = zeros); dc_last: (B,H,W,C) fp32 cotangent of Call[T].
     prev_cot: cotangent already attached to this stage's INPUT frames (T*B,H_in,W_in,Cin) (added to the conv dgrad).
     Returns (d_input or None, dh0, dc0, {param name: fp32 grad})."""
@@ -200,7 +201,8 @@ def stage_seq_backward(sw: StageWeights, g: StageGeom, sv: StageSaved, dH: Optio
             ops.lstm_dgrad(dz[t], sw.lstm_wt, dx[t], dhc[t])
             ops.dwconv(dhc[t], wh, None, dws['k'], transpose=True, out=nxt)
         dh_rec = nxt
-    side = SideStream(dz)
+    if side is None:
+        side = SideStream(dz)
     h_seg = sv.Hall[:T].reshape(F_, H, W, C) if dws is None else sv.hconv.view(F_, H, W, C)
 
     def lstm_wgrad_fn():
@@ -317,5 +319,6 @@ def stage_seq_backward(sw: StageWeights, g: StageGeom, sv: StageSaved, dH: Optio
     d_in = None
     if need_input_grad:
         d_in = ops.conv_dgrad(dy0, sw.conv_wd, prev_cot, g.H_in, g.W_in, g.Cin, g.k, g.stride, g.pad)
-    side.join()                 # every parameter gradient of this stage is final from here on (DDP hook, optimizer)
+    if join:
+        side.join()             # every parameter gradient of this stage is final from here on (DDP hook, optimizer)
     return d_in, dh0, dc0, grads
