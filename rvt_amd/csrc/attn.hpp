@@ -79,16 +79,20 @@ template <class T> __device__ __forceinline__ frag_t<T> acc_slot_frag(const f32x
     return f;
 }
 
-// S^T column softmax for one query block; returns normalised P^T in s[][] (fp32)
+// S^T column softmax for one query block.  In: raw scores s[bj][r] (keys down the registers, this lane's query).
+// Out: p[bj][r] = exp(scale*(s - max)) (UN-normalised, plain VGPR array so the accumulator registers are only read)
+// and the column's 1/sum.  Padded keys (j >= L) only exist in the last 32-key block: they get an additive -1e30
+// (kmask[r], built once per kernel) instead of per-element selects; exp2 with scale*log2(e) folded into one multiply.
 template <int NB>
-__device__ __forceinline__ void softmax_cols(f32x16 (&s)[NB], int lane, int L, float scale) {
+__device__ __forceinline__ float softmax_cols(const f32x16 (&s)[NB], float (&p)[NB][16], const float (&kmask)[16], float scale_log2e) {
     float mx = -3.0e38f;
 #pragma unroll
     for (int bj = 0; bj < NB; bj++)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            int j = 32 * bj + acc_row(r, lane);
-            if (j < L) mx = fmaxf(mx, s[bj][r]);
+            const float v = bj == NB - 1 ? s[bj][r] + kmask[r] : s[bj][r];
+            p[bj][r] = v;
+            mx = fmaxf(mx, v);
         }
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     float sum = 0.f;
@@ -96,17 +100,25 @@ __device__ __forceinline__ void softmax_cols(f32x16 (&s)[NB], int lane, int L, f
     for (int bj = 0; bj < NB; bj++)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            int j = 32 * bj + acc_row(r, lane);
-            float p = (j < L) ? __expf((s[bj][r] - mx) * scale) : 0.f;
-            s[bj][r] = p;
-            sum += p;
+            const float e = fast_exp2((p[bj][r] - mx) * scale_log2e);
+            p[bj][r] = e;
+            sum += e;
         }
     sum += __shfl_xor(sum, 32);
-    const float inv = 1.0f / sum;
+    return 1.0f / sum;
+}
+
+template <class T> __device__ __forceinline__ frag_t<T> arr_slot_frag(const float (&a)[16], int q) {
+    frag_t<T> f;
 #pragma unroll
-    for (int bj = 0; bj < NB; bj++)
+    for (int e = 0; e < 8; e++) f[e] = (T)a[8 * q + e];
+    return f;
+}
+
+// additive key mask of the LAST key block for this lane's accumulator rows
+template <int NB> __device__ __forceinline__ void make_kmask(float (&kmask)[16], int lane, int L) {
 #pragma unroll
-        for (int r = 0; r < 16; r++) s[bj][r] *= inv;
+    for (int r = 0; r < 16; r++) kmask[r] = (32 * (NB - 1) + acc_row(r, lane) < L) ? 0.f : -1.0e30f;
 }
 
 template <class T, int NB>
@@ -128,6 +140,9 @@ attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, AttnGeom g) {
         valid[b] = l < g.L;
         tok[b] = attn_token(g, (int)f, (int)p, valid[b] ? l : 0);
     }
+    float kmask[16];
+    make_kmask<NB>(kmask, lane, g.L);
+    const float scale_log2e = g.scale * 1.4426950408889634f;
     // V^T -> LDS (zeros for padded keys so that 0 * garbage can never appear)
 #pragma unroll
     for (int b = 0; b < NB; b++)
@@ -156,19 +171,20 @@ attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, AttnGeom g) {
                 }
             }
         }
-        softmax_cols<NB>(s, lane, g.L, g.scale);
+        float pr[NB][16];
+        const float inv = softmax_cols<NB>(s, pr, kmask, scale_log2e);
         f32x16 o; acc_zero(o);
 #pragma unroll
         for (int bj = 0; bj < NB; bj++)
 #pragma unroll
             for (int q = 0; q < 2; q++)
-                mma32(o, load_slot_frag<T>(Vt, PITCH, li, half, bj, q), acc_slot_frag<T>(s[bj], q));
-        if (valid[bi]) {
+                mma32(o, load_slot_frag<T>(Vt, PITCH, li, half, bj, q), arr_slot_frag<T>(pr[bj], q));
+        if (valid[bi]) {       // normalise the 16 outputs instead of the 32*NB probabilities
             T* orow = out + (size_t)tok[bi] * g.C + head * dh;
 #pragma unroll
             for (int gq = 0; gq < 4; gq++) {
                 int d0 = 8 * gq + 4 * half;
-                if (d0 < dh) store4<T>(orow + d0, o[4 * gq], o[4 * gq + 1], o[4 * gq + 2], o[4 * gq + 3]);
+                if (d0 < dh) store4<T>(orow + d0, o[4 * gq] * inv, o[4 * gq + 1] * inv, o[4 * gq + 2] * inv, o[4 * gq + 3] * inv);
             }
         }
     }
@@ -196,6 +212,9 @@ attn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ dout, T* __rest
         valid[b] = l < g.L;
         tok[b] = attn_token(g, (int)f, (int)p, valid[b] ? l : 0);
     }
+    float kmask[16];
+    make_kmask<NB>(kmask, lane, g.L);
+    const float scale_log2e = g.scale * 1.4426950408889634f;
 #pragma unroll
     for (int b = 0; b < NB; b++)
 #pragma unroll
@@ -232,23 +251,25 @@ attn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ dout, T* __rest
                 }
             }
         }
-        softmax_cols<NB>(s, lane, g.L, g.scale);
+        float pr[NB][16];
+        const float inv = softmax_cols<NB>(s, pr, kmask, scale_log2e);
         float delta = 0.f;
 #pragma unroll
         for (int bj = 0; bj < NB; bj++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) delta += s[bj][r] * dp[bj][r];
+            for (int r = 0; r < 16; r++) { pr[bj][r] *= inv; delta += pr[bj][r] * dp[bj][r]; }
         delta += __shfl_xor(delta, 32);
         // P^T -> LDS [key][query-in-block] for dV
 #pragma unroll
         for (int bj = 0; bj < NB; bj++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) PS[(32 * bj + acc_row(r, lane)) * PSP + li] = (T)s[bj][r];
+            for (int r = 0; r < 16; r++) PS[(32 * bj + acc_row(r, lane)) * PSP + li] = (T)pr[bj][r];
         // dS^T (keeps the softmax scale so that dQ and dK need no further factor)
+        float ds[NB][16];
 #pragma unroll
         for (int bj = 0; bj < NB; bj++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) dp[bj][r] = s[bj][r] * (dp[bj][r] - delta) * g.scale;
+            for (int r = 0; r < 16; r++) ds[bj][r] = pr[bj][r] * (dp[bj][r] - delta) * g.scale;
         __syncthreads();
 #pragma unroll
         for (int bj = 0; bj < NB; bj++)
@@ -262,7 +283,7 @@ attn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ dout, T* __rest
 #pragma unroll
         for (int bj = 0; bj < NB; bj++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) PS[(32 * bj + acc_row(r, lane)) * PSP + li] = (T)dp[bj][r];
+            for (int r = 0; r < 16; r++) PS[(32 * bj + acc_row(r, lane)) * PSP + li] = (T)ds[bj][r];
         __syncthreads();
 #pragma unroll
         for (int bj = 0; bj < NB; bj++)
@@ -278,7 +299,7 @@ attn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ dout, T* __rest
         for (int bj = 0; bj < NB; bj++)
 #pragma unroll
             for (int q = 0; q < 2; q++)
-                mma32(dq, load_slot_frag<T>(Kt, PITCH, li, half, bj, q), acc_slot_frag<T>(dp[bj], q));
+                mma32(dq, load_slot_frag<T>(Kt, PITCH, li, half, bj, q), arr_slot_frag<T>(ds[bj], q));
         if (valid[bi]) {
             T* qrow = dqkv + (size_t)tok[bi] * C3 + qoff;
 #pragma unroll

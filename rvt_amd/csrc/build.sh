@@ -4,5 +4,5 @@ set -e
 cd "$(dirname "$0")"
 OUT=../librvt_hip.so
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-result \
-    -ffp-contract=off capi.hip -o "$OUT" "$@"
+    -ffp-contract=off -fno-honor-nans capi.hip -o "$OUT" "$@"
 echo "built $(realpath $OUT)"

@@ -142,6 +142,14 @@ __device__ __forceinline__ void sched_fence() {
 #endif
 }
 
+__device__ __forceinline__ float fast_exp2(float x) {
+#ifdef RVT_EMU
+    return exp2f(x);
+#else
+    return __builtin_amdgcn_exp2f(x);       // v_exp_f32
+#endif
+}
+
 // ---- scalar math -------------------------------------------------------------------------------
 __device__ __forceinline__ float fast_rcp(float x) {
 #ifdef RVT_EMU
