@@ -330,7 +330,8 @@ int rvt_mlp_fused_supported(int dtype, int C) {
 static int mlp_grid(int dtype, int C, int M) {
     static const int resident_override = getenv("RVT_GEMM_RESIDENT") ? atoi(getenv("RVT_GEMM_RESIDENT")) : 0;
     const int n_tiles = (M + 127) / 128;
-    return imax(1, imin(n_tiles, resident_override > 0 ? resident_override : 256));     // ~97-129 KiB LDS: one per CU
+    const int per_cu = (dtype == RVT_BF16 && C == 64) ? 2 : 1;                          // 57 KiB LDS at bf16 C=64
+    return imax(1, imin(n_tiles, resident_override > 0 ? resident_override : 256 * per_cu));
 }
 
 int rvt_mlp_fwd(const void* xmid, void* xout, void* g_out, void* gp_out, const float* ln_w, const float* ln_b,

@@ -87,7 +87,7 @@ __device__ __forceinline__ void stage_read8(const float* stage, int ld, int srow
     }
 }
 
-template <class T> struct MlpGeom { static constexpr int JC = sizeof(T) == 2 ? 128 : 64; };
+template <class T> struct MlpGeom { static constexpr int JC = 64; };   // 64-column hidden chunks: ~57 KiB LDS at C=64 -> two workgroups per CU
 
 template <class T, int C> struct MlpSmem {
     static constexpr int JC = MlpGeom<T>::JC;
@@ -112,7 +112,7 @@ template <class T, int C> struct TileSlots {
 
 // ===================================================================================================== forward
 template <class T, int C>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 mlp_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, T* __restrict__ g_out, T* __restrict__ gp_out,
                const float* __restrict__ ln_w, const float* __restrict__ ln_b, const T* __restrict__ W1,
                const float* __restrict__ b1, const T* __restrict__ W2, const float* __restrict__ b2,
@@ -231,7 +231,7 @@ mlp_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, T* __restrict__
 // dv2[m][C]   = dh W1                                      W1^T stored [C][4C]                    ("fc1_wt")
 // dxmid       = dxout + LN2'(dv2; xmid)                    dln_w += dv2 * xhat, dln_b += dv2
 template <class T, int C>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 mlp_bwd_dgrad_kernel(const T* __restrict__ dxout, const T* __restrict__ gp, const T* __restrict__ xmid, T* __restrict__ dh,
                      T* __restrict__ dxmid, const float* __restrict__ ln_w, const T* __restrict__ W2gT,
                      const T* __restrict__ W1T, float* __restrict__ dln_w, float* __restrict__ dln_b, int M, float eps) {

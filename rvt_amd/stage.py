@@ -24,13 +24,18 @@ from . import ops
 from .weights import StageWeights, unpack_conv_wgrad
 
 
-def use_fused_mlp(dtype, C: int) -> bool:
-    """Opt-in (RVT_FUSED_MLP=1): route the MLP half of the blocks through the fused kernels of csrc/mlp.hpp where they
-    are built (C in {64,128}).  Off by default: on MI355X they are still slower than the op-by-op chain (one workgroup
-    per CU, un-pipelined phases — see DESIGN.md §5), so the measured default stays the chain."""
-    return os.environ.get('RVT_FUSED_MLP', '0') == '1' and ops.mlp_fused_supported(dtype, C)
-
-Tensor = torch.Tensor
+def use_fused_mlp(dtype, C: int, what: str) -> bool:
+    """Which MLP halves go through the fused kernels of csrc/mlp.hpp (built for C in {64,128}).
+    Default = where they measured faster than the op-by-op chain on MI355X (profiles/microbench_mlp.py, bf16):
+      C=64 : backward dgrad chain 3.2 vs 4.5 ms, inference forward 3.3 vs 4.3 ms, training forward 4.4 vs 4.3 ms (chain kept)
+      C=128: slower everywhere (one workgroup per CU; needs the 64-token tile variant) -> chain.
+    RVT_FUSED_MLP=1 forces every supported case (used by the parity tests), =0 disables all."""
+    mode = os.environ.get('RVT_FUSED_MLP', 'auto')
+    if mode == '0' or not ops.mlp_fused_supported(dtype, C):
+        return False
+    if mode == '1':
+        return True
+    return C == 64 and what in ('bwd', 'fwd_infer')
 
 
 class SideStream:
@@ -122,7 +127,7 @@ def stage_seq_forward(sw: StageWeights, g: StageGeom, inp: Tensor, h0: Optional[
             qkv = ops.linear_fwd(u, bw['qkv_w'], bw['qkv_b'])                     # maxvit.py:347
             a = ops.attn_fwd(qkv, F_, H, W, C, g.dim_head, g.ph, g.pw, window)    # maxvit.py:349-352
             xmid = ops.linear_scale_res_fwd(a, bw['proj_w'], bw['proj_b'], bw['g1'], x)        # :353, :268
-            if use_fused_mlp(dt, C):
+            if use_fused_mlp(dt, C, 'fwd_train' if save else 'fwd_infer'):
                 xout, hg, hgp = ops.mlp_fwd(xmid, bw['n2_w'], bw['n2_b'], bw['fc1_w'], bw['fc1_b'], bw['fc2_w'],
                                             bw['fc2_b'], bw['g2'], g.eps, want_grad=save)
             else:
@@ -250,7 +255,7 @@ def stage_seq_backward(sw: StageWeights, g: StageGeom, sv: StageSaved, dH: Optio
                 grads[bp + 'ls2.gamma'] = (bw['fc2_w32'] * S2).sum(1) + p[bp + 'mlp.net.2.bias'].detach().to(f32) * cs
             side.run(fc2_wgrad_fn, dx, s['hg'])
             dn2w, dn2b = zeros(C), zeros(C)
-            fused = use_fused_mlp(dt, C)
+            fused = use_fused_mlp(dt, C, 'bwd')
             if fused:       # fc2 dgrad * gp, fc1 dgrad and LayerNorm-2 backward (+ residual) in one kernel
                 dhd, dxmid = ops.mlp_bwd_dgrad(dx, s['hgp'], s['xmid'], bw['n2_w'], bw['fc2_wt'], bw['fc1_wt'], dn2w, dn2b,
                                                g.eps)
