@@ -327,10 +327,16 @@ int rvt_mlp_fused_supported(int dtype, int C) {
     return 0;
 }
 
-static int mlp_grid(int dtype, int C, int M) {
+// tile height and resident workgroups per CU of the fused MLP kernels (LDS: ~41 KiB at bf16 C=64 TM=64, ~57 KiB at C=128)
+static int mlp_tm(int dtype, int C) {
+    static const int tm_override = getenv("RVT_MLP_TM") ? atoi(getenv("RVT_MLP_TM")) : 0;     // tuning knob (bf16 C=64 only)
+    if (dtype == RVT_BF16 && C == 64 && tm_override == 128) return 128;
+    return 64;
+}
+static int mlp_grid(int dtype, int C, int M, int tm) {
     static const int resident_override = getenv("RVT_GEMM_RESIDENT") ? atoi(getenv("RVT_GEMM_RESIDENT")) : 0;
-    const int n_tiles = (M + 127) / 128;
-    const int per_cu = (dtype == RVT_BF16 && C == 64) ? 2 : 1;                          // 57 KiB LDS at bf16 C=64
+    const int n_tiles = (M + tm - 1) / tm;
+    const int per_cu = dtype == RVT_BF16 ? (C == 64 && tm == 64 ? 3 : 2) : 2;
     return imax(1, imin(n_tiles, resident_override > 0 ? resident_override : 256 * per_cu));
 }
 
@@ -340,13 +346,15 @@ int rvt_mlp_fwd(const void* xmid, void* xout, void* g_out, void* gp_out, const f
     RVT_CHECK(rvt_mlp_fused_supported(dtype, C), "mlp_fwd: fused MLP not built for dtype=%d C=%d", dtype, C);
     RVT_CHECK((g_out == nullptr) == (gp_out == nullptr), "mlp_fwd: g_out and gp_out go together");
     hipStream_t st = (hipStream_t)stream;
-    const int grid = mlp_grid(dtype, C, M);
-#define RVT_MLP_FWD(TT, CC)                                                                                           \
-    hipLaunchKernelGGL((mlp_fwd_kernel<TT, CC>), dim3(grid), dim3(256), 0, st, (const TT*)xmid, (TT*)xout, (TT*)g_out, \
+    const int tm = mlp_tm(dtype, C);
+    const int grid = mlp_grid(dtype, C, M, tm);
+#define RVT_MLP_FWD(TT, CC, TMM)                                                                                           \
+    hipLaunchKernelGGL((mlp_fwd_kernel<TT, CC, TMM>), dim3(grid), dim3(256), 0, st, (const TT*)xmid, (TT*)xout, (TT*)g_out, \
                        (TT*)gp_out, ln_w, ln_b, (const TT*)w1, b1, (const TT*)w2, b2, gamma, M, eps)
-    if (dtype == RVT_BF16 && C == 64) RVT_MLP_FWD(bf16, 64);
-    else if (dtype == RVT_BF16 && C == 128) RVT_MLP_FWD(bf16, 128);
-    else RVT_MLP_FWD(float, 64);
+    if (dtype == RVT_BF16 && C == 64 && tm == 128) RVT_MLP_FWD(bf16, 64, 128);
+    else if (dtype == RVT_BF16 && C == 64) RVT_MLP_FWD(bf16, 64, 64);
+    else if (dtype == RVT_BF16 && C == 128) RVT_MLP_FWD(bf16, 128, 64);
+    else RVT_MLP_FWD(float, 64, 64);
 #undef RVT_MLP_FWD
     return check_launch("mlp_fwd");
 }
@@ -356,13 +364,15 @@ int rvt_mlp_bwd_dgrad(const void* dxout, const void* gp, const void* xmid, void*
                       void* stream) {
     RVT_CHECK(rvt_mlp_fused_supported(dtype, C), "mlp_bwd_dgrad: fused MLP not built for dtype=%d C=%d", dtype, C);
     hipStream_t st = (hipStream_t)stream;
-    const int grid = mlp_grid(dtype, C, M);
-#define RVT_MLP_BWD(TT, CC)                                                                                            \
-    hipLaunchKernelGGL((mlp_bwd_dgrad_kernel<TT, CC>), dim3(grid), dim3(256), 0, st, (const TT*)dxout, (const TT*)gp,     \
+    const int tm = mlp_tm(dtype, C);
+    const int grid = mlp_grid(dtype, C, M, tm);
+#define RVT_MLP_BWD(TT, CC, TMM)                                                                                          \
+    hipLaunchKernelGGL((mlp_bwd_dgrad_kernel<TT, CC, TMM>), dim3(grid), dim3(256), 0, st, (const TT*)dxout, (const TT*)gp,   \
                        (const TT*)xmid, (TT*)dh, (TT*)dxmid, ln_w, (const TT*)w2g_t, (const TT*)w1_t, dln_w, dln_b, M, eps)
-    if (dtype == RVT_BF16 && C == 64) RVT_MLP_BWD(bf16, 64);
-    else if (dtype == RVT_BF16 && C == 128) RVT_MLP_BWD(bf16, 128);
-    else RVT_MLP_BWD(float, 64);
+    if (dtype == RVT_BF16 && C == 64 && tm == 128) RVT_MLP_BWD(bf16, 64, 128);
+    else if (dtype == RVT_BF16 && C == 64) RVT_MLP_BWD(bf16, 64, 64);
+    else if (dtype == RVT_BF16 && C == 128) RVT_MLP_BWD(bf16, 128, 64);
+    else RVT_MLP_BWD(float, 64, 64);
 #undef RVT_MLP_BWD
     return check_launch("mlp_bwd_dgrad");
 }

@@ -68,17 +68,19 @@ __device__ __forceinline__ void opm_mma(f32x16 (&acc)[MI][NJ], const char* A, in
     }
 }
 
-// one 64-row pass of a 2x2-wave accumulator (wave tile 64 x 32*NJ) into fp32 staging [64][ld]:
-// MFMA row block i of every wave: stage row wm*32+r  <->  tile row wm*64+i*32+r
-template <int NJ>
-__device__ __forceinline__ void stage_pass(float* stage, int ld, const f32x16 (&acc)[2][NJ], int i, int wm, int wn, int lane) {
+// one 64-row pass of a 2x2-wave accumulator (wave tile 32*MI x 32*NJ) into fp32 staging [64][ld]:
+// MFMA row block i of every wave: stage row wm*32+r  <->  tile row wm*32*MI+i*32+r
+template <int MI, int NJ>
+__device__ __forceinline__ void stage_pass(float* stage, int ld, const f32x16 (&acc)[MI][NJ], int i, int wm, int wn, int lane) {
 #pragma unroll
     for (int j = 0; j < NJ; j++)
 #pragma unroll
         for (int r = 0; r < 16; r++)
             stage[(wm * 32 + acc_row(r, lane)) * ld + wn * (32 * NJ) + j * 32 + (lane & 31)] = acc[i][j][r];
 }
-__device__ __forceinline__ int stage_row_to_tile_row(int srow, int pass) { return (srow >> 5) * 64 + pass * 32 + (srow & 31); }
+template <int MI> __device__ __forceinline__ int stage_row_to_tile_row(int srow, int pass) {
+    return (srow >> 5) * (32 * MI) + pass * 32 + (srow & 31);
+}
 __device__ __forceinline__ void stage_read8(const float* stage, int ld, int srow, int col0, float (&v)[8]) {
 #pragma unroll
     for (int h = 0; h < 2; h++) {
@@ -89,37 +91,42 @@ __device__ __forceinline__ void stage_read8(const float* stage, int ld, int srow
 
 template <class T> struct MlpGeom { static constexpr int JC = 64; };   // 64-column hidden chunks: ~57 KiB LDS at C=64 -> two workgroups per CU
 
-template <class T, int C> struct MlpSmem {
+// TM = tokens per tile (64 or 128): 4 waves as 2x2, each wave TM/2 = 32*MI token rows.
+template <class T, int C, int TM> struct MlpSmem {
     static constexpr int JC = MlpGeom<T>::JC;
     static constexpr int KT_C = C / TileGeom<T>::BK, KT_J = JC / TileGeom<T>::BK;
-    static constexpr int A_X = KT_C * 128 * 128;                       // [128 tokens][C]   (v2 in fwd, dxout in bwd)
+    static constexpr int A_X = KT_C * TM * 128;                        // [TM tokens][C]    (v2 in fwd, dxout in bwd)
     static constexpr int B_1 = KT_C * JC * 128;                        // [JC][C]           (W1_j / (W2 gamma)^T_j)
-    static constexpr int STG_A = 64 * (JC + 4) * 4, STG_B = 64 * (C + 4) * 4;
-    static constexpr int STG = STG_A > STG_B ? STG_A : STG_B;          // fp32 staging, overlays B_1 (+ pad)
-    static constexpr int R1 = B_1 > STG ? B_1 : STG;
-    static constexpr int A_H = KT_J * 128 * 128;                       // [128 tokens][JC]  (g in fwd, dh in bwd)
+    static constexpr int STG_A = 64 * (JC + 4) * 4;                    // per-chunk fp32 staging, overlays B_1
+    static constexpr int STG_B = 64 * (C + 4) * 4;                     // final staging: may run on into A_H / B_2 (dead by then)
+    static constexpr int R1 = B_1 > STG_A ? B_1 : STG_A;
+    static constexpr int A_H = KT_J * TM * 128;                        // [TM tokens][JC]   (g in fwd, dh in bwd)
     static constexpr int B_2 = KT_J * C * 128;                         // [C][JC]           (W2[:, j] / W1^T[:, j])
     static constexpr int OFF_1 = A_X, OFF_H = OFF_1 + R1, OFF_2 = OFF_H + A_H;
     static constexpr int BYTES = OFF_2 + B_2;
     static_assert(BYTES <= 160 * 1024, "fused MLP tile does not fit the LDS");
+    static_assert(STG_B <= BYTES - OFF_1, "final staging does not fit behind the input tile");
+    static_assert(256 * 16 * 4 <= BYTES, "reduction scratch");
 };
 
-// (row, 8-channel chunk) thread layout of a [128][C] tile: slot q of thread tid is frag f = tid + 256 q, row f/G, chunk f%G
-template <class T, int C> struct TileSlots {
+// (row, 8-channel chunk) thread layout of a [TM][C] tile: slot q of thread tid is frag f = tid + 256 q, row f/G, chunk f%G
+template <class T, int C, int TM> struct TileSlots {
     static constexpr int G = C / 8;
-    static constexpr int NFX = 128 * G / 256;
+    static constexpr int NFX = TM * G / 256;
+    static_assert(NFX >= 1, "tile too small for 256 threads");
 };
 
 // ===================================================================================================== forward
-template <class T, int C>
+template <class T, int C, int TM>
 __global__ void __launch_bounds__(256, 2)
 mlp_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, T* __restrict__ g_out, T* __restrict__ gp_out,
                const float* __restrict__ ln_w, const float* __restrict__ ln_b, const T* __restrict__ W1,
                const float* __restrict__ b1, const T* __restrict__ W2, const float* __restrict__ b2,
                const float* __restrict__ gamma, int M, float eps) {
-    typedef MlpSmem<T, C> S;
+    typedef MlpSmem<T, C, TM> S;
+    constexpr int MI = TM / 64;
     constexpr int JC = S::JC, HID = 4 * C;
-    constexpr int G = TileSlots<T, C>::G, NFX = TileSlots<T, C>::NFX;
+    constexpr int G = TileSlots<T, C, TM>::G, NFX = TileSlots<T, C, TM>::NFX;
     constexpr int NJ1 = JC / 64, NJ2 = C / 64;
     constexpr int LD1 = JC + 4, LD2 = C + 4;
     constexpr int UPR1 = JC / 8;                           // 8-column units per staged row (fc1 side)
@@ -132,10 +139,10 @@ mlp_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, T* __restrict__
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int n_tiles = (M + 127) / 128;
+    const int n_tiles = (M + TM - 1) / TM;
 
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int m0 = tile * 128;
+        const int m0 = tile * TM;
         // ---- load + LayerNorm (maxvit.py:241) ----
         frag_t<T> raw[NFX];
 #pragma unroll
@@ -156,12 +163,12 @@ mlp_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, T* __restrict__
             float o[8];
 #pragma unroll
             for (int e = 0; e < 8; e++) o[e] = ok ? (v[e] - mean) * rstd * ln_w[cl * 8 + e] + ln_b[cl * 8 + e] : 0.f;
-            opm_store_frag<T>(Ax, 128, row, cl, frag_from_float<T>(o));
+            opm_store_frag<T>(Ax, TM, row, cl, frag_from_float<T>(o));
         }
 
-        f32x16 acc2[2][NJ2];
+        f32x16 acc2[MI][NJ2];
 #pragma unroll
-        for (int i = 0; i < 2; i++)
+        for (int i = 0; i < MI; i++)
 #pragma unroll
             for (int j = 0; j < NJ2; j++) acc_zero(acc2[i][j]);
 
@@ -169,27 +176,27 @@ mlp_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, T* __restrict__
             opm_stage<T>(B1, W1 + (size_t)j0 * C, C, JC, C, tid);               // W1 rows j0.., all C columns
             opm_stage<T>(B2, W2 + j0, HID, C, JC, tid);                         // W2[:, j0..j0+JC)
             __syncthreads();
-            f32x16 acc1[2][NJ1];
+            f32x16 acc1[MI][NJ1];
 #pragma unroll
-            for (int i = 0; i < 2; i++)
+            for (int i = 0; i < MI; i++)
 #pragma unroll
                 for (int j = 0; j < NJ1; j++) acc_zero(acc1[i][j]);
-            opm_mma<T, 2, NJ1>(acc1, Ax, 128, wm * 64, B1, JC, wn * (JC / 2), C, lane);
+            opm_mma<T, MI, NJ1>(acc1, Ax, TM, wm * 32 * MI, B1, JC, wn * (JC / 2), C, lane);
             __syncthreads();                                                     // B1 consumed -> staging may overlay it
 #pragma unroll
-            for (int i = 0; i < 2; i++) {
+            for (int i = 0; i < MI; i++) {
                 if (i) __syncthreads();
-                stage_pass<NJ1>(stage, LD1, acc1, i, wm, wn, lane);
+                stage_pass<MI, NJ1>(stage, LD1, acc1, i, wm, wn, lane);
                 __syncthreads();
                 for (int u = tid; u < 64 * UPR1; u += 256) {
                     const int srow = u / UPR1, cu = u % UPR1;
-                    const int row = stage_row_to_tile_row(srow, i);
+                    const int row = stage_row_to_tile_row<MI>(srow, i);
                     float v[8], a[8], b[8];
                     stage_read8(stage, LD1, srow, cu * 8, v);
 #pragma unroll
                     for (int e = 0; e < 8; e++) gelu_both_f(v[e] + b1[j0 + cu * 8 + e], a[e], b[e]);
                     const frag_t<T> gf = frag_from_float<T>(a);
-                    opm_store_frag<T>(Ah, 128, row, cu, gf);
+                    opm_store_frag<T>(Ah, TM, row, cu, gf);
                     if (g_out != nullptr && m0 + row < M) {
                         const size_t o = (size_t)(m0 + row) * HID + j0 + cu * 8;
                         frag_store<T>(g_out + o, gf);
@@ -198,24 +205,24 @@ mlp_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, T* __restrict__
                 }
             }
             __syncthreads();
-            opm_mma<T, 2, NJ2>(acc2, Ah, 128, wm * 64, B2, C, wn * (C / 2), JC, lane);
+            opm_mma<T, MI, NJ2>(acc2, Ah, TM, wm * 32 * MI, B2, C, wn * (C / 2), JC, lane);
             __syncthreads();                                                     // Ah / B2 / staging free for the next chunk
         }
 
         // ---- LayerScale + residual (maxvit.py:51-53,269) in the load layout: the residual is still in registers ----
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < MI; i++) {
             if (i) __syncthreads();
-            stage_pass<NJ2>(stage, LD2, acc2, i, wm, wn, lane);
+            stage_pass<MI, NJ2>(stage, LD2, acc2, i, wm, wn, lane);
             __syncthreads();
 #pragma unroll
             for (int q = 0; q < NFX; q++) {
                 const int f = tid + q * 256, row = f / G, cl = f % G;
-                if (((row >> 5) & 1) != i) continue;
+                if (((row >> 5) % MI) != i) continue;
                 if (m0 + row < M) {
                     float v[8], res[8];
                     frag_to_float<T>(raw[q], res);
-                    stage_read8(stage, LD2, (row >> 6) * 32 + (row & 31), cl * 8, v);
+                    stage_read8(stage, LD2, (row / (32 * MI)) * 32 + (row & 31), cl * 8, v);
 #pragma unroll
                     for (int e = 0; e < 8; e++) v[e] = res[e] + gamma[cl * 8 + e] * (v[e] + b2[cl * 8 + e]);
                     frag_store<T>(xout + (size_t)(m0 + row) * C + cl * 8, frag_from_float<T>(v));
@@ -230,14 +237,15 @@ mlp_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, T* __restrict__
 // dh[m][4C]   = (dxout W2g)[m][:] * gp[m][:]              W2g^T = (W2 * gamma)^T stored [4C][C]  ("fc2_wt")
 // dv2[m][C]   = dh W1                                      W1^T stored [C][4C]                    ("fc1_wt")
 // dxmid       = dxout + LN2'(dv2; xmid)                    dln_w += dv2 * xhat, dln_b += dv2
-template <class T, int C>
+template <class T, int C, int TM>
 __global__ void __launch_bounds__(256, 2)
 mlp_bwd_dgrad_kernel(const T* __restrict__ dxout, const T* __restrict__ gp, const T* __restrict__ xmid, T* __restrict__ dh,
                      T* __restrict__ dxmid, const float* __restrict__ ln_w, const T* __restrict__ W2gT,
                      const T* __restrict__ W1T, float* __restrict__ dln_w, float* __restrict__ dln_b, int M, float eps) {
-    typedef MlpSmem<T, C> S;
+    typedef MlpSmem<T, C, TM> S;
+    constexpr int MI = TM / 64;
     constexpr int JC = S::JC, HID = 4 * C;
-    constexpr int G = TileSlots<T, C>::G, NFX = TileSlots<T, C>::NFX;
+    constexpr int G = TileSlots<T, C, TM>::G, NFX = TileSlots<T, C, TM>::NFX;
     constexpr int NJ1 = JC / 64, NJ2 = C / 64;
     constexpr int LD1 = JC + 4, LD2 = C + 4;
     constexpr int UPR1 = JC / 8;
@@ -250,14 +258,14 @@ mlp_bwd_dgrad_kernel(const T* __restrict__ dxout, const T* __restrict__ gp, cons
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int n_tiles = (M + 127) / 128;
+    const int n_tiles = (M + TM - 1) / TM;
     const int cl_own = tid % G;                             // every slot of this thread has the same channel chunk
     float aw[8], ab[8];
 #pragma unroll
     for (int e = 0; e < 8; e++) { aw[e] = 0.f; ab[e] = 0.f; }
 
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int m0 = tile * 128;
+        const int m0 = tile * TM;
         frag_t<T> rawdx[NFX], rawx[NFX];
         float mean[NFX], rstd[NFX];
 #pragma unroll
@@ -268,7 +276,7 @@ mlp_bwd_dgrad_kernel(const T* __restrict__ dxout, const T* __restrict__ gp, cons
             rawdx[q] = frag_load<T>(dxout + o);
             rawx[q] = frag_load<T>(xmid + o);
             const frag_t<T> z = frag_zero<T>();
-            opm_store_frag<T>(Ax, 128, row, cl, ok ? rawdx[q] : z);
+            opm_store_frag<T>(Ax, TM, row, cl, ok ? rawdx[q] : z);
             float v[8];
             frag_to_float<T>(rawx[q], v);
             float s = 0.f;
@@ -281,9 +289,9 @@ mlp_bwd_dgrad_kernel(const T* __restrict__ dxout, const T* __restrict__ gp, cons
             rstd[q] = 1.0f / sqrtf(group_sum(qq, G) / (float)C + eps);
         }
 
-        f32x16 acc2[2][NJ2];
+        f32x16 acc2[MI][NJ2];
 #pragma unroll
-        for (int i = 0; i < 2; i++)
+        for (int i = 0; i < MI; i++)
 #pragma unroll
             for (int j = 0; j < NJ2; j++) acc_zero(acc2[i][j]);
 
@@ -291,21 +299,21 @@ mlp_bwd_dgrad_kernel(const T* __restrict__ dxout, const T* __restrict__ gp, cons
             opm_stage<T>(B1, W2gT + (size_t)j0 * C, C, JC, C, tid);             // rows j0.. of (W2 gamma)^T
             opm_stage<T>(B2, W1T + j0, HID, C, JC, tid);                        // W1^T[:, j0..j0+JC)
             __syncthreads();
-            f32x16 acc1[2][NJ1];
+            f32x16 acc1[MI][NJ1];
 #pragma unroll
-            for (int i = 0; i < 2; i++)
+            for (int i = 0; i < MI; i++)
 #pragma unroll
                 for (int j = 0; j < NJ1; j++) acc_zero(acc1[i][j]);
-            opm_mma<T, 2, NJ1>(acc1, Ax, 128, wm * 64, B1, JC, wn * (JC / 2), C, lane);
+            opm_mma<T, MI, NJ1>(acc1, Ax, TM, wm * 32 * MI, B1, JC, wn * (JC / 2), C, lane);
             __syncthreads();
 #pragma unroll
-            for (int i = 0; i < 2; i++) {
+            for (int i = 0; i < MI; i++) {
                 if (i) __syncthreads();
-                stage_pass<NJ1>(stage, LD1, acc1, i, wm, wn, lane);
+                stage_pass<MI, NJ1>(stage, LD1, acc1, i, wm, wn, lane);
                 __syncthreads();
                 for (int u = tid; u < 64 * UPR1; u += 256) {
                     const int srow = u / UPR1, cu = u % UPR1;
-                    const int row = stage_row_to_tile_row(srow, i);
+                    const int row = stage_row_to_tile_row<MI>(srow, i);
                     const bool ok = m0 + row < M;
                     const size_t o = (size_t)(ok ? m0 + row : 0) * HID + j0 + cu * 8;
                     float v[8], p[8];
@@ -314,28 +322,28 @@ mlp_bwd_dgrad_kernel(const T* __restrict__ dxout, const T* __restrict__ gp, cons
 #pragma unroll
                     for (int e = 0; e < 8; e++) v[e] = ok ? v[e] * p[e] : 0.f;
                     const frag_t<T> df = frag_from_float<T>(v);
-                    opm_store_frag<T>(Ah, 128, row, cu, df);
+                    opm_store_frag<T>(Ah, TM, row, cu, df);
                     if (ok) frag_store<T>(dh + o, df);
                 }
             }
             __syncthreads();
-            opm_mma<T, 2, NJ2>(acc2, Ah, 128, wm * 64, B2, C, wn * (C / 2), JC, lane);
+            opm_mma<T, MI, NJ2>(acc2, Ah, TM, wm * 32 * MI, B2, C, wn * (C / 2), JC, lane);
             __syncthreads();
         }
 
         // ---- LayerNorm backward + residual, in the load layout (all lanes of a row group take part in the shuffles) ----
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < MI; i++) {
             if (i) __syncthreads();
-            stage_pass<NJ2>(stage, LD2, acc2, i, wm, wn, lane);
+            stage_pass<MI, NJ2>(stage, LD2, acc2, i, wm, wn, lane);
             __syncthreads();
 #pragma unroll
             for (int q = 0; q < NFX; q++) {
                 const int f = tid + q * 256, row = f / G, cl = f % G;
-                const bool mine = ((row >> 5) & 1) == i;          // uniform over the G lanes of a row
+                const bool mine = ((row >> 5) % MI) == i;         // uniform over the G lanes of a row
                 const bool ok = mine && (m0 + row < M);
                 float d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, xv[8], dxv[8], xh[8];
-                if (mine) stage_read8(stage, LD2, (row >> 6) * 32 + (row & 31), cl * 8, d);
+                if (mine) stage_read8(stage, LD2, (row / (32 * MI)) * 32 + (row & 31), cl * 8, d);
                 frag_to_float<T>(rawx[q], xv);
                 frag_to_float<T>(rawdx[q], dxv);
                 float gsum = 0.f, gxsum = 0.f;
