@@ -26,16 +26,16 @@ from .weights import StageWeights, unpack_conv_wgrad
 
 def use_fused_mlp(dtype, C: int, what: str) -> bool:
     """Which MLP halves go through the fused kernels of csrc/mlp.hpp (built for C in {64,128}).
-    Default = where they measured faster than the op-by-op chain on MI355X (profiles/microbench_mlp.py, bf16):
-      C=64 : backward dgrad chain 3.2 vs 4.5 ms, inference forward 3.3 vs 4.3 ms, training forward 4.4 vs 4.3 ms (chain kept)
-      C=128: slower everywhere (one workgroup per CU; needs the 64-token tile variant) -> chain.
+    Default = where they measured faster than the op-by-op chain on MI355X (profiles/microbench_mlp.py, bf16, ms):
+      C=64 : training forward 4.06 vs 4.30, inference forward 2.92 vs 4.30, backward dgrad chain 2.90 vs 4.57 -> fused
+      C=128: 3.26 vs 2.45 / 2.40 vs 2.45 / 2.51 vs 2.29 (weight panels are re-staged per 64-token tile)      -> chain
     RVT_FUSED_MLP=1 forces every supported case (used by the parity tests), =0 disables all."""
     mode = os.environ.get('RVT_FUSED_MLP', 'auto')
     if mode == '0' or not ops.mlp_fused_supported(dtype, C):
         return False
     if mode == '1':
         return True
-    return C == 64 and what in ('bwd', 'fwd_infer')
+    return C == 64
 
 
 class SideStream:
