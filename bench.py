@@ -268,6 +268,8 @@ def main():
     # weight-gradient side stream), and a timed region that still grows the pool pays hipMalloc inside it
     for _ in range(2):
         step()
+    torch.cuda.synchronize()
+    timer.records.clear()
 
     barrier()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
