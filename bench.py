@@ -171,6 +171,38 @@ def cpu_baseline(workload: str):
                     sample=f'cpu baseline did not finish within its 150 s bound ({type(e).__name__})')
 
 
+def stream_latency(wl, dtype, device, args):
+    """BASELINE configs[4]: one forward step (T=1) on a batch of 64 streams with the ConvLSTM state carried across
+    steps (the validation / deployment path, modules/detection.py:231-255), latency per step."""
+    model = build_model(wl, dtype, device)
+    Bs = args.batch or 64
+    g = torch.Generator(device=device).manual_seed(3)
+    frames = [torch.randint(0, 11, (Bs, 20, *wl['hw']), generator=g, dtype=torch.uint8, device=device) for _ in range(4)]
+    states = None
+    lat = []
+    with torch.no_grad():
+        for i in range(args.warmup + 8):                       # pre-warm 8 steps (SURVEY.md §8d)
+            _, states = model(frames[i % 4], states)
+        torch.cuda.synchronize()
+        for i in range(max(args.steps, 50)):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            e0.record()
+            _, states = model(frames[i % 4], states)
+            e1.record()
+            torch.cuda.synchronize()
+            lat.append((1e3 * (time.perf_counter() - t0), e0.elapsed_time(e1)))
+    wall = sorted(x[0] for x in lat)
+    gpu = sorted(x[1] for x in lat)
+    pct = lambda a, q: a[min(len(a) - 1, int(q * len(a)))]
+    print(json.dumps({'metric': 'streaming-inference step latency (T=1, persistent ConvLSTM state)', 'unit': 'ms',
+                      'batch': Bs, 'dtype': args.dtype, 'config': {'workload': wl['label'].split(',')[0] + f', B={Bs}, T=1'},
+                      'wall_p50': round(pct(wall, 0.5), 3), 'wall_p99': round(pct(wall, 0.99), 3),
+                      'gpu_p50': round(pct(gpu, 0.5), 3), 'gpu_p99': round(pct(gpu, 0.99), 3),
+                      'event_tensors_per_s_p50': round(Bs / pct(wall, 0.5) * 1e3, 1), 'higher_is_better': False,
+                      'data': 'synthetic'}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -184,6 +216,9 @@ def main():
     ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--no-optimizer', action='store_true')
     ap.add_argument('--op-breakdown', default=None, help='write a per-op HIP-event time table to this path')
+    ap.add_argument('--stream-latency', action='store_true',
+                    help='BASELINE configs[4] instead of the training step: T=1 streaming inference with persistent '
+                         'ConvLSTM state, batch 64; prints per-step latency percentiles (not the headline metric)')
     args = ap.parse_args()
 
     if args.cpu_baseline_worker:
@@ -205,6 +240,8 @@ def main():
         dist.init_process_group('nccl', device_id=device)      # "nccl" = RCCL on ROCm
 
     dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    if args.stream_latency:
+        return stream_latency(wl, dtype, device, args)
     model = build_model(wl, dtype, device)
     params = [p for p in model.parameters()]
     opt = None if args.no_optimizer else torch.optim.AdamW(params, lr=2e-4, fused=True)
