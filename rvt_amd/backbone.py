@@ -239,11 +239,19 @@ class _BackboneSeqFn(torch.autograd.Function):
         if src.dtype not in (torch.uint8, torch.float32):
             src = src.float()
         inp = ops.prepack_input(src, Hm, Wm, round8(Cin), dt)
+        # kernel-side weight views are rebuilt only when a parameter changed (optimizer step, load_state_dict, .to()):
+        # streaming inference calls forward once per time step with frozen weights
+        key = (dt, need_grad, tuple((id(t), t._version) for t in params))
+        cache = getattr(mod, '_sw_cache', None)
+        if cache is None or cache[0] != key:
+            cache = (key, [StageWeights(p, f'stages.{si}.', geoms[si].C, geoms[si].Cin, geoms[si].k, geoms[si].stride,
+                                        geoms[si].pad, geoms[si].num_blocks, dt, need_grad) for si in range(ns)])
+            mod._sw_cache = cache
         sws, svs, outs = [], [], []
         for si in range(ns):
             g = geoms[si]
             pre = f'stages.{si}.'
-            sw = StageWeights(p, pre, g.C, g.Cin, g.k, g.stride, g.pad, g.num_blocks, dt, need_grad)
+            sw = cache[1][si]
             h0, c0 = states_in[2 * si], states_in[2 * si + 1]
             if h0 is not None:
                 h0, c0 = _to_cl(h0, dt), _to_cl(c0, torch.float32)
