@@ -152,7 +152,7 @@ attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, AttnGeom g) {
             frag_t<T> v = load_chunk<T>(qkv + (size_t)tok[b] * C3 + voff, chunk, dh, valid[b]);
             store_transposed<T>(Vt, PITCH, chunk, 32 * b + li, v);
         }
-    __syncthreads();
+    lds_barrier();
 
 #pragma unroll
     for (int bi = 0; bi < NB; bi++) {
@@ -226,7 +226,7 @@ attn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ dout, T* __rest
             store_transposed<T>(dOt, PITCH, chunk, 32 * b + li,
                                 load_chunk<T>(dout + (size_t)tok[b] * g.C + ooff, chunk, dh, valid[b]));
         }
-    __syncthreads();
+    lds_barrier();
 
     f32x16 dk[NB], dv[NB];
 #pragma unroll
@@ -270,7 +270,7 @@ attn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ dout, T* __rest
         for (int bj = 0; bj < NB; bj++)
 #pragma unroll
             for (int r = 0; r < 16; r++) ds[bj][r] = pr[bj][r] * (dp[bj][r] - delta) * g.scale;
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int bj = 0; bj < NB; bj++)
 #pragma unroll
@@ -279,12 +279,12 @@ attn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ dout, T* __rest
                 frag_t<T> b = frag_load<T>(dOt + li * PITCH + 32 * bi + ks * 16 + half * 8);
                 mma32(dv[bj], a, b);
             }
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int bj = 0; bj < NB; bj++)
 #pragma unroll
             for (int r = 0; r < 16; r++) PS[(32 * bj + acc_row(r, lane)) * PSP + li] = (T)ds[bj][r];
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int bj = 0; bj < NB; bj++)
 #pragma unroll
@@ -308,20 +308,20 @@ attn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ dout, T* __rest
                 if (d0 < dh) store4<T>(qrow + d0, dq[4 * gq], dq[4 * gq + 1], dq[4 * gq + 2], dq[4 * gq + 3]);
             }
         }
-        __syncthreads();   // PS is rewritten by the next query block
+        lds_barrier();   // PS is rewritten by the next query block
     }
     // dK, dV: accumulator rows = keys, col = d = lane&31.  Stage each through LDS (the P^T buffer, [key][40]) so that the
     // global writes are 16-byte row segments instead of 2-byte scalars.
     constexpr int CPR = 32 / 8;                       // 8-channel chunks per key row (dh <= 32)
 #pragma unroll
     for (int which = 0; which < 2; which++) {
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int bj = 0; bj < NB; bj++)
 #pragma unroll
             for (int r = 0; r < 16; r++)
                 PS[(32 * bj + acc_row(r, lane)) * PSP + li] = (T)(which == 0 ? dk[bj][r] : dv[bj][r]);
-        __syncthreads();
+        lds_barrier();
         const int off = which == 0 ? koff : voff;
         for (int u = lane; u < LP * CPR; u += 64) {
             const int j = u / CPR, c = u % CPR;

@@ -135,6 +135,19 @@ template <class T> __device__ __forceinline__ frag_t<T> tile_load_frag(const cha
     return v;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also fences global memory: hipcc emits
+// `s_waitcnt vmcnt(0)` in front of the barrier, i.e. every wave waits until its outstanding global STORES are
+// acknowledged (CDNA counts stores on vmcnt).  In these kernels barriers only protect LDS tiles / staging buffers —
+// global data is never exchanged between waves inside a launch — so waiting for LDS (lgkmcnt) is sufficient and lets
+// the epilogue stores drain while the next tile is already being computed.
+__device__ __forceinline__ void lds_barrier() {
+#ifdef RVT_EMU
+    __syncthreads();
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
 // keep the instruction scheduler from moving anything across this point (used to pin prefetch loads early)
 __device__ __forceinline__ void sched_fence() {
 #ifndef RVT_EMU

@@ -273,7 +273,7 @@ template <class T, int ROWS, class Src, class Xf, bool HIGH> struct TNLoader {
 #pragma unroll
             for (int f = 0; f < 8; f++) scratch[u * 8 + f] = fvalid ? csum[f] : 0.f;
         }
-        __syncthreads();
+        lds_barrier();
         if (u >= 0 && u < FC) {
 #pragma unroll
             for (int f = 0; f < 8; f++) {
@@ -283,7 +283,7 @@ template <class T, int ROWS, class Src, class Xf, bool HIGH> struct TNLoader {
                 if (feat < n_features) out[feat] = a;
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
     __device__ __forceinline__ void store(char* tile, const Xf& xf, int tid) {
         if (u < 0) return;
@@ -550,7 +550,7 @@ gemm_kernel(ASrc as, AXf axf, BSrc bs, BXf bxf, Ep ep, int M, int N, int K, int 
             la.store(smem, axf, tid);
             lb.store(smem + BM * 128, bxf, tid);
         }
-        __syncthreads();
+        lds_barrier();
         for (int kt = 0; kt < nk; kt++) {
             const int cur = kt & 1;
             const bool more = kt + 1 < nk;
@@ -577,7 +577,7 @@ gemm_kernel(ASrc as, AXf axf, BSrc bs, BXf bxf, Ep ep, int M, int N, int K, int 
                 la.store(smem + (cur ^ 1) * STAGE_BYTES, axf, tid);
                 lb.store(smem + (cur ^ 1) * STAGE_BYTES + BM * 128, bxf, tid);
             }
-            __syncthreads();
+            lds_barrier();
         }
 
         // bias gradient: per-K-slice partial column sums of the A operand -> a_colsum[slice][M]  (workgroup-uniform branch)
@@ -603,13 +603,13 @@ gemm_kernel(ASrc as, AXf axf, BSrc bs, BXf bxf, Ep ep, int M, int N, int K, int 
         constexpr int UPR = BN / UNIT;
 #pragma unroll
         for (int i = 0; i < 2; i++) {
-            if (i) __syncthreads();
+            if (i) lds_barrier();
 #pragma unroll
             for (int j = 0; j < WN; j++)
 #pragma unroll
                 for (int r = 0; r < 16; r++)
                     stage[(wm * 32 + acc_row(r, lane)) * LDS_LD + wn * (BN / 2) + j * 32 + (lane & 31)] = acc[i][j][r];
-            __syncthreads();
+            lds_barrier();
             for (int u = tid; u < 64 * UPR; u += 256) {
                 const int srow = u / UPR, cu = u % UPR;
                 const int m = m0 + (srow >> 5) * 64 + i * 32 + (srow & 31), n = n0 + cu * UNIT;
@@ -624,7 +624,7 @@ gemm_kernel(ASrc as, AXf axf, BSrc bs, BXf bxf, Ep ep, int M, int N, int K, int 
                 }
             }
         }
-        __syncthreads();            // staging buffer is reused by the next tile's operand stores
+        lds_barrier();            // staging buffer is reused by the next tile's operand stores
         have = have2; mt = mt2; nt = nt2; seq++;
     }
 }

@@ -175,19 +175,19 @@ mlp_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, T* __restrict__
         for (int j0 = 0; j0 < HID; j0 += JC) {
             opm_stage<T>(B1, W1 + (size_t)j0 * C, C, JC, C, tid);               // W1 rows j0.., all C columns
             opm_stage<T>(B2, W2 + j0, HID, C, JC, tid);                         // W2[:, j0..j0+JC)
-            __syncthreads();
+            lds_barrier();
             f32x16 acc1[MI][NJ1];
 #pragma unroll
             for (int i = 0; i < MI; i++)
 #pragma unroll
                 for (int j = 0; j < NJ1; j++) acc_zero(acc1[i][j]);
             opm_mma<T, MI, NJ1>(acc1, Ax, TM, wm * 32 * MI, B1, JC, wn * (JC / 2), C, lane);
-            __syncthreads();                                                     // B1 consumed -> staging may overlay it
+            lds_barrier();                                                     // B1 consumed -> staging may overlay it
 #pragma unroll
             for (int i = 0; i < MI; i++) {
-                if (i) __syncthreads();
+                if (i) lds_barrier();
                 stage_pass<MI, NJ1>(stage, LD1, acc1, i, wm, wn, lane);
-                __syncthreads();
+                lds_barrier();
                 for (int u = tid; u < 64 * UPR1; u += 256) {
                     const int srow = u / UPR1, cu = u % UPR1;
                     const int row = stage_row_to_tile_row<MI>(srow, i);
@@ -204,17 +204,17 @@ mlp_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, T* __restrict__
                     }
                 }
             }
-            __syncthreads();
+            lds_barrier();
             opm_mma<T, MI, NJ2>(acc2, Ah, TM, wm * 32 * MI, B2, C, wn * (C / 2), JC, lane);
-            __syncthreads();                                                     // Ah / B2 / staging free for the next chunk
+            lds_barrier();                                                     // Ah / B2 / staging free for the next chunk
         }
 
         // ---- LayerScale + residual (maxvit.py:51-53,269) in the load layout: the residual is still in registers ----
 #pragma unroll
         for (int i = 0; i < MI; i++) {
-            if (i) __syncthreads();
+            if (i) lds_barrier();
             stage_pass<MI, NJ2>(stage, LD2, acc2, i, wm, wn, lane);
-            __syncthreads();
+            lds_barrier();
 #pragma unroll
             for (int q = 0; q < NFX; q++) {
                 const int f = tid + q * 256, row = f / G, cl = f % G;
@@ -229,7 +229,7 @@ mlp_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, T* __restrict__
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
 }
 
@@ -298,19 +298,19 @@ mlp_bwd_dgrad_kernel(const T* __restrict__ dxout, const T* __restrict__ gp, cons
         for (int j0 = 0; j0 < HID; j0 += JC) {
             opm_stage<T>(B1, W2gT + (size_t)j0 * C, C, JC, C, tid);             // rows j0.. of (W2 gamma)^T
             opm_stage<T>(B2, W1T + j0, HID, C, JC, tid);                        // W1^T[:, j0..j0+JC)
-            __syncthreads();
+            lds_barrier();
             f32x16 acc1[MI][NJ1];
 #pragma unroll
             for (int i = 0; i < MI; i++)
 #pragma unroll
                 for (int j = 0; j < NJ1; j++) acc_zero(acc1[i][j]);
             opm_mma<T, MI, NJ1>(acc1, Ax, TM, wm * 32 * MI, B1, JC, wn * (JC / 2), C, lane);
-            __syncthreads();
+            lds_barrier();
 #pragma unroll
             for (int i = 0; i < MI; i++) {
-                if (i) __syncthreads();
+                if (i) lds_barrier();
                 stage_pass<MI, NJ1>(stage, LD1, acc1, i, wm, wn, lane);
-                __syncthreads();
+                lds_barrier();
                 for (int u = tid; u < 64 * UPR1; u += 256) {
                     const int srow = u / UPR1, cu = u % UPR1;
                     const int row = stage_row_to_tile_row<MI>(srow, i);
@@ -326,17 +326,17 @@ mlp_bwd_dgrad_kernel(const T* __restrict__ dxout, const T* __restrict__ gp, cons
                     if (ok) frag_store<T>(dh + o, df);
                 }
             }
-            __syncthreads();
+            lds_barrier();
             opm_mma<T, MI, NJ2>(acc2, Ah, TM, wm * 32 * MI, B2, C, wn * (C / 2), JC, lane);
-            __syncthreads();
+            lds_barrier();
         }
 
         // ---- LayerNorm backward + residual, in the load layout (all lanes of a row group take part in the shuffles) ----
 #pragma unroll
         for (int i = 0; i < MI; i++) {
-            if (i) __syncthreads();
+            if (i) lds_barrier();
             stage_pass<MI, NJ2>(stage, LD2, acc2, i, wm, wn, lane);
-            __syncthreads();
+            lds_barrier();
 #pragma unroll
             for (int q = 0; q < NFX; q++) {
                 const int f = tid + q * 256, row = f / G, cl = f % G;
@@ -365,14 +365,14 @@ mlp_bwd_dgrad_kernel(const T* __restrict__ dxout, const T* __restrict__ gp, cons
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
 
     // LayerNorm parameter gradients: fold the 256/G threads that own the same channel chunk, one atomic per channel per WG
     float* red = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int e = 0; e < 8; e++) { red[tid * 16 + e] = aw[e]; red[tid * 16 + 8 + e] = ab[e]; }
-    __syncthreads();
+    lds_barrier();
     if (tid < G) {
 #pragma unroll
         for (int e = 0; e < 8; e++) {
