@@ -92,16 +92,6 @@ static void launch_wgrad(const ASrc& a, const BSrc& b, const BXf& bxf, float* ou
         else { constexpr int BN = 128; __VA_ARGS__; }                \
     } while (0)
 
-// NT linears whose whole contraction fits one K tile (stage 1: K = 64) and whose output rows are wider than 128 columns
-// use a 128 x 256 tile: a workgroup then writes whole 512-byte output rows (one contiguous 64 KiB block per tile) instead
-// of 256-byte pieces at a 512-byte stride — measured: partial-row writers plateau at ~3 TB/s, full-row writers reach ~5.
-#define DISPATCH_BN_WIDE(N, K, ...)                                                      \
-    do {                                                                                 \
-        if ((N) <= 64) { constexpr int BN = 64; __VA_ARGS__; }                           \
-        else if ((N) > 128 && (K) * (int)sizeof(T) <= 128) { constexpr int BN = 256; __VA_ARGS__; } \
-        else { constexpr int BN = 128; __VA_ARGS__; }                                    \
-    } while (0)
-
 extern "C" {
 
 const char* rvt_last_error(void) { return g_err; }
@@ -252,7 +242,7 @@ int rvt_linear_fwd(const void* x, const void* w, const float* bias, void* y, int
         PlainSrc<T> a{(const T*)x, K, M, K};
         PlainSrc<T> b{(const T*)w, K, N, K};
         EpStore<T> ep{(T*)y, N, bias, nullptr};
-        DISPATCH_BN_WIDE(N, K, {
+        DISPATCH_BN(N, {
             if (gelu_in) launch_gemm<T, BN, false>(a, XfGelu(), b, XfNone(), ep, M, N, K, 1, st);
             else launch_gemm<T, BN, false>(a, XfNone(), b, XfNone(), ep, M, N, K, 1, st);
         });
@@ -268,7 +258,7 @@ int rvt_linear_gelu_fwd(const void* x, const void* w, const float* bias, void* g
         PlainSrc<T> a{(const T*)x, K, M, K};
         PlainSrc<T> b{(const T*)w, K, N, K};
         EpGeluDual<T> ep{(T*)g, (T*)gp, N, bias};
-        DISPATCH_BN_WIDE(N, K, (launch_gemm<T, BN, false>(a, XfNone(), b, XfNone(), ep, M, N, K, 1, st)));
+        DISPATCH_BN(N, (launch_gemm<T, BN, false>(a, XfNone(), b, XfNone(), ep, M, N, K, 1, st)));
     });
     return check_launch("linear_gelu_fwd");
 }
@@ -299,7 +289,7 @@ int rvt_linear_dgrad(const void* dy, const void* wt, const void* gelu_pre, const
     DISPATCH_DTYPE(dtype, {
         PlainSrc<T> a{(const T*)dy, N, M, N};
         PlainSrc<T> b{(const T*)wt, N, K, N};
-        DISPATCH_BN_WIDE(K, N, {
+        DISPATCH_BN(K, {
             if (gelu_pre) {
                 EpGeluBwd<T> ep{(T*)dx, (const T*)gelu_pre, K};
                 launch_gemm<T, BN, false>(a, XfNone(), b, XfNone(), ep, M, K, N, 1, st);

@@ -652,7 +652,7 @@ inline void launch_gemm(const ASrc& as, const AXf& axf, const BSrc& bs, const BX
     if (!TN) {                                   // persistent: ~one resident wave of workgroups striding over the tiles
         static const int resident_override = getenv("RVT_GEMM_RESIDENT") ? atoi(getenv("RVT_GEMM_RESIDENT")) : 0;
         // workgroups per CU: LDS-bound (2 x 64 KiB) when double buffered; register-bound (~3) when K fits one tile
-        const int per_cu = BN == 256 ? 2 : ((K <= BK) ? 3 : (BN == 64 ? 3 : 2));
+        const int per_cu = (K <= BK) ? 3 : (BN == 64 ? 3 : 2);
         const int resident = resident_override > 0 ? resident_override : 256 * per_cu;
         if (total > resident) gx = resident;
         panel_major = (n_tiles > 1 && m_tiles >= 4 * gx) ? 1 : 0;
