@@ -58,3 +58,14 @@ for C, M in ((64, 7741440), (128, 1935360)):
     ms = timeit(lambda: ops.layernorm_fwd(x, lw, lb, 1e-5, out=dxo))
     report(f'layernorm_fwd C={C}', ms, M * 2 * C * 2, 0)
     del x, dy4, y4, dxo, x2
+
+# write-pattern probe: same K, output width = 64 / 128 (full rows per tile) vs 256 (two tiles per row)
+M, C = 7741440, 64
+x = rnd(M, C)
+for N in (64, 128, 256):
+    w = rnd(N, C)
+    b = torch.zeros(N, device=dev)
+    y = torch.empty(M, N, device=dev, dtype=dt)
+    ms = timeit(lambda: ops.linear_fwd(x, w, b, out=y))
+    report(f'probe linear_fwd K=64 N={N}', ms, M * C * 2 + M * N * 2, 2.0 * M * C * N)
+    del y
