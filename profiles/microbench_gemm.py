@@ -7,14 +7,22 @@ dev = torch.device('cuda', 0)
 dt = torch.bfloat16
 
 
-def timeit(fn, n=5):
-    fn(); torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(n):
+if '--lib' in sys.argv:       # A/B a differently-built library (tuning only)
+    from rvt_amd import _lib
+    _lib._install_test_library(_lib.load_library(os.path.abspath(sys.argv[sys.argv.index('--lib') + 1])))
+
+
+def timeit(fn, n=9):
+    """median of n individually timed launches after 3 warm-ups"""
+    for _ in range(3):
         fn()
-    e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    return sorted(ts)[n // 2]
 
 
 def rnd(*shape):

@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'librvt_hip.so')
+LIB_PATH = os.environ.get('RVT_HIP_LIB') or os.path.join(_HERE, 'librvt_hip.so')   # env: another BUILD of the same library
 
 RVT_F32, RVT_BF16 = 0, 1
 _DT = {torch.float32: RVT_F32, torch.bfloat16: RVT_BF16}

@@ -307,92 +307,157 @@ template <class T, int ROWS, class Src, class Xf, bool HIGH> struct TNLoader {
 };
 
 // ------------------------------------------------------------------------------------------------
-// epilogues: called with UNIT consecutive columns (n0 .. n0+UNIT-1) of row m, both in range
+// epilogues.  A thread owns ONE column unit (UNIT consecutive columns n .. n+UNIT-1) for the whole tile and a few rows
+// of it per 64-row pass, so an epilogue is split into three steps that the kernel schedules separately:
+//   cols(n)            per-column parameters (bias, LayerScale gamma) -> registers, once per tile, before the MFMA loop
+//   fetch(m, n)        per-element side inputs (residual, GELU', c_prev ...) -> registers; issued for ALL units of the
+//                      tile before the next tile's operand prefetch, so that nothing in the store path ever waits on a
+//                      load: on gfx950 loads and stores share the in-order vmcnt counter, and a load issued after a
+//                      store cannot be waited for without also waiting for that store's acknowledgement from memory
+//   apply(m, n, v, aux, cols)   arithmetic + stores
 // ------------------------------------------------------------------------------------------------
+struct EpNone {};
+
+template <int N> struct EpColVec {
+    float v[N];
+};
+template <int N> __device__ __forceinline__ EpColVec<N> ep_load_cols(const float* p, int n, bool ok) {
+    EpColVec<N> c;
+    if (p != nullptr && ok) {
+#pragma unroll
+        for (int q = 0; q < N / 4; q++) {
+            f32x4 t = *reinterpret_cast<const f32x4*>(p + n + q * 4);
+            c.v[q * 4 + 0] = t[0]; c.v[q * 4 + 1] = t[1]; c.v[q * 4 + 2] = t[2]; c.v[q * 4 + 3] = t[3];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; i++) c.v[i] = 0.f;
+    }
+    return c;
+}
+template <class T> struct EpFragAux {
+    frag_t<T> f;
+    __device__ __forceinline__ EpFragAux() : f(frag_zero<T>()) {}
+};
+
 template <class T> struct EpStore {
     __device__ __forceinline__ void begin_block(int) {}            // out = v (+bias) (+add)
     static constexpr int UNIT = 8;
+    typedef EpColVec<8> Cols;
+    typedef EpFragAux<T> Aux;
     T* out; int ld; const float* bias; const T* add;
-    __device__ __forceinline__ void operator()(int m, int n0, float (&v)[8]) const {
-        if (bias) {
+    __device__ __forceinline__ Cols cols(int n, bool ok) const { return ep_load_cols<8>(bias, n, ok); }
+    __device__ __forceinline__ Aux fetch(int m, int n) const {
+        Aux a;
+        if (add) a.f = frag_load<T>(add + (size_t)m * ld + n);
+        return a;
+    }
+    __device__ __forceinline__ void apply(int m, int n, float (&v)[8], const Aux& aux, const Cols& c) const {
+        float a[8]; frag_to_float<T>(aux.f, a);
 #pragma unroll
-            for (int i = 0; i < 8; i++) v[i] += bias[n0 + i];
-        }
-        if (add) {
-            float a[8]; frag_to_float<T>(frag_load<T>(add + (size_t)m * ld + n0), a);
-#pragma unroll
-            for (int i = 0; i < 8; i++) v[i] += a[i];
-        }
-        frag_store<T>(out + (size_t)m * ld + n0, frag_from_float<T>(v));
+        for (int i = 0; i < 8; i++) v[i] += c.v[i] + a[i];
+        frag_store<T>(out + (size_t)m * ld + n, frag_from_float<T>(v));
     }
 };
 
 template <class T> struct EpScaleRes {
     __device__ __forceinline__ void begin_block(int) {}         // out = res + gamma * (v + bias)     (LayerScale + residual)
     static constexpr int UNIT = 8;
+    struct Cols { EpColVec<8> b, g; };
+    typedef EpFragAux<T> Aux;
     T* out; const T* res; int ld; const float* bias; const float* gamma;
-    __device__ __forceinline__ void operator()(int m, int n0, float (&v)[8]) const {
-        float a[8]; frag_to_float<T>(frag_load<T>(res + (size_t)m * ld + n0), a);
+    __device__ __forceinline__ Cols cols(int n, bool ok) const {
+        Cols c; c.b = ep_load_cols<8>(bias, n, ok); c.g = ep_load_cols<8>(gamma, n, ok); return c;
+    }
+    __device__ __forceinline__ Aux fetch(int m, int n) const {
+        Aux a; a.f = frag_load<T>(res + (size_t)m * ld + n); return a;
+    }
+    __device__ __forceinline__ void apply(int m, int n, float (&v)[8], const Aux& aux, const Cols& c) const {
+        float a[8]; frag_to_float<T>(aux.f, a);
 #pragma unroll
-        for (int i = 0; i < 8; i++) v[i] = a[i] + gamma[n0 + i] * (v[i] + bias[n0 + i]);
-        frag_store<T>(out + (size_t)m * ld + n0, frag_from_float<T>(v));
+        for (int i = 0; i < 8; i++) v[i] = a[i] + c.g.v[i] * (v[i] + c.b.v[i]);
+        frag_store<T>(out + (size_t)m * ld + n, frag_from_float<T>(v));
     }
 };
 
 template <class T> struct EpGeluBwd {
     __device__ __forceinline__ void begin_block(int) {}          // out = v * gelu'(pre[m][n])
     static constexpr int UNIT = 8;
+    typedef EpNone Cols;
+    typedef EpFragAux<T> Aux;
     T* out; const T* pre; int ld;
-    __device__ __forceinline__ void operator()(int m, int n0, float (&v)[8]) const {
-        float a[8]; frag_to_float<T>(frag_load<T>(pre + (size_t)m * ld + n0), a);
+    __device__ __forceinline__ Cols cols(int, bool) const { return Cols(); }
+    __device__ __forceinline__ Aux fetch(int m, int n) const {
+        Aux a; a.f = frag_load<T>(pre + (size_t)m * ld + n); return a;
+    }
+    __device__ __forceinline__ void apply(int m, int n, float (&v)[8], const Aux& aux, const Cols&) const {
+        float a[8]; frag_to_float<T>(aux.f, a);
 #pragma unroll
         for (int i = 0; i < 8; i++) v[i] *= gelu_grad_f(a[i]);
-        frag_store<T>(out + (size_t)m * ld + n0, frag_from_float<T>(v));
+        frag_store<T>(out + (size_t)m * ld + n, frag_from_float<T>(v));
     }
 };
 
 template <class T> struct EpGeluDual {         // g = gelu(v + bias), gp = gelu'(v + bias)  (gp nullable)
     __device__ __forceinline__ void begin_block(int) {}
     static constexpr int UNIT = 8;
+    typedef EpColVec<8> Cols;
+    typedef EpNone Aux;
     T* g; T* gp; int ld; const float* bias;
-    __device__ __forceinline__ void operator()(int m, int n0, float (&v)[8]) const {
+    __device__ __forceinline__ Cols cols(int n, bool ok) const { return ep_load_cols<8>(bias, n, ok); }
+    __device__ __forceinline__ Aux fetch(int, int) const { return Aux(); }
+    __device__ __forceinline__ void apply(int m, int n, float (&v)[8], const Aux&, const Cols& c) const {
         float a[8], b[8];
 #pragma unroll
-        for (int i = 0; i < 8; i++) gelu_both_f(v[i] + bias[n0 + i], a[i], b[i]);
-        frag_store<T>(g + (size_t)m * ld + n0, frag_from_float<T>(a));
-        if (gp) frag_store<T>(gp + (size_t)m * ld + n0, frag_from_float<T>(b));
+        for (int i = 0; i < 8; i++) gelu_both_f(v[i] + c.v[i], a[i], b[i]);
+        frag_store<T>(g + (size_t)m * ld + n, frag_from_float<T>(a));
+        if (gp) frag_store<T>(gp + (size_t)m * ld + n, frag_from_float<T>(b));
     }
 };
 
 template <class T> struct EpMul {              // out = v * mul[m][n]
     __device__ __forceinline__ void begin_block(int) {}
     static constexpr int UNIT = 8;
+    typedef EpNone Cols;
+    typedef EpFragAux<T> Aux;
     T* out; const T* mul; int ld;
-    __device__ __forceinline__ void operator()(int m, int n0, float (&v)[8]) const {
-        float a[8]; frag_to_float<T>(frag_load<T>(mul + (size_t)m * ld + n0), a);
+    __device__ __forceinline__ Cols cols(int, bool) const { return Cols(); }
+    __device__ __forceinline__ Aux fetch(int m, int n) const {
+        Aux a; a.f = frag_load<T>(mul + (size_t)m * ld + n); return a;
+    }
+    __device__ __forceinline__ void apply(int m, int n, float (&v)[8], const Aux& aux, const Cols&) const {
+        float a[8]; frag_to_float<T>(aux.f, a);
 #pragma unroll
         for (int i = 0; i < 8; i++) v[i] *= a[i];
-        frag_store<T>(out + (size_t)m * ld + n0, frag_from_float<T>(v));
+        frag_store<T>(out + (size_t)m * ld + n, frag_from_float<T>(v));
     }
 };
 
 template <class T> struct EpSplit2 {
     __device__ __forceinline__ void begin_block(int) {}           // columns [0,C) -> out0, [C,2C) -> out1 (both ld = C)
     static constexpr int UNIT = 8;
+    typedef EpNone Cols;
+    typedef EpNone Aux;
     T* out0; T* out1; int C;
-    __device__ __forceinline__ void operator()(int m, int n0, float (&v)[8]) const {
-        T* o = n0 < C ? out0 + (size_t)m * C + n0 : out1 + (size_t)m * C + (n0 - C);
+    __device__ __forceinline__ Cols cols(int, bool) const { return Cols(); }
+    __device__ __forceinline__ Aux fetch(int, int) const { return Aux(); }
+    __device__ __forceinline__ void apply(int m, int n, float (&v)[8], const Aux&, const Cols&) const {
+        T* o = n < C ? out0 + (size_t)m * C + n : out1 + (size_t)m * C + (n - C);
         frag_store<T>(o, frag_from_float<T>(v));
     }
 };
 
 struct EpAtomicF32 {                           // direct atomic accumulation (kept for tiny problems / no workspace)
     static constexpr int UNIT = 8;
+    typedef EpNone Cols;
+    typedef EpNone Aux;
     __device__ __forceinline__ void begin_block(int) {}
     float* out; int ld;
-    __device__ __forceinline__ void operator()(int m, int n0, float (&v)[8]) const {
+    __device__ __forceinline__ Cols cols(int, bool) const { return Cols(); }
+    __device__ __forceinline__ Aux fetch(int, int) const { return Aux(); }
+    __device__ __forceinline__ void apply(int m, int n, float (&v)[8], const Aux&, const Cols&) const {
 #pragma unroll
-        for (int i = 0; i < 8; i++) atomicAdd(out + (size_t)m * ld + n0 + i, v[i]);
+        for (int i = 0; i < 8; i++) atomicAdd(out + (size_t)m * ld + n + i, v[i]);
     }
 };
 
@@ -401,10 +466,14 @@ struct EpAtomicF32 {                           // direct atomic accumulation (ke
 // 8-XCD MI355X — ~64 B of fabric traffic and ~0.4 ns each chip-wide — so they are kept off the hot path.)
 struct EpPartialStore {
     static constexpr int UNIT = 8;
+    typedef EpNone Cols;
+    typedef EpNone Aux;
     float* ws; int ld; size_t slice_elems; int slice;
     __device__ __forceinline__ void begin_block(int split) { slice = split; }
-    __device__ __forceinline__ void operator()(int m, int n0, float (&v)[8]) const {
-        float* o = ws + (size_t)slice * slice_elems + (size_t)m * ld + n0;
+    __device__ __forceinline__ Cols cols(int, bool) const { return Cols(); }
+    __device__ __forceinline__ Aux fetch(int, int) const { return Aux(); }
+    __device__ __forceinline__ void apply(int m, int n, float (&v)[8], const Aux&, const Cols&) const {
+        float* o = ws + (size_t)slice * slice_elems + (size_t)m * ld + n;
         *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
         *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
     }
@@ -424,18 +493,26 @@ splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int 
 template <class T> struct EpDgradScatter {
     __device__ __forceinline__ void begin_block(int) {}
     static constexpr int UNIT = 8;
+    typedef EpNone Cols;
+    typedef EpFragAux<T> Aux;
     T* out; const T* add; int H, W, Cin, s, py, px; FastDiv dHcWc, dWc;
-    __device__ __forceinline__ void operator()(int m, int n0, float (&v)[8]) const {
+    __device__ __forceinline__ size_t offset(int m, int n) const {
         uint32_t f, rem, yy, xx;
         dHcWc.divmod((uint32_t)m, f, rem);
         dWc.divmod(rem, yy, xx);
-        size_t o = (((size_t)f * H + yy * s + py) * W + xx * s + px) * Cin + n0;
-        if (add) {
-            float a[8]; frag_to_float<T>(frag_load<T>(add + o), a);
+        return (((size_t)f * H + yy * s + py) * W + xx * s + px) * Cin + n;
+    }
+    __device__ __forceinline__ Cols cols(int, bool) const { return Cols(); }
+    __device__ __forceinline__ Aux fetch(int m, int n) const {
+        Aux a;
+        if (add) a.f = frag_load<T>(add + offset(m, n));
+        return a;
+    }
+    __device__ __forceinline__ void apply(int m, int n, float (&v)[8], const Aux& aux, const Cols&) const {
+        float a[8]; frag_to_float<T>(aux.f, a);
 #pragma unroll
-            for (int i = 0; i < 8; i++) v[i] += a[i];
-        }
-        frag_store<T>(out + o, frag_from_float<T>(v));
+        for (int i = 0; i < 8; i++) v[i] += a[i];
+        frag_store<T>(out + offset(m, n), frag_from_float<T>(v));
     }
 };
 
@@ -445,28 +522,41 @@ template <class T> struct EpDgradScatter {
 template <class T> struct EpLstm {
     __device__ __forceinline__ void begin_block(int) {}
     static constexpr int UNIT = 32;
+    typedef EpColVec<32> Cols;
+    struct Aux {
+        f32x4 c0, c1;
+        __device__ __forceinline__ Aux() : c0(f32x4{0.f, 0.f, 0.f, 0.f}), c1(f32x4{0.f, 0.f, 0.f, 0.f}) {}
+    };
     const float* bias;      // permuted like the columns, length 4C
     const float* c_prev;    // [rows][C] fp32
     float* c_out;           // [rows][C] fp32
     T* h_out;               // [rows][C]
     T* gates;               // [rows][4C] natural layout [f|i|o|g] (activated), may be null
     int C;
-    __device__ __forceinline__ void operator()(int m, int n0, float (&v)[32]) const {
-        int c0 = (n0 >> 5) << 3;
+    __device__ __forceinline__ Cols cols(int n, bool ok) const { return ep_load_cols<32>(bias, n, ok); }
+    __device__ __forceinline__ Aux fetch(int m, int n) const {
+        const float* cp = c_prev + (size_t)m * C + ((n >> 5) << 3);
+        Aux a;
+        a.c0 = *reinterpret_cast<const f32x4*>(cp);
+        a.c1 = *reinterpret_cast<const f32x4*>(cp + 4);
+        return a;
+    }
+    __device__ __forceinline__ void apply(int m, int n, float (&v)[32], const Aux& aux, const Cols& b) const {
+        int c0 = (n >> 5) << 3;
         float f[8], ig[8], o[8], g[8], cn[8], hn[8];
-        const float* cp = c_prev + (size_t)m * C + c0;
+        const float cp[8] = {aux.c0[0], aux.c0[1], aux.c0[2], aux.c0[3], aux.c1[0], aux.c1[1], aux.c1[2], aux.c1[3]};
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            f[i] = sigmoid_f(v[i] + bias[n0 + i]);
-            ig[i] = sigmoid_f(v[8 + i] + bias[n0 + 8 + i]);
-            o[i] = sigmoid_f(v[16 + i] + bias[n0 + 16 + i]);
-            g[i] = tanh_f(v[24 + i] + bias[n0 + 24 + i]);
+            f[i] = sigmoid_f(v[i] + b.v[i]);
+            ig[i] = sigmoid_f(v[8 + i] + b.v[8 + i]);
+            o[i] = sigmoid_f(v[16 + i] + b.v[16 + i]);
+            g[i] = tanh_f(v[24 + i] + b.v[24 + i]);
             cn[i] = f[i] * cp[i] + ig[i] * g[i];
             hn[i] = o[i] * tanh_f(cn[i]);
         }
         float* co = c_out + (size_t)m * C + c0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) co[i] = cn[i];
+        *reinterpret_cast<f32x4*>(co) = f32x4{cn[0], cn[1], cn[2], cn[3]};
+        *reinterpret_cast<f32x4*>(co + 4) = f32x4{cn[4], cn[5], cn[6], cn[7]};
         frag_store<T>(h_out + (size_t)m * C + c0, frag_from_float<T>(hn));
         if (gates) {
             T* gp = gates + (size_t)m * 4 * C + c0;
@@ -490,7 +580,7 @@ template <int BN, bool ONE_K> struct GemmSmem {
 };
 
 template <class T, int BN, bool TN, bool ONE_K, class ASrc, class AXf, class BSrc, class BXf, class Ep>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, (TN ? 1 : (BN == 64 && Ep::UNIT == 8 && sizeof(T) == 2 ? 3 : 2)))
 gemm_kernel(ASrc as, AXf axf, BSrc bs, BXf bxf, Ep ep, int M, int N, int K, int m_tiles, int n_tiles, int ksplit_len,
             float* a_colsum, int panel_major) {
     constexpr int BM = 128;
@@ -530,6 +620,15 @@ gemm_kernel(ASrc as, AXf axf, BSrc bs, BXf bxf, Ep ep, int M, int N, int K, int 
     LA la; LB lb;
     ep.begin_block(by);
 
+    // epilogue geometry: a thread keeps one UNIT-wide column unit and walks rows (see the epilogue protocol above)
+    constexpr int LDS_LD = BN + 4;
+    constexpr int UNIT = Ep::UNIT;
+    constexpr int UPR = BN / UNIT;                       // units per tile row (a power of two <= 16)
+    constexpr int RSTEP = 256 / UPR;                     // rows covered by the 256 threads at once
+    constexpr int UPT = (64 + RSTEP - 1) / RSTEP;        // units per thread per 64-row pass
+    const int ep_cu = tid % UPR, ep_row0 = tid / UPR;
+    constexpr bool EARLY = ONE_K && !TN;
+
     int seq = 0, mt, nt;
     bool have = tile_of(0, mt, nt);
     if (have && nk > 0) {
@@ -537,20 +636,59 @@ gemm_kernel(ASrc as, AXf axf, BSrc bs, BXf bxf, Ep ep, int M, int N, int K, int 
         lb.init(bs, nt * BN, tid);
         la.load(as, axf, kbeg, kend, tid);
         lb.load(bs, bxf, kbeg, kend, tid);
+        la.store(smem, axf, tid);
+        lb.store(smem + BM * 128, bxf, tid);
     }
+    // The prefetched operands of the NEXT tile are moved to LDS at the BOTTOM of the loop body, not at its top: there
+    // the compiler sees "8 loads, then this tile's output stores" on every path and waits with vmcnt(#stores).  With
+    // the move at the loop top the header merges the prologue path (loads only) with the back edge, the wait becomes
+    // vmcnt(0), and every tile stalls until its predecessor's output stores are acknowledged by memory.
     while (have) {
         const int m0 = mt * BM, n0 = nt * BN;
+        const int ncol = n0 + ep_cu * UNIT;
+        const bool col_ok = ep_row0 < 64 && ncol < N;
         f32x16 acc[2][WN];
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
             for (int j = 0; j < WN; j++) acc_zero(acc[i][j]);
 
-        if (nk > 0) {
-            la.store(smem, axf, tid);
-            lb.store(smem + BM * 128, bxf, tid);
-        }
+        // Global-memory traffic of a tile, in issue order (vmcnt counts loads and stores in ONE in-order queue, so a wait
+        // for some load also waits for everything issued before it):
+        //   1. side inputs of this tile's epilogue (bias/gamma columns, residual, GELU', c_prev ...)
+        //   2. the operand prefetch of the NEXT tile
+        //   3. this tile's output stores
+        // so the epilogue arithmetic waits for (1) only, and the move of (2) into LDS at the loop bottom waits with
+        // vmcnt(#stores) and never for a store acknowledgement.  When the whole contraction is one K tile (EARLY) both
+        // are issued before the MFMA phase — a full tile time ahead of their use; with a K loop its operand loads share
+        // the loader registers, so (1) and (2) are issued after the last K tile instead.
+        typename Ep::Cols cols;
+        typename Ep::Aux aux[2][UPT];
+        int mt2 = 0, nt2 = 0;
+        bool have2 = false;
+        auto fetch_side = [&]() {
+            cols = ep.cols(ncol, col_ok);
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int q = 0; q < UPT; q++) {
+                    const int srow = ep_row0 + q * RSTEP;
+                    const int m = m0 + (srow >> 5) * 64 + i * 32 + (srow & 31);
+                    if (col_ok && srow < 64 && m < M) aux[i][q] = ep.fetch(m, ncol);
+                }
+        };
+        auto prefetch_next = [&]() {
+            have2 = tile_of(seq + 1, mt2, nt2);
+            if (have2 && nk > 0) {
+                la.init(as, mt2 * BM, tid);
+                lb.init(bs, nt2 * BN, tid);
+                la.load(as, axf, kbeg, kend, tid);
+                lb.load(bs, bxf, kbeg, kend, tid);
+            }
+        };
+
         lds_barrier();
+        if (EARLY) { fetch_side(); sched_fence(); prefetch_next(); sched_fence(); }
         for (int kt = 0; kt < nk; kt++) {
             const int cur = kt & 1;
             const bool more = kt + 1 < nk;
@@ -584,23 +722,12 @@ gemm_kernel(ASrc as, AXf axf, BSrc bs, BXf bxf, Ep ep, int M, int N, int K, int 
         if (TN && a_colsum != nullptr && n0 == 0)
             la.flush_colsum(a_colsum + (size_t)by * M, m0, reinterpret_cast<float*>(smem), M);
 
-        // next tile's first K tile: issue its global loads now so they fly during this tile's epilogue
-        int mt2 = 0, nt2 = 0;
-        const bool have2 = tile_of(seq + 1, mt2, nt2);
-        if (have2 && nk > 0) {
-            la.init(as, mt2 * BM, tid);
-            lb.init(bs, nt2 * BN, tid);
-            la.load(as, axf, kbeg, kend, tid);
-            lb.load(bs, bxf, kbeg, kend, tid);
-        }
+        if (!EARLY) { fetch_side(); sched_fence(); prefetch_next(); }
         sched_fence();      // the prefetch must be ISSUED here, not sunk below the epilogue
 
         // ---- epilogue: accumulators -> LDS (fp32, row pitch BN+4) -> UNIT-wide row segments, 64 tile rows per pass
         // (pass i = MFMA row block i of every wave: stage row wm*32+r <-> tile row wm*64+i*32+r) ----
         float* stage = reinterpret_cast<float*>(smem);
-        constexpr int LDS_LD = BN + 4;
-        constexpr int UNIT = Ep::UNIT;
-        constexpr int UPR = BN / UNIT;
 #pragma unroll
         for (int i = 0; i < 2; i++) {
             if (i) lds_barrier();
@@ -610,22 +737,27 @@ gemm_kernel(ASrc as, AXf axf, BSrc bs, BXf bxf, Ep ep, int M, int N, int K, int 
                 for (int r = 0; r < 16; r++)
                     stage[(wm * 32 + acc_row(r, lane)) * LDS_LD + wn * (BN / 2) + j * 32 + (lane & 31)] = acc[i][j][r];
             lds_barrier();
-            for (int u = tid; u < 64 * UPR; u += 256) {
-                const int srow = u / UPR, cu = u % UPR;
-                const int m = m0 + (srow >> 5) * 64 + i * 32 + (srow & 31), n = n0 + cu * UNIT;
-                if (m < M && n < N) {
+#pragma unroll
+            for (int q = 0; q < UPT; q++) {
+                const int srow = ep_row0 + q * RSTEP;
+                const int m = m0 + (srow >> 5) * 64 + i * 32 + (srow & 31);
+                if (col_ok && srow < 64 && m < M) {
                     float v[UNIT];
 #pragma unroll
-                    for (int q = 0; q < UNIT / 4; q++) {
-                        f32x4 t = *reinterpret_cast<const f32x4*>(stage + srow * LDS_LD + cu * UNIT + q * 4);
-                        v[q * 4 + 0] = t[0]; v[q * 4 + 1] = t[1]; v[q * 4 + 2] = t[2]; v[q * 4 + 3] = t[3];
+                    for (int w = 0; w < UNIT / 4; w++) {
+                        f32x4 t = *reinterpret_cast<const f32x4*>(stage + srow * LDS_LD + ep_cu * UNIT + w * 4);
+                        v[w * 4 + 0] = t[0]; v[w * 4 + 1] = t[1]; v[w * 4 + 2] = t[2]; v[w * 4 + 3] = t[3];
                     }
-                    ep(m, n, v);
+                    ep.apply(m, ncol, v, aux[i][q], cols);
                 }
             }
         }
         lds_barrier();            // staging buffer is reused by the next tile's operand stores
         have = have2; mt = mt2; nt = nt2; seq++;
+        if (have && nk > 0) {
+            la.store(smem, axf, tid);
+            lb.store(smem + BM * 128, bxf, tid);
+        }
     }
 }
 
@@ -649,15 +781,29 @@ inline void launch_gemm(const ASrc& as, const AXf& axf, const BSrc& bs, const BX
     int nsplit = gemm_slices(K, ksplit, BK);
     int total = m_tiles * n_tiles;
     int gx = total, panel_major = 0;
-    if (!TN) {                                   // persistent: ~one resident wave of workgroups striding over the tiles
+    const bool one_k = !TN && K <= BK;
+    if (!TN) {                                   // persistent: exactly one resident wave of workgroups striding over the tiles
         static const int resident_override = getenv("RVT_GEMM_RESIDENT") ? atoi(getenv("RVT_GEMM_RESIDENT")) : 0;
-        // workgroups per CU: LDS-bound (2 x 64 KiB) when double buffered; register-bound (~3) when K fits one tile
-        const int per_cu = (K <= BK) ? 3 : (BN == 64 ? 3 : 2);
+        // workgroups per CU as the hardware will actually schedule them (registers and LDS of THIS instantiation): more
+        // would queue behind the resident ones and run as a half-empty second wave
+        static int per_cu_one = 0, per_cu_multi = 0;
+        int& per_cu = one_k ? per_cu_one : per_cu_multi;
+        if (per_cu == 0) {
+#ifdef RVT_EMU
+            per_cu = 2;
+#else
+            int nb = 0;
+            hipError_t e = one_k
+                ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gemm_kernel<T, BN, TN, true, ASrc, AXf, BSrc, BXf, Ep>, 256, 0)
+                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gemm_kernel<T, BN, TN, false, ASrc, AXf, BSrc, BXf, Ep>, 256, 0);
+            per_cu = (e == hipSuccess && nb > 0) ? nb : 2;
+#endif
+        }
         const int resident = resident_override > 0 ? resident_override : 256 * per_cu;
         if (total > resident) gx = resident;
         panel_major = (n_tiles > 1 && m_tiles >= 4 * gx) ? 1 : 0;
     }
-    if (!TN && K <= BK)       // whole contraction in one K tile: single operand stage, more workgroups per CU
+    if (one_k)                // whole contraction in one K tile: single operand stage, more workgroups per CU
         hipLaunchKernelGGL((gemm_kernel<T, BN, TN, true, ASrc, AXf, BSrc, BXf, Ep>), dim3(gx, nsplit), dim3(256), 0, stream,
                            as, axf, bs, bxf, ep, M, N, K, m_tiles, n_tiles, klen, a_colsum, panel_major);
     else
