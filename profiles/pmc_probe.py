@@ -1,0 +1,22 @@
+"""One GEMM-family op in isolation, for `rocprofv3 --pmc` passes (see profiles/pmc_probe.sh).  usage: pmc_probe.py <op>"""
+import sys, os, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rvt_amd import ops
+
+dev, dt = torch.device('cuda', 0), torch.bfloat16
+op = sys.argv[1] if len(sys.argv) > 1 else 'wgrad'
+M, C = 7741440, 64
+rnd = lambda *s: torch.randn(*s, device=dev).to(dt)
+x, dy4 = rnd(M, C), rnd(M, 4 * C)
+if op == 'wgrad':           # dW[256][64] = dy^T x  (+ bias gradient)
+    dw, cs = torch.zeros(4 * C, C, device=dev), torch.zeros(4 * C, device=dev)
+    fn = lambda: ops.linear_wgrad(dy4, x, dw, colsum_out=cs)
+elif op == 'fwd':           # y[M][256] = x W^T + b
+    w, b, y = rnd(4 * C, C), torch.zeros(4 * C, device=dev), torch.empty(M, 4 * C, device=dev, dtype=dt)
+    fn = lambda: ops.linear_fwd(x, w, b, out=y)
+elif op == 'dgrad':         # dx[M][64] = dy W
+    wt, dx = rnd(C, 4 * C), torch.empty(M, C, device=dev, dtype=dt)
+    fn = lambda: ops.linear_dgrad(dy4, wt, out=dx)
+for _ in range(3):
+    fn()
+torch.cuda.synchronize()

@@ -30,6 +30,9 @@ namespace rvt {
 // ------------------------------------------------------------------------------------------------
 template <class T> struct PlainSrc {
     const T* p; int ld; int rows; int cols;
+    static constexpr bool LINEAR = true;               // element (row, seg, off) = linear_base(seg)[row * linear_ld() + off]
+    __device__ __forceinline__ const T* linear_base(int) const { return p; }
+    __device__ __forceinline__ int linear_ld() const { return ld; }
     typedef const T* Ctx;
     __device__ __forceinline__ Ctx row_ctx(int m) const { return (m >= 0 && m < rows) ? p + (size_t)m * ld : nullptr; }
     __device__ __forceinline__ void split(int kcol, int& seg, int& off) const { seg = 0; off = kcol; }
@@ -41,6 +44,9 @@ template <class T> struct PlainSrc {
 
 template <class T> struct ConcatSrc {   // [x | h], both [rows][C]
     const T* x; const T* h; int C; int rows; int cols;  // cols = 2C
+    static constexpr bool LINEAR = true;
+    __device__ __forceinline__ const T* linear_base(int seg) const { return seg ? h : x; }
+    __device__ __forceinline__ int linear_ld() const { return C; }
     typedef int Ctx;
     __device__ __forceinline__ Ctx row_ctx(int m) const { return (m >= 0 && m < rows) ? m : -1; }
     __device__ __forceinline__ void split(int kcol, int& seg, int& off) const { seg = kcol >= C; off = kcol - seg * C; }
@@ -56,6 +62,9 @@ template <class T> struct ConcatSrc {   // [x | h], both [rows][C]
 template <class T> struct Im2colSrc {
     const T* p; int H, W, Cin, Ho, Wo, kw, stride, pad; int rows; int cols;  // cols = kh*kw*Cin
     FastDiv dHoWo, dWo, dkw, dCin;
+    static constexpr bool LINEAR = false;
+    __device__ __forceinline__ const T* linear_base(int) const { return p; }
+    __device__ __forceinline__ int linear_ld() const { return 0; }
     struct Ctx { int base; int iy0; int ix0; };
     __device__ __forceinline__ Ctx row_ctx(int m) const {
         Ctx c;
@@ -100,6 +109,9 @@ template <class T> struct DgradSrc {
     int s, pad, py, px; int nky, nkx; int ky[4], kx[4];
     int rows; int cols;                             // cols = nky*nkx*Cout
     FastDiv dHcWc, dWc, dCout;
+    static constexpr bool LINEAR = false;
+    __device__ __forceinline__ const T* linear_base(int) const { return dy; }
+    __device__ __forceinline__ int linear_ld() const { return 0; }
     struct Ctx { int f; int y; int x; };
     __device__ __forceinline__ Ctx row_ctx(int m) const {
         Ctx c;
@@ -154,6 +166,7 @@ template <class T, class Xf> __device__ __forceinline__ frag_t<T> xf_apply(const
 template <class T, int ROWS, class Src, class Xf> struct NTLoader {
     static constexpr int FPR = TileGeom<T>::FPR;
     static constexpr int NF = ROWS * FPR / 256;
+    struct Regs {};                                       // (interface symmetry with TNLoader: NT keeps its registers itself)
     typename Src::Ctx ctx[NF];
     frag_t<T> r[NF];
     bool valid[NF];
@@ -188,7 +201,6 @@ template <class T, int ROWS, class Src, class Xf> struct NTLoader {
             tile_store_frag<T>(tile, u / FPR, u % FPR, v);
         }
     }
-    __device__ __forceinline__ void flush_colsum(float*, int, float*, int) const {}
 };
 
 // Transposing loader: tile row = source COLUMN (feature), contraction = source ROW (token).
@@ -207,7 +219,8 @@ template <> struct Transpose8<float> {
 };
 template <> struct Transpose8<bf16> {
     static __device__ __forceinline__ void run(const bf16x8 (&in)[8], bf16x8 (&out)[8]) {
-        // 16-bit 8x8 transpose on packed dwords: out[f].dword[q] = { in[2q].half[f], in[2q+1].half[f] }
+        // 16-bit 8x8 transpose on packed dwords: out[f].dword[q] = { in[2q].half[f], in[2q+1].half[f] } — one byte
+        // permute (v_perm_b32) per output dword
         u32x4 w[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) w[j] = *reinterpret_cast<const u32x4*>(&in[j]);
@@ -217,11 +230,22 @@ template <> struct Transpose8<bf16> {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 uint32_t a = w[2 * q][f >> 1], b = w[2 * q + 1][f >> 1];
+#ifdef RVT_EMU
                 o[q] = (f & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
+#else
+                o[q] = __builtin_amdgcn_perm(b, a, (f & 1) ? 0x07060302u : 0x05040100u);   // bytes 0-3 = a, 4-7 = b
+#endif
             }
             out[f] = *reinterpret_cast<const bf16x8*>(&o);
         }
     }
+};
+
+// The eight raw source rows of one unit while they are in flight.  A thread serves the A operand or the B operand,
+// never both (wave-uniform), so the two loaders of a kernel share one TNRegs; the K loop keeps TWO of them in flight.
+template <class T> struct TNRegs {
+    frag_t<T> r[8];
+    unsigned vmask;
 };
 
 template <class T, int ROWS, class Src, class Xf, bool HIGH> struct TNLoader {
@@ -229,29 +253,43 @@ template <class T, int ROWS, class Src, class Xf, bool HIGH> struct TNLoader {
     static constexpr int FC = ROWS / 8;                   // feature chunks per tile
     static constexpr int NUNITS = FC * FPR;               // <= 128
     static_assert(NUNITS <= 256, "tile too large for one unit per thread");
-    static constexpr bool WANT_COLSUM = !HIGH;            // only the A (dY) side feeds bias gradients
+    typedef TNRegs<T> Regs;
     int u;                                                // this thread's unit or -1
     int seg, off;
     bool fvalid;
-    unsigned vmask;
-    frag_t<T> r[8];
-    float csum[8];                                        // running sum over tokens of this unit's 8 features
+    const T* colbase;                                     // LINEAR sources: address of (token 0, this unit's first feature)
+    int ldl;
+    int soff[8 * TileGeom<T>::CPF];                       // LDS byte offsets of the unit's 8 feature rows (fixed for the launch)
     __device__ __forceinline__ void init(const Src& s, int row0, int tid) {
         u = HIGH ? tid - (256 - NUNITS) : tid;
         if (u >= NUNITS) u = -1;
-        seg = 0; off = 0; fvalid = false;
-#pragma unroll
-        for (int f = 0; f < 8; f++) csum[f] = 0.f;
+        seg = 0; off = 0; fvalid = false; colbase = s.safe(); ldl = 0;
         if (u >= 0) {
             int feat = row0 + (u % FC) * 8;
             fvalid = feat < s.cols;
             if (fvalid) s.split(feat, seg, off);
+            if (Src::LINEAR) { colbase = s.linear_base(seg) + off; ldl = s.linear_ld(); }
+#pragma unroll
+            for (int f = 0; f < 8; f++)
+#pragma unroll
+                for (int c = 0; c < TileGeom<T>::CPF; c++)
+                    soff[f * TileGeom<T>::CPF + c] = lds_chunk_off((u % FC) * 8 + f, (u / FC) * TileGeom<T>::CPF + c);
         }
     }
-    __device__ __forceinline__ void load(const Src& s, const Xf& xf, int k0, int kend, int tid) {
+    __device__ __forceinline__ void load(const Src& s, const Xf& xf, int k0, int kend, int tid, Regs& R) {
         if (u < 0) return;
         const int tok0 = k0 + (u / FC) * 8;
-        vmask = 0;
+        if (!fvalid) { R.vmask = 0u; return; }               // feature padding of a partial tile: zeros, no traffic
+        if (Src::LINEAR && tok0 + 8 <= kend) {
+            // interior unit of a row-major source (every K tile but a slice's last): eight unconditional loads,
+            // one address computation
+            const T* p = colbase + (size_t)tok0 * ldl;
+#pragma unroll
+            for (int j = 0; j < 8; j++) R.r[j] = frag_load<T>(p + (size_t)j * ldl);
+            R.vmask = 0xffu;
+            return;
+        }
+        unsigned vmask = 0;
         // tokens tok0..tok0+7 are consecutive source rows: decode the first, step the rest (validity is by index,
         // so stepping past the last real row is harmless: those loads go to the clamped address)
         typename Src::Ctx c = s.row_ctx(tok0 < kend ? tok0 : 0);
@@ -260,49 +298,33 @@ template <class T, int ROWS, class Src, class Xf, bool HIGH> struct TNLoader {
             const int tok = tok0 + j;
             const T* p = s.seg_ptr(c, seg);
             const bool ok = fvalid & (tok < kend) & (p != nullptr);
-            r[j] = frag_load<T>(ok ? p + off : s.safe());     // branch-free; raw rows, post-processing in store()
+            R.r[j] = frag_load<T>(ok ? p + off : s.safe());   // branch-free; raw rows, post-processing in store()
             vmask |= ok ? (1u << j) : 0u;
             c = s.advance(c);
         }
+        R.vmask = vmask;
     }
-    // Fold the FPR token-chunk threads that own the same 8 features through LDS and store the block's sums to
-    // out[row0 + feature] (plain store: `out` is this K-slice's private row of the split-K workspace).
-    // Must be called by ALL threads of the workgroup; `scratch` = >= NUNITS*8 floats of free LDS.
-    __device__ __forceinline__ void flush_colsum(float* out, int row0, float* scratch, int n_features) const {
-        if (u >= 0) {
-#pragma unroll
-            for (int f = 0; f < 8; f++) scratch[u * 8 + f] = fvalid ? csum[f] : 0.f;
-        }
-        lds_barrier();
-        if (u >= 0 && u < FC) {
-#pragma unroll
-            for (int f = 0; f < 8; f++) {
-                float a = 0.f;
-                for (int tc = 0; tc < FPR; tc++) a += scratch[(tc * FC + u) * 8 + f];
-                const int feat = row0 + u * 8 + f;
-                if (feat < n_features) out[feat] = a;
-            }
-        }
-        lds_barrier();
-    }
-    __device__ __forceinline__ void store(char* tile, const Xf& xf, int tid) {
+    __device__ __forceinline__ void store(char* tile, const Xf& xf, int tid, const Regs& R) {
         if (u < 0) return;
         frag_t<T> in[8], out[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            frag_t<T> v = r[j];
-            if (!Xf::identity) v = xf_apply<T>(v, xf);
+            in[j] = R.r[j];
+            if (!Xf::identity) in[j] = xf_apply<T>(in[j], xf);
+        }
+        if (R.vmask != 0xffu) {                               // padding rows / columns -> exact zeros
             const frag_t<T> z = frag_zero<T>();
-            v = ((vmask >> j) & 1u) ? v : z;
-            in[j] = v;
-            if (WANT_COLSUM) {
 #pragma unroll
-                for (int f = 0; f < 8; f++) csum[f] += (float)v[f];
-            }
+            for (int j = 0; j < 8; j++) in[j] = ((R.vmask >> j) & 1u) ? in[j] : z;
         }
         Transpose8<T>::run(in, out);
 #pragma unroll
-        for (int f = 0; f < 8; f++) tile_store_frag<T>(tile, (u % FC) * 8 + f, u / FC, out[f]);
+        for (int f = 0; f < 8; f++) {
+            const u32x4* src = reinterpret_cast<const u32x4*>(&out[f]);
+#pragma unroll
+            for (int c = 0; c < TileGeom<T>::CPF; c++)
+                *reinterpret_cast<u32x4*>(tile + soff[f * TileGeom<T>::CPF + c]) = src[c];
+        }
     }
 };
 
@@ -629,104 +651,56 @@ gemm_kernel(ASrc as, AXf axf, BSrc bs, BXf bxf, Ep ep, int M, int N, int K, int 
     const int ep_cu = tid % UPR, ep_row0 = tid / UPR;
     constexpr bool EARLY = ONE_K && !TN;
 
-    int seq = 0, mt, nt;
-    bool have = tile_of(0, mt, nt);
-    if (have && nk > 0) {
-        la.init(as, mt * BM, tid);
-        lb.init(bs, nt * BN, tid);
-        la.load(as, axf, kbeg, kend, tid);
-        lb.load(bs, bxf, kbeg, kend, tid);
-        la.store(smem, axf, tid);
-        lb.store(smem + BM * 128, bxf, tid);
-    }
-    // The prefetched operands of the NEXT tile are moved to LDS at the BOTTOM of the loop body, not at its top: there
-    // the compiler sees "8 loads, then this tile's output stores" on every path and waits with vmcnt(#stores).  With
-    // the move at the loop top the header merges the prologue path (loads only) with the back edge, the wait becomes
-    // vmcnt(0), and every tile stalls until its predecessor's output stores are acknowledged by memory.
-    while (have) {
-        const int m0 = mt * BM, n0 = nt * BN;
-        const int ncol = n0 + ep_cu * UNIT;
-        const bool col_ok = ep_row0 < 64 && ncol < N;
-        f32x16 acc[2][WN];
+    f32x16 acc[2][WN];
+    auto zero_acc = [&]() {
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
             for (int j = 0; j < WN; j++) acc_zero(acc[i][j]);
-
-        // Global-memory traffic of a tile, in issue order (vmcnt counts loads and stores in ONE in-order queue, so a wait
-        // for some load also waits for everything issued before it):
-        //   1. side inputs of this tile's epilogue (bias/gamma columns, residual, GELU', c_prev ...)
-        //   2. the operand prefetch of the NEXT tile
-        //   3. this tile's output stores
-        // so the epilogue arithmetic waits for (1) only, and the move of (2) into LDS at the loop bottom waits with
-        // vmcnt(#stores) and never for a store acknowledgement.  When the whole contraction is one K tile (EARLY) both
-        // are issued before the MFMA phase — a full tile time ahead of their use; with a K loop its operand loads share
-        // the loader registers, so (1) and (2) are issued after the last K tile instead.
-        typename Ep::Cols cols;
-        typename Ep::Aux aux[2][UPT];
-        int mt2 = 0, nt2 = 0;
-        bool have2 = false;
-        auto fetch_side = [&]() {
-            cols = ep.cols(ncol, col_ok);
+    };
+    // Bias gradient of a TN launch = column sums of its A operand over the K slice.  They ride on the matrix cores:
+    // A_tile . ones accumulates sum_k A[row][k] in every column of a 32x32 block, so the loader does no per-element
+    // work for them.  The two waves that share an A row panel (wn = 0/1) take one 32-row block each.
+    f32x16 colacc;
+    acc_zero(colacc);
+    frag_t<T> ones;
+#pragma unroll
+    for (int e = 0; e < 8; e++) ones[e] = (T)1.0f;
+    auto mma_stage = [&](int cur, bool with_colsum) {    // acc += A_tile . B_tile of LDS operand stage `cur`
+        const char* At = smem + cur * STAGE_BYTES;
+        const char* Bt = At + BM * 128;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ks++) {
+            const int fc = ks * 2 + (lane >> 5);
+            frag_t<T> a[2], b[WN];
+#pragma unroll
+            for (int i = 0; i < 2; i++) a[i] = tile_load_frag<T>(At, wm * 64 + i * 32 + (lane & 31), fc);
+#pragma unroll
+            for (int j = 0; j < WN; j++) b[j] = tile_load_frag<T>(Bt, wn * (BN / 2) + j * 32 + (lane & 31), fc);
 #pragma unroll
             for (int i = 0; i < 2; i++)
 #pragma unroll
-                for (int q = 0; q < UPT; q++) {
-                    const int srow = ep_row0 + q * RSTEP;
-                    const int m = m0 + (srow >> 5) * 64 + i * 32 + (srow & 31);
-                    if (col_ok && srow < 64 && m < M) aux[i][q] = ep.fetch(m, ncol);
-                }
-        };
-        auto prefetch_next = [&]() {
-            have2 = tile_of(seq + 1, mt2, nt2);
-            if (have2 && nk > 0) {
-                la.init(as, mt2 * BM, tid);
-                lb.init(bs, nt2 * BN, tid);
-                la.load(as, axf, kbeg, kend, tid);
-                lb.load(bs, bxf, kbeg, kend, tid);
+                for (int j = 0; j < WN; j++) mma32(acc[i][j], a[i], b[j]);
+            if (TN && with_colsum) {                     // workgroup-uniform
+                if (wn == 0) mma32(colacc, a[0], ones);
+                else mma32(colacc, a[1], ones);
             }
-        };
-
-        lds_barrier();
-        if (EARLY) { fetch_side(); sched_fence(); prefetch_next(); sched_fence(); }
-        for (int kt = 0; kt < nk; kt++) {
-            const int cur = kt & 1;
-            const bool more = kt + 1 < nk;
-            const char* At = smem + cur * STAGE_BYTES;
-            const char* Bt = At + BM * 128;
-            if (more) {
-                la.load(as, axf, kbeg + (kt + 1) * BK, kend, tid);
-                lb.load(bs, bxf, kbeg + (kt + 1) * BK, kend, tid);
-            }
-#pragma unroll
-            for (int ks = 0; ks < BK / 16; ks++) {
-                const int fc = ks * 2 + (lane >> 5);
-                frag_t<T> a[2], b[WN];
-#pragma unroll
-                for (int i = 0; i < 2; i++) a[i] = tile_load_frag<T>(At, wm * 64 + i * 32 + (lane & 31), fc);
-#pragma unroll
-                for (int j = 0; j < WN; j++) b[j] = tile_load_frag<T>(Bt, wn * (BN / 2) + j * 32 + (lane & 31), fc);
-#pragma unroll
-                for (int i = 0; i < 2; i++)
-#pragma unroll
-                    for (int j = 0; j < WN; j++) mma32(acc[i][j], a[i], b[j]);
-            }
-            if (more) {
-                la.store(smem + (cur ^ 1) * STAGE_BYTES, axf, tid);
-                lb.store(smem + (cur ^ 1) * STAGE_BYTES + BM * 128, bxf, tid);
-            }
-            lds_barrier();
         }
-
-        // bias gradient: per-K-slice partial column sums of the A operand -> a_colsum[slice][M]  (workgroup-uniform branch)
-        if (TN && a_colsum != nullptr && n0 == 0)
-            la.flush_colsum(a_colsum + (size_t)by * M, m0, reinterpret_cast<float*>(smem), M);
-
-        if (!EARLY) { fetch_side(); sched_fence(); prefetch_next(); }
-        sched_fence();      // the prefetch must be ISSUED here, not sunk below the epilogue
-
-        // ---- epilogue: accumulators -> LDS (fp32, row pitch BN+4) -> UNIT-wide row segments, 64 tile rows per pass
-        // (pass i = MFMA row block i of every wave: stage row wm*32+r <-> tile row wm*64+i*32+r) ----
+    };
+    // epilogue: accumulators -> LDS (fp32, row pitch BN+4) -> UNIT-wide row segments, 64 tile rows per pass
+    // (pass i = MFMA row block i of every wave: stage row wm*32+r <-> tile row wm*64+i*32+r)
+    auto side_fetch = [&](int m0, int ncol, bool col_ok, typename Ep::Cols& cols, typename Ep::Aux (&aux)[2][UPT]) {
+        cols = ep.cols(ncol, col_ok);
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int q = 0; q < UPT; q++) {
+                const int srow = ep_row0 + q * RSTEP;
+                const int m = m0 + (srow >> 5) * 64 + i * 32 + (srow & 31);
+                if (col_ok && srow < 64 && m < M) aux[i][q] = ep.fetch(m, ncol);
+            }
+    };
+    auto epilogue = [&](int m0, int ncol, bool col_ok, const typename Ep::Cols& cols, const typename Ep::Aux (&aux)[2][UPT]) {
         float* stage = reinterpret_cast<float*>(smem);
 #pragma unroll
         for (int i = 0; i < 2; i++) {
@@ -752,14 +726,142 @@ gemm_kernel(ASrc as, AXf axf, BSrc bs, BXf bxf, Ep ep, int M, int N, int K, int 
                 }
             }
         }
-        lds_barrier();            // staging buffer is reused by the next tile's operand stores
-        have = have2; mt = mt2; nt = nt2; seq++;
+    };
+
+    if constexpr (TN) {
+        // ---- split-K weight gradient: ONE output tile per workgroup, a long K (token) loop.  One workgroup per CU, so
+        // the bytes in flight ARE the prefetch depth: two K tiles (2 x 32 KiB) are kept in flight in two register sets
+        // while a third is consumed from LDS. ----
+        int mt, nt;
+        if (!tile_of(0, mt, nt)) return;
+        const int m0 = mt * BM, n0 = nt * BN;
+        const int ncol = n0 + ep_cu * UNIT;
+        const bool col_ok = ep_row0 < 64 && ncol < N;
+        typename LA::Regs R0, R1;
+        const bool want_colsum = a_colsum != nullptr && n0 == 0;
+        zero_acc();
+        la.init(as, m0, tid);
+        lb.init(bs, n0, tid);
+        if (nk > 0) {
+            la.load(as, axf, kbeg, kend, tid, R0);
+            lb.load(bs, bxf, kbeg, kend, tid, R0);
+        }
+        if (nk > 1) {
+            la.load(as, axf, kbeg + BK, kend, tid, R1);
+            lb.load(bs, bxf, kbeg + BK, kend, tid, R1);
+        }
+        if (nk > 0) {
+            la.store(smem, axf, tid, R0);
+            lb.store(smem + BM * 128, bxf, tid, R0);
+        }
+        lds_barrier();
+        // step kt: LDS stage `cur` holds K tile kt, `Rnext` holds kt+1 (in flight), `Rfree` is reloaded with kt+2
+        auto step = [&](int kt, typename LA::Regs& Rfree, typename LA::Regs& Rnext, int cur) {
+            if (kt + 2 < nk) {
+                la.load(as, axf, kbeg + (kt + 2) * BK, kend, tid, Rfree);
+                lb.load(bs, bxf, kbeg + (kt + 2) * BK, kend, tid, Rfree);
+            }
+            mma_stage(cur, want_colsum);
+            if (kt + 1 < nk) {
+                la.store(smem + (cur ^ 1) * STAGE_BYTES, axf, tid, Rnext);
+                lb.store(smem + (cur ^ 1) * STAGE_BYTES + BM * 128, bxf, tid, Rnext);
+            }
+            lds_barrier();
+        };
+        for (int kt = 0; kt < nk; kt += 2) {
+            step(kt, R0, R1, 0);
+            if (kt + 1 < nk) step(kt + 1, R1, R0, 1);
+        }
+        // bias gradient: this K slice's partial column sums of the A operand -> a_colsum[slice][M]; every column of
+        // colacc holds the same sums, lanes 0 and 32 own the 2 x 16 rows of the block
+        if (want_colsum && (lane & 31) == 0) {
+            float* cs_out = a_colsum + (size_t)by * M;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = m0 + wm * 64 + wn * 32 + acc_row(r, lane);
+                if (row < M) cs_out[row] = colacc[r];
+            }
+        }
+        typename Ep::Cols cols;
+        typename Ep::Aux aux[2][UPT];
+        side_fetch(m0, ncol, col_ok, cols, aux);
+        epilogue(m0, ncol, col_ok, cols, aux);
+    } else {
+        typename LA::Regs nr;                            // (NT loaders keep their own registers)
+        int seq = 0, mt, nt;
+        bool have = tile_of(0, mt, nt);
         if (have && nk > 0) {
+            la.init(as, mt * BM, tid);
+            lb.init(bs, nt * BN, tid);
+            la.load(as, axf, kbeg, kend, tid);
+            lb.load(bs, bxf, kbeg, kend, tid);
             la.store(smem, axf, tid);
             lb.store(smem + BM * 128, bxf, tid);
         }
+        // The prefetched operands of the NEXT tile are moved to LDS at the BOTTOM of the loop body, not at its top: there
+        // the compiler sees "8 loads, then this tile's output stores" on every path and waits with vmcnt(#stores).  With
+        // the move at the loop top the header merges the prologue path (loads only) with the back edge, the wait becomes
+        // vmcnt(0), and every tile stalls until its predecessor's output stores are acknowledged by memory.
+        while (have) {
+            const int m0 = mt * BM, n0 = nt * BN;
+            const int ncol = n0 + ep_cu * UNIT;
+            const bool col_ok = ep_row0 < 64 && ncol < N;
+            zero_acc();
+
+            // Global-memory traffic of a tile, in issue order (vmcnt counts loads and stores in ONE in-order queue, so a
+            // wait for some load also waits for everything issued before it):
+            //   1. side inputs of this tile's epilogue (bias/gamma columns, residual, GELU', c_prev ...)
+            //   2. the operand prefetch of the NEXT tile
+            //   3. this tile's output stores
+            // so the epilogue arithmetic waits for (1) only, and the move of (2) into LDS at the loop bottom waits with
+            // vmcnt(#stores) and never for a store acknowledgement.  When the whole contraction is one K tile (EARLY)
+            // both are issued before the MFMA phase — a full tile time ahead of their use; with a K loop its operand
+            // loads share the loader registers, so (1) and (2) are issued after the last K tile instead.
+            typename Ep::Cols cols;
+            typename Ep::Aux aux[2][UPT];
+            int mt2 = 0, nt2 = 0;
+            bool have2 = false;
+            auto prefetch_next = [&]() {
+                have2 = tile_of(seq + 1, mt2, nt2);
+                if (have2 && nk > 0) {
+                    la.init(as, mt2 * BM, tid);
+                    lb.init(bs, nt2 * BN, tid);
+                    la.load(as, axf, kbeg, kend, tid);
+                    lb.load(bs, bxf, kbeg, kend, tid);
+                }
+            };
+
+            lds_barrier();
+            if (EARLY) { side_fetch(m0, ncol, col_ok, cols, aux); sched_fence(); prefetch_next(); sched_fence(); }
+            for (int kt = 0; kt < nk; kt++) {
+                const int cur = kt & 1;
+                const bool more = kt + 1 < nk;
+                if (more) {
+                    la.load(as, axf, kbeg + (kt + 1) * BK, kend, tid);
+                    lb.load(bs, bxf, kbeg + (kt + 1) * BK, kend, tid);
+                }
+                mma_stage(cur, false);
+                if (more) {
+                    la.store(smem + (cur ^ 1) * STAGE_BYTES, axf, tid);
+                    lb.store(smem + (cur ^ 1) * STAGE_BYTES + BM * 128, bxf, tid);
+                }
+                lds_barrier();
+            }
+            if (!EARLY) { side_fetch(m0, ncol, col_ok, cols, aux); sched_fence(); prefetch_next(); }
+            sched_fence();      // the prefetch must be ISSUED here, not sunk below the epilogue
+
+            epilogue(m0, ncol, col_ok, cols, aux);
+            lds_barrier();            // staging buffer is reused by the next tile's operand stores
+            have = have2; mt = mt2; nt = nt2; seq++;
+            if (have && nk > 0) {
+                la.store(smem, axf, tid);
+                lb.store(smem + BM * 128, bxf, tid);
+            }
+        }
+        (void)nr;
     }
 }
+
 
 inline int gemm_slices(int K, int ksplit, int BK) {
     if (ksplit < 1) ksplit = 1;
