@@ -37,10 +37,18 @@ static inline int grid_for(size_t units, int cap = 2048) {
     return (int)(g > (size_t)cap ? cap : g);
 }
 // split the token contraction of a weight gradient so that the launch fills the chip
+// output-tile width of the weight-gradient kernels: 128x64 tiles run two workgroups per CU (registers), 128x128 one
+static inline int wgrad_bn(int out_cols) {
+    static const int forced = getenv("RVT_WGRAD_BN") ? atoi(getenv("RVT_WGRAD_BN")) : 0;                   // tuning knob
+    if (forced == 64 || forced == 128) return forced;
+    return out_cols <= 64 ? 64 : 128;
+}
 static inline int wgrad_ksplit(int out_rows, int out_cols, int tokens, int bn) {
     static const int split_override = getenv("RVT_WGRAD_BLOCKS") ? atoi(getenv("RVT_WGRAD_BLOCKS")) : 0;   // tuning knob
     int tiles = ((out_rows + 127) / 128) * ((out_cols + bn - 1) / bn);
-    int want = imax(1, (split_override > 0 ? split_override : 256) / imax(1, tiles));   // ~one workgroup per CU (measured best)
+    // as many workgroups as are resident at once (measured: 2/CU for the 128x64 kernel 5.9 TB/s vs 4.2 at 1/CU; the
+    // 128x128 kernel holds one per CU and loses with more)
+    int want = imax(1, (split_override > 0 ? split_override : (bn == 64 ? 512 : 256)) / imax(1, tiles));
     int maxs = imax(1, tokens / 512);
     int ks = imin(want, maxs);
     if (ks >= 16) ks = ks / 8 * 8;             // multiple of 8 slices: tiles of one slice can share an XCD's L2
@@ -92,6 +100,12 @@ static void launch_wgrad(const ASrc& a, const BSrc& b, const BXf& bxf, float* ou
         else { constexpr int BN = 128; __VA_ARGS__; }                \
     } while (0)
 
+#define DISPATCH_WGRAD_BN(N, ...)                                    \
+    do {                                                             \
+        if (wgrad_bn(N) == 64) { constexpr int BN = 64; __VA_ARGS__; } \
+        else { constexpr int BN = 128; __VA_ARGS__; }                \
+    } while (0)
+
 extern "C" {
 
 const char* rvt_last_error(void) { return g_err; }
@@ -105,7 +119,7 @@ int rvt_is_emulator(void) {
 }
 
 size_t rvt_wgrad_workspace_floats(int dtype, int out_rows, int out_cols, int tokens, int want_colsum) {
-    int bn = out_cols <= 64 ? 64 : 128;
+    int bn = wgrad_bn(out_cols);
     int bk = dtype == RVT_F32 ? TileGeom<float>::BK : TileGeom<bf16>::BK;
     return wgrad_ws_floats(out_rows, out_cols, tokens, bn, bk, want_colsum);
 }
@@ -159,7 +173,7 @@ int rvt_conv_wgrad(const void* in, const void* dy, float* dw, float* ws, int dty
     DISPATCH_DTYPE(dtype, {
         Im2colSrc<T> b = make_im2col<T>(in, F, H, W, Cin, k, stride, pad);
         PlainSrc<T> a{(const T*)dy, Cout, b.rows, Cout};
-        DISPATCH_BN(b.cols, (launch_wgrad<T, BN>(a, b, XfNone(), dw, nullptr, ws, Cout, b.cols, b.rows, st)));
+        DISPATCH_WGRAD_BN(b.cols, (launch_wgrad<T, BN>(a, b, XfNone(), dw, nullptr, ws, Cout, b.cols, b.rows, st)));
     });
     return check_launch("conv_wgrad");
 }
@@ -312,7 +326,7 @@ int rvt_linear_wgrad(const void* dy, const void* x, float* dw, float* dy_colsum,
     DISPATCH_DTYPE(dtype, {
         PlainSrc<T> a{(const T*)dy, N, M, N};
         PlainSrc<T> b{(const T*)x, K, M, K};
-        DISPATCH_BN(K, {
+        DISPATCH_WGRAD_BN(K, {
             if (gelu_in) launch_wgrad<T, BN>(a, b, XfGelu(), dw, dy_colsum, ws, N, K, M, st);
             else launch_wgrad<T, BN>(a, b, XfNone(), dw, dy_colsum, ws, N, K, M, st);
         });
@@ -466,7 +480,7 @@ int rvt_lstm_wgrad(const void* dz, const void* x, const void* h_prev, float* dw,
     DISPATCH_DTYPE(dtype, {
         PlainSrc<T> a{(const T*)dz, 4 * C, M, 4 * C};
         ConcatSrc<T> b{(const T*)x, (const T*)h_prev, C, M, 2 * C};
-        DISPATCH_BN(2 * C, (launch_wgrad<T, BN>(a, b, XfNone(), dw, dz_colsum, ws, 4 * C, 2 * C, M, st)));
+        DISPATCH_WGRAD_BN(2 * C, (launch_wgrad<T, BN>(a, b, XfNone(), dw, dz_colsum, ws, 4 * C, 2 * C, M, st)));
     });
     return check_launch("lstm_wgrad");
 }
