@@ -128,7 +128,9 @@ int rvt_prepack_input(const void* src, int src_u8, void* dst, int dtype, int F, 
                       int Cp, void* stream) {
     RVT_CHECK(Cp % 8 == 0 && Cp >= Cin && H >= h && W >= w, "prepack: bad shape Cp=%d Cin=%d", Cp, Cin);
     hipStream_t st = (hipStream_t)stream;
-    int grid = grid_for((size_t)F * H * W * (Cp / 8), 8192);
+    RVT_CHECK(Cin <= 32, "prepack: Cin=%d > 32 staged channels", Cin);
+    size_t items = (size_t)F * H * ((W + PREPACK_SEG - 1) / PREPACK_SEG);
+    int grid = (int)(items < 16384 ? (items < 1 ? 1 : items) : 16384);
     DISPATCH_DTYPE(dtype, {
         if (src_u8)
             hipLaunchKernelGGL((prepack_kernel<T, unsigned char>), dim3(grid), dim3(256), 0, st,
@@ -350,7 +352,7 @@ static int mlp_tm(int dtype, int C) {
 static int mlp_grid(int dtype, int C, int M, int tm) {
     static const int resident_override = getenv("RVT_GEMM_RESIDENT") ? atoi(getenv("RVT_GEMM_RESIDENT")) : 0;
     const int n_tiles = (M + tm - 1) / tm;
-    const int per_cu = dtype == RVT_BF16 ? (C == 64 && tm == 64 ? 3 : 2) : 2;
+    const int per_cu = (dtype == RVT_BF16 && C == 64 && tm == 64) ? 2 : 1;   // resident workgroups per CU (registers; see the kernels' launch bounds)
     return imax(1, imin(n_tiles, resident_override > 0 ? resident_override : 256 * per_cu));
 }
 

@@ -171,33 +171,35 @@ __device__ __forceinline__ float fast_rcp(float x) {
     return __builtin_amdgcn_rcpf(x);        // v_rcp_f32, 1 ulp
 #endif
 }
-// erf(z) by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. at fp32 round-off): one v_exp, one v_rcp, a
-// 5-term Horner — ~12 VALU ops instead of the ~100-op libm erff.  Also returns e = exp(-z*z), which the GELU
-// derivative needs anyway (exp(-x^2/2) with z = x/sqrt2).
-__device__ __forceinline__ float erf_as(float z, float& e) {
-    const float az = fabsf(z);
-    const float t = fast_rcp(1.0f + 0.3275911f * az);
-    e = __expf(-z * z);
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float r = 1.0f - poly * e;
-    return z < 0.0f ? -r : r;
+// erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. at fp32 round-off): one v_exp, one v_rcp, a 5-term Horner
+// instead of the ~100-op libm erff.
+// exact-erf GELU of the reference (layers/activations.py:138-145) and its derivative.  The fc1 epilogues that evaluate
+// them are VALU-bound (79 G evaluations per RVT-Base step-stage), so the A&S form is folded for the fewest instructions:
+//   q = 0.5 * poly(t) * exp(-x^2/2),  t = 1/(1 + p/sqrt2 |x|);   Phi(x) = x < 0 ? q : 1 - q;   g = x Phi,  g' = Phi + x phi(x)
+// (halved coefficients, |x| as a source modifier, exp through one v_exp_f32: 14 plain + 2 quarter-rate instructions
+// for both values).
+__device__ __forceinline__ float gelu_phi(float x, float& e) {                    // Phi(x); e = exp(-x^2/2)
+    const float t = fast_rcp(fmaf(0.23164189f, fabsf(x), 1.0f));                 // 0.3275911 / sqrt(2)
+    e = fast_exp2(x * x * -0.72134752044448170f);                                 // 2^(-x^2 log2(e) / 2)
+    const float poly = t * (0.127414796f + t * (-0.142248368f + t * (0.7107068705f + t * (-0.7265760135f + t * 0.5307027145f))));
+    const float q = poly * e;
+    return x < 0.0f ? q : 1.0f - q;
 }
-// exact-erf GELU of the reference (layers/activations.py:138-145) and its derivative
 __device__ __forceinline__ float gelu_f(float x) {
     float e;
-    return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f, e));
+    return x * gelu_phi(x, e);
 }
 __device__ __forceinline__ float gelu_grad_f(float x) {
     float e;
-    const float er = erf_as(x * 0.70710678118654752f, e);
-    return 0.5f * (1.0f + er) + x * 0.3989422804014327f * e;
+    const float c = gelu_phi(x, e);
+    return fmaf(x * 0.3989422804014327f, e, c);
 }
-// both at once (one erf/exp evaluation): used by the fc1 epilogue that saves GELU(x) and GELU'(x)
+// both at once (one evaluation): used by the fc1 epilogues that save GELU(x) and GELU'(x)
 __device__ __forceinline__ void gelu_both_f(float x, float& g, float& gp) {
     float e;
-    const float c = 0.5f * (1.0f + erf_as(x * 0.70710678118654752f, e));
+    const float c = gelu_phi(x, e);
     g = x * c;
-    gp = c + x * 0.3989422804014327f * e;
+    gp = fmaf(x * 0.3989422804014327f, e, c);
 }
 __device__ __forceinline__ float sigmoid_f(float x) { return fast_rcp(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanh_f(float x) {

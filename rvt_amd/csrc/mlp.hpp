@@ -116,9 +116,59 @@ template <class T, int C, int TM> struct TileSlots {
     static_assert(NFX >= 1, "tile too small for 256 threads");
 };
 
+// Global-memory schedule shared by both kernels (see the GEMM epilogue notes in gemm.hpp: loads and stores retire
+// through ONE in-order counter, so a load issued after a store cannot be waited for without also waiting for that
+// store's acknowledgement):
+//   * everything a stretch of code reads from global memory is issued BEFORE the stores of the stretch preceding it:
+//     the next tile's rows at the top of the current tile, the next hidden chunk's weight panels (and gp rows) at
+//     the top of the current chunk — one full tile / chunk ahead of their use;
+//   * per-thread column constants (LayerNorm weights, LayerScale, b2) live in registers for the whole launch;
+//   * prefetched registers are moved to LDS at the BOTTOM of the loop that consumes them, where every path has
+//     issued the same loads and stores, so the compiler's wait counts exclude the stores.
+template <class T, int C, int TM> struct MlpPanels {       // register image of one hidden chunk's two weight panels
+    static constexpr int JC = MlpGeom<T>::JC;
+    static constexpr int F1 = C / 8, F2 = JC / 8;            // 16-byte frags per row of panel 1 [JC][C] / panel 2 [C][JC]
+    static constexpr int N1 = JC * F1 / 256, N2 = C * F2 / 256;
+    static_assert(N1 >= 1 && N2 >= 1 && (JC * F1) % 256 == 0 && (C * F2) % 256 == 0, "weight panel / thread mapping");
+    frag_t<T> r1[N1], r2[N2];
+    // panel 1 = rows j0.. of P1 ([4C][C] row-major), panel 2 = columns j0.. of P2 ([C][4C] row-major)
+    __device__ __forceinline__ void load(const T* P1, const T* P2, int j0, int tid) {
+#pragma unroll
+        for (int i = 0; i < N1; i++) {
+            const int f = tid + i * 256;
+            r1[i] = frag_load<T>(P1 + (size_t)(j0 + f / F1) * C + (f % F1) * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < N2; i++) {
+            const int f = tid + i * 256;
+            r2[i] = frag_load<T>(P2 + (size_t)(f / F2) * (4 * C) + j0 + (f % F2) * 8);
+        }
+    }
+    __device__ __forceinline__ void store(char* B1, char* B2, int tid) const {
+#pragma unroll
+        for (int i = 0; i < N1; i++) {
+            const int f = tid + i * 256;
+            opm_store_frag<T>(B1, JC, f / F1, f % F1, r1[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < N2; i++) {
+            const int f = tid + i * 256;
+            opm_store_frag<T>(B2, C, f / F2, f % F2, r2[i]);
+        }
+    }
+};
+
+template <int N> __device__ __forceinline__ void load_cols(const float* p, int c0, float (&v)[N]) {
+#pragma unroll
+    for (int q = 0; q < N / 4; q++) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(p + c0 + q * 4);
+        v[q * 4 + 0] = t[0]; v[q * 4 + 1] = t[1]; v[q * 4 + 2] = t[2]; v[q * 4 + 3] = t[3];
+    }
+}
+
 // ===================================================================================================== forward
 template <class T, int C, int TM>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, (sizeof(T) == 2 && C == 64 && TM == 64) ? 2 : 1)
 mlp_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, T* __restrict__ g_out, T* __restrict__ gp_out,
                const float* __restrict__ ln_w, const float* __restrict__ ln_b, const T* __restrict__ W1,
                const float* __restrict__ b1, const T* __restrict__ W2, const float* __restrict__ b2,
@@ -130,6 +180,8 @@ mlp_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, T* __restrict__
     constexpr int NJ1 = JC / 64, NJ2 = C / 64;
     constexpr int LD1 = JC + 4, LD2 = C + 4;
     constexpr int UPR1 = JC / 8;                           // 8-column units per staged row (fc1 side)
+    constexpr int UPT1 = 64 * UPR1 / 256;                  // units per thread per 64-row pass
+    static_assert(256 % G == 0 && 256 % UPR1 == 0 && UPT1 >= 1, "a thread keeps one column chunk");
     __shared__ __attribute__((aligned(16))) char smem[S::BYTES];
     char* const Ax = smem;
     char* const B1 = smem + S::OFF_1;
@@ -140,18 +192,28 @@ mlp_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, T* __restrict__
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int n_tiles = (M + TM - 1) / TM;
+    const int cl = tid % G;                                // this thread's 8-channel chunk in the (row, chunk) layout
+    const int cu = tid % UPR1;                             // ... and its 8-column unit of a hidden chunk
+    float lnw[8], lnb[8], gam[8], b2v[8];
+    load_cols<8>(ln_w, cl * 8, lnw); load_cols<8>(ln_b, cl * 8, lnb);
+    load_cols<8>(gamma, cl * 8, gam); load_cols<8>(b2, cl * 8, b2v);
 
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int m0 = tile * TM;
-        // ---- load + LayerNorm (maxvit.py:241) ----
-        frag_t<T> raw[NFX];
+    auto load_rows = [&](int tile, frag_t<T> (&r)[NFX]) {
 #pragma unroll
         for (int q = 0; q < NFX; q++) {
-            const int f = tid + q * 256, row = f / G, cl = f % G;
-            const bool ok = m0 + row < M;
+            const int row = (tid + q * 256) / G;
+            const bool ok = tile * TM + row < M;
+            r[q] = frag_load<T>(xmid + (size_t)(ok ? tile * TM + row : 0) * C + cl * 8);
+        }
+    };
+    // LayerNorm (maxvit.py:241) of a tile held in registers -> A operand of fc1
+    auto norm_to_lds = [&](int tile, const frag_t<T> (&r)[NFX]) {
+#pragma unroll
+        for (int q = 0; q < NFX; q++) {
+            const int row = (tid + q * 256) / G;
+            const bool ok = tile * TM + row < M;
             float v[8];
-            raw[q] = frag_load<T>(xmid + (size_t)(ok ? m0 + row : 0) * C + cl * 8);
-            frag_to_float<T>(raw[q], v);
+            frag_to_float<T>(r[q], v);
             float s = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; e++) s += v[e];
@@ -162,9 +224,25 @@ mlp_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, T* __restrict__
             const float rstd = 1.0f / sqrtf(group_sum(qq, G) / (float)C + eps);
             float o[8];
 #pragma unroll
-            for (int e = 0; e < 8; e++) o[e] = ok ? (v[e] - mean) * rstd * ln_w[cl * 8 + e] + ln_b[cl * 8 + e] : 0.f;
+            for (int e = 0; e < 8; e++) o[e] = ok ? (v[e] - mean) * rstd * lnw[e] + lnb[e] : 0.f;
             opm_store_frag<T>(Ax, TM, row, cl, frag_from_float<T>(o));
         }
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    frag_t<T> raw[NFX], nxt[NFX];
+    MlpPanels<T, C, TM> wp;
+    load_rows(tile, raw);
+    wp.load(W1, W2, 0, tid);
+    norm_to_lds(tile, raw);
+    wp.store(B1, B2, tid);
+
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const int m0 = tile * TM;
+        const int tile2 = tile + gridDim.x;
+        const bool have2 = tile2 < n_tiles;
+        if (have2) load_rows(tile2, nxt);
 
         f32x16 acc2[MI][NJ2];
 #pragma unroll
@@ -173,9 +251,13 @@ mlp_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, T* __restrict__
             for (int j = 0; j < NJ2; j++) acc_zero(acc2[i][j]);
 
         for (int j0 = 0; j0 < HID; j0 += JC) {
-            opm_stage<T>(B1, W1 + (size_t)j0 * C, C, JC, C, tid);               // W1 rows j0.., all C columns
-            opm_stage<T>(B2, W2 + j0, HID, C, JC, tid);                         // W2[:, j0..j0+JC)
-            lds_barrier();
+            const bool last = j0 + JC >= HID;
+            lds_barrier();                                                     // this chunk's panels (and Ax) are in LDS
+            if (!last) wp.load(W1, W2, j0 + JC, tid);
+            else if (have2) wp.load(W1, W2, 0, tid);
+            float b1v[8];
+            load_cols<8>(b1, j0 + cu * 8, b1v);
+            sched_fence();
             f32x16 acc1[MI][NJ1];
 #pragma unroll
             for (int i = 0; i < MI; i++)
@@ -188,13 +270,14 @@ mlp_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, T* __restrict__
                 if (i) lds_barrier();
                 stage_pass<MI, NJ1>(stage, LD1, acc1, i, wm, wn, lane);
                 lds_barrier();
-                for (int u = tid; u < 64 * UPR1; u += 256) {
-                    const int srow = u / UPR1, cu = u % UPR1;
+#pragma unroll
+                for (int q = 0; q < UPT1; q++) {
+                    const int srow = tid / UPR1 + q * (256 / UPR1);
                     const int row = stage_row_to_tile_row<MI>(srow, i);
                     float v[8], a[8], b[8];
                     stage_read8(stage, LD1, srow, cu * 8, v);
 #pragma unroll
-                    for (int e = 0; e < 8; e++) gelu_both_f(v[e] + b1[j0 + cu * 8 + e], a[e], b[e]);
+                    for (int e = 0; e < 8; e++) gelu_both_f(v[e] + b1v[e], a[e], b[e]);
                     const frag_t<T> gf = frag_from_float<T>(a);
                     opm_store_frag<T>(Ah, TM, row, cu, gf);
                     if (g_out != nullptr && m0 + row < M) {
@@ -207,6 +290,7 @@ mlp_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, T* __restrict__
             lds_barrier();
             opm_mma<T, MI, NJ2>(acc2, Ah, TM, wm * 32 * MI, B2, C, wn * (C / 2), JC, lane);
             lds_barrier();                                                     // Ah / B2 / staging free for the next chunk
+            if (!last) wp.store(B1, B2, tid);
         }
 
         // ---- LayerScale + residual (maxvit.py:51-53,269) in the load layout: the residual is still in registers ----
@@ -217,19 +301,25 @@ mlp_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, T* __restrict__
             lds_barrier();
 #pragma unroll
             for (int q = 0; q < NFX; q++) {
-                const int f = tid + q * 256, row = f / G, cl = f % G;
+                const int row = (tid + q * 256) / G;
                 if (((row >> 5) % MI) != i) continue;
                 if (m0 + row < M) {
                     float v[8], res[8];
                     frag_to_float<T>(raw[q], res);
                     stage_read8(stage, LD2, (row / (32 * MI)) * 32 + (row & 31), cl * 8, v);
 #pragma unroll
-                    for (int e = 0; e < 8; e++) v[e] = res[e] + gamma[cl * 8 + e] * (v[e] + b2[cl * 8 + e]);
+                    for (int e = 0; e < 8; e++) v[e] = res[e] + gam[e] * (v[e] + b2v[e]);
                     frag_store<T>(xout + (size_t)(m0 + row) * C + cl * 8, frag_from_float<T>(v));
                 }
             }
         }
-        lds_barrier();
+        lds_barrier();                                                         // staging (over B1 .. B2) is free again
+        if (have2) {
+            wp.store(B1, B2, tid);
+#pragma unroll
+            for (int q = 0; q < NFX; q++) raw[q] = nxt[q];
+            norm_to_lds(tile2, raw);
+        }
     }
 }
 
@@ -238,7 +328,7 @@ mlp_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, T* __restrict__
 // dv2[m][C]   = dh W1                                      W1^T stored [C][4C]                    ("fc1_wt")
 // dxmid       = dxout + LN2'(dv2; xmid)                    dln_w += dv2 * xhat, dln_b += dv2
 template <class T, int C, int TM>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, (sizeof(T) == 2 && C == 64 && TM == 64) ? 2 : 1)
 mlp_bwd_dgrad_kernel(const T* __restrict__ dxout, const T* __restrict__ gp, const T* __restrict__ xmid, T* __restrict__ dh,
                      T* __restrict__ dxmid, const float* __restrict__ ln_w, const T* __restrict__ W2gT,
                      const T* __restrict__ W1T, float* __restrict__ dln_w, float* __restrict__ dln_b, int M, float eps) {
@@ -249,6 +339,8 @@ mlp_bwd_dgrad_kernel(const T* __restrict__ dxout, const T* __restrict__ gp, cons
     constexpr int NJ1 = JC / 64, NJ2 = C / 64;
     constexpr int LD1 = JC + 4, LD2 = C + 4;
     constexpr int UPR1 = JC / 8;
+    constexpr int UPT1 = 64 * UPR1 / 256;
+    static_assert(256 % G == 0 && 256 % UPR1 == 0 && UPT1 >= 1, "a thread keeps one column chunk");
     __shared__ __attribute__((aligned(16))) char smem[S::BYTES];
     char* const Ax = smem;                                  // dxout tile
     char* const B1 = smem + S::OFF_1;                       // W2g^T rows j0..: [JC][C]
@@ -259,26 +351,45 @@ mlp_bwd_dgrad_kernel(const T* __restrict__ dxout, const T* __restrict__ gp, cons
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int n_tiles = (M + TM - 1) / TM;
-    const int cl_own = tid % G;                             // every slot of this thread has the same channel chunk
-    float aw[8], ab[8];
+    const int cl = tid % G;                                 // every slot of this thread has the same channel chunk
+    const int cu = tid % UPR1;
+    float lnw[8], aw[8], ab[8];
+    load_cols<8>(ln_w, cl * 8, lnw);
 #pragma unroll
     for (int e = 0; e < 8; e++) { aw[e] = 0.f; ab[e] = 0.f; }
 
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int m0 = tile * TM;
-        frag_t<T> rawdx[NFX], rawx[NFX];
-        float mean[NFX], rstd[NFX];
+    auto load_rows = [&](int tile, frag_t<T> (&rdx)[NFX], frag_t<T> (&rx)[NFX]) {
 #pragma unroll
         for (int q = 0; q < NFX; q++) {
-            const int f = tid + q * 256, row = f / G, cl = f % G;
-            const bool ok = m0 + row < M;
-            const size_t o = (size_t)(ok ? m0 + row : 0) * C + cl * 8;
-            rawdx[q] = frag_load<T>(dxout + o);
-            rawx[q] = frag_load<T>(xmid + o);
+            const int row = (tid + q * 256) / G;
+            const bool ok = tile * TM + row < M;
+            const size_t o = (size_t)(ok ? tile * TM + row : 0) * C + cl * 8;
+            rdx[q] = frag_load<T>(dxout + o);
+            rx[q] = frag_load<T>(xmid + o);
+        }
+    };
+    // gp rows of hidden chunk j0 this thread multiplies with: unit (pass i, slot q)
+    auto load_gp = [&](int tile, int j0, frag_t<T> (&r)[MI][UPT1]) {
+#pragma unroll
+        for (int i = 0; i < MI; i++)
+#pragma unroll
+            for (int q = 0; q < UPT1; q++) {
+                const int row = stage_row_to_tile_row<MI>(tid / UPR1 + q * (256 / UPR1), i);
+                const bool ok = tile * TM + row < M;
+                r[i][q] = frag_load<T>(gp + (size_t)(ok ? tile * TM + row : 0) * HID + j0 + cu * 8);
+            }
+    };
+    float mean[NFX], rstd[NFX];
+    // dxout tile -> A operand of the fc2 input gradient; LayerNorm statistics of the xmid tile
+    auto stage_tile = [&](int tile, const frag_t<T> (&rdx)[NFX], const frag_t<T> (&rx)[NFX]) {
+#pragma unroll
+        for (int q = 0; q < NFX; q++) {
+            const int row = (tid + q * 256) / G;
+            const bool ok = tile * TM + row < M;
             const frag_t<T> z = frag_zero<T>();
-            opm_store_frag<T>(Ax, TM, row, cl, ok ? rawdx[q] : z);
+            opm_store_frag<T>(Ax, TM, row, cl, ok ? rdx[q] : z);
             float v[8];
-            frag_to_float<T>(rawx[q], v);
+            frag_to_float<T>(rx[q], v);
             float s = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; e++) s += v[e];
@@ -288,87 +399,131 @@ mlp_bwd_dgrad_kernel(const T* __restrict__ dxout, const T* __restrict__ gp, cons
             for (int e = 0; e < 8; e++) { const float d = v[e] - mean[q]; qq += d * d; }
             rstd[q] = 1.0f / sqrtf(group_sum(qq, G) / (float)C + eps);
         }
+    };
 
-        f32x16 acc2[MI][NJ2];
-#pragma unroll
-        for (int i = 0; i < MI; i++)
-#pragma unroll
-            for (int j = 0; j < NJ2; j++) acc_zero(acc2[i][j]);
+    int tile = blockIdx.x;
+    if (tile < n_tiles) {
+        frag_t<T> rawdx[NFX], rawx[NFX], ndx[NFX], nx[NFX], gpr[MI][UPT1];
+        MlpPanels<T, C, TM> wp;
+        load_rows(tile, rawdx, rawx);
+        wp.load(W2gT, W1T, 0, tid);
+        load_gp(tile, 0, gpr);
+        stage_tile(tile, rawdx, rawx);
+        wp.store(B1, B2, tid);
 
-        for (int j0 = 0; j0 < HID; j0 += JC) {
-            opm_stage<T>(B1, W2gT + (size_t)j0 * C, C, JC, C, tid);             // rows j0.. of (W2 gamma)^T
-            opm_stage<T>(B2, W1T + j0, HID, C, JC, tid);                        // W1^T[:, j0..j0+JC)
-            lds_barrier();
-            f32x16 acc1[MI][NJ1];
+        for (; tile < n_tiles; tile += gridDim.x) {
+            const int m0 = tile * TM;
+            const int tile2 = tile + gridDim.x;
+            const bool have2 = tile2 < n_tiles;
+            if (have2) load_rows(tile2, ndx, nx);
+
+            f32x16 acc2[MI][NJ2];
 #pragma unroll
             for (int i = 0; i < MI; i++)
 #pragma unroll
-                for (int j = 0; j < NJ1; j++) acc_zero(acc1[i][j]);
-            opm_mma<T, MI, NJ1>(acc1, Ax, TM, wm * 32 * MI, B1, JC, wn * (JC / 2), C, lane);
-            lds_barrier();
+                for (int j = 0; j < NJ2; j++) acc_zero(acc2[i][j]);
+
+            for (int j0 = 0; j0 < HID; j0 += JC) {
+                const bool last = j0 + JC >= HID;
+                lds_barrier();
+                if (!last) wp.load(W2gT, W1T, j0 + JC, tid);
+                else if (have2) wp.load(W2gT, W1T, 0, tid);
+                sched_fence();
+                f32x16 acc1[MI][NJ1];
+#pragma unroll
+                for (int i = 0; i < MI; i++)
+#pragma unroll
+                    for (int j = 0; j < NJ1; j++) acc_zero(acc1[i][j]);
+                opm_mma<T, MI, NJ1>(acc1, Ax, TM, wm * 32 * MI, B1, JC, wn * (JC / 2), C, lane);
+                lds_barrier();
+#pragma unroll
+                for (int i = 0; i < MI; i++) {
+                    if (i) lds_barrier();
+                    stage_pass<MI, NJ1>(stage, LD1, acc1, i, wm, wn, lane);
+                    lds_barrier();
+                    frag_t<T> df[UPT1];
+#pragma unroll
+                    for (int q = 0; q < UPT1; q++) {
+                        const int srow = tid / UPR1 + q * (256 / UPR1);
+                        const int row = stage_row_to_tile_row<MI>(srow, i);
+                        const bool ok = m0 + row < M;
+                        float v[8], p[8];
+                        stage_read8(stage, LD1, srow, cu * 8, v);
+                        frag_to_float<T>(gpr[i][q], p);
+#pragma unroll
+                        for (int e = 0; e < 8; e++) v[e] = ok ? v[e] * p[e] : 0.f;
+                        df[q] = frag_from_float<T>(v);
+                    }
+                    // this pass's gp registers are consumed: refill them for the next chunk BEFORE the dh stores go out
+#pragma unroll
+                    for (int q = 0; q < UPT1; q++) {
+                        const int row = stage_row_to_tile_row<MI>(tid / UPR1 + q * (256 / UPR1), i);
+                        const int t2 = last ? tile2 : tile;
+                        const int jn = last ? 0 : j0 + JC;
+                        const bool ok2 = (!last || have2) && (t2 * TM + row < M);
+                        gpr[i][q] = frag_load<T>(gp + (size_t)(ok2 ? t2 * TM + row : 0) * HID + jn + cu * 8);
+                    }
+                    sched_fence();
+#pragma unroll
+                    for (int q = 0; q < UPT1; q++) {
+                        const int srow = tid / UPR1 + q * (256 / UPR1);
+                        const int row = stage_row_to_tile_row<MI>(srow, i);
+                        opm_store_frag<T>(Ah, TM, row, cu, df[q]);
+                        if (m0 + row < M) frag_store<T>(dh + (size_t)(m0 + row) * HID + j0 + cu * 8, df[q]);
+                    }
+                }
+                lds_barrier();
+                opm_mma<T, MI, NJ2>(acc2, Ah, TM, wm * 32 * MI, B2, C, wn * (C / 2), JC, lane);
+                lds_barrier();
+                if (!last) wp.store(B1, B2, tid);
+            }
+
+            // ---- LayerNorm backward + residual, in the load layout (all lanes of a row group take part in the shuffles) ----
 #pragma unroll
             for (int i = 0; i < MI; i++) {
                 if (i) lds_barrier();
-                stage_pass<MI, NJ1>(stage, LD1, acc1, i, wm, wn, lane);
+                stage_pass<MI, NJ2>(stage, LD2, acc2, i, wm, wn, lane);
                 lds_barrier();
-                for (int u = tid; u < 64 * UPR1; u += 256) {
-                    const int srow = u / UPR1, cu = u % UPR1;
-                    const int row = stage_row_to_tile_row<MI>(srow, i);
-                    const bool ok = m0 + row < M;
-                    const size_t o = (size_t)(ok ? m0 + row : 0) * HID + j0 + cu * 8;
-                    float v[8], p[8];
-                    stage_read8(stage, LD1, srow, cu * 8, v);
-                    frag_to_float<T>(frag_load<T>(gp + o), p);
 #pragma unroll
-                    for (int e = 0; e < 8; e++) v[e] = ok ? v[e] * p[e] : 0.f;
-                    const frag_t<T> df = frag_from_float<T>(v);
-                    opm_store_frag<T>(Ah, TM, row, cu, df);
-                    if (ok) frag_store<T>(dh + o, df);
+                for (int q = 0; q < NFX; q++) {
+                    const int row = (tid + q * 256) / G;
+                    const bool mine = ((row >> 5) % MI) == i;         // uniform over the G lanes of a row
+                    const bool ok = mine && (m0 + row < M);
+                    float d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, xv[8], dxv[8], xh[8];
+                    if (mine) stage_read8(stage, LD2, (row / (32 * MI)) * 32 + (row & 31), cl * 8, d);
+                    frag_to_float<T>(rawx[q], xv);
+                    frag_to_float<T>(rawdx[q], dxv);
+                    float gsum = 0.f, gxsum = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        d[e] = ok ? d[e] : 0.f;
+                        xh[e] = ok ? (xv[e] - mean[q]) * rstd[q] : 0.f;
+                        const float g_ = d[e] * lnw[e];
+                        gsum += g_; gxsum += g_ * xh[e];
+                        aw[e] += d[e] * xh[e]; ab[e] += d[e];
+                    }
+                    const float m1 = group_sum(gsum, G) / (float)C;
+                    const float m2 = group_sum(gxsum, G) / (float)C;
+                    if (ok) {
+                        float o[8];
+#pragma unroll
+                        for (int e = 0; e < 8; e++) o[e] = dxv[e] + rstd[q] * (d[e] * lnw[e] - m1 - xh[e] * m2);
+                        frag_store<T>(dxmid + (size_t)(m0 + row) * C + cl * 8, frag_from_float<T>(o));
+                    }
                 }
             }
             lds_barrier();
-            opm_mma<T, MI, NJ2>(acc2, Ah, TM, wm * 32 * MI, B2, C, wn * (C / 2), JC, lane);
-            lds_barrier();
-        }
-
-        // ---- LayerNorm backward + residual, in the load layout (all lanes of a row group take part in the shuffles) ----
+            if (have2) {
+                wp.store(B1, B2, tid);
 #pragma unroll
-        for (int i = 0; i < MI; i++) {
-            if (i) lds_barrier();
-            stage_pass<MI, NJ2>(stage, LD2, acc2, i, wm, wn, lane);
-            lds_barrier();
-#pragma unroll
-            for (int q = 0; q < NFX; q++) {
-                const int f = tid + q * 256, row = f / G, cl = f % G;
-                const bool mine = ((row >> 5) % MI) == i;         // uniform over the G lanes of a row
-                const bool ok = mine && (m0 + row < M);
-                float d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, xv[8], dxv[8], xh[8];
-                if (mine) stage_read8(stage, LD2, (row / (32 * MI)) * 32 + (row & 31), cl * 8, d);
-                frag_to_float<T>(rawx[q], xv);
-                frag_to_float<T>(rawdx[q], dxv);
-                float gsum = 0.f, gxsum = 0.f;
-#pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    d[e] = ok ? d[e] : 0.f;
-                    xh[e] = ok ? (xv[e] - mean[q]) * rstd[q] : 0.f;
-                    const float g_ = d[e] * ln_w[cl * 8 + e];
-                    gsum += g_; gxsum += g_ * xh[e];
-                    aw[e] += d[e] * xh[e]; ab[e] += d[e];
-                }
-                const float m1 = group_sum(gsum, G) / (float)C;
-                const float m2 = group_sum(gxsum, G) / (float)C;
-                if (ok) {
-                    float o[8];
-#pragma unroll
-                    for (int e = 0; e < 8; e++) o[e] = dxv[e] + rstd[q] * (d[e] * ln_w[cl * 8 + e] - m1 - xh[e] * m2);
-                    frag_store<T>(dxmid + (size_t)(m0 + row) * C + cl * 8, frag_from_float<T>(o));
-                }
+                for (int q = 0; q < NFX; q++) { rawdx[q] = ndx[q]; rawx[q] = nx[q]; }
+                stage_tile(tile2, rawdx, rawx);
             }
         }
-        lds_barrier();
     }
 
     // LayerNorm parameter gradients: fold the 256/G threads that own the same channel chunk, one atomic per channel per WG
+    lds_barrier();
     float* red = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int e = 0; e < 8; e++) { red[tid * 16 + e] = aw[e]; red[tid * 16 + 8 + e] = ab[e]; }
@@ -378,8 +533,8 @@ mlp_bwd_dgrad_kernel(const T* __restrict__ dxout, const T* __restrict__ gp, cons
         for (int e = 0; e < 8; e++) {
             float sw = 0.f, sb = 0.f;
             for (int t = tid; t < 256; t += G) { sw += red[t * 16 + e]; sb += red[t * 16 + 8 + e]; }
-            atomicAdd(dln_w + cl_own * 8 + e, sw);
-            atomicAdd(dln_b + cl_own * 8 + e, sb);
+            atomicAdd(dln_w + cl * 8 + e, sw);
+            atomicAdd(dln_b + cl * 8 + e, sb);
         }
     }
 }

@@ -161,27 +161,54 @@ colsum_kernel(const T* __restrict__ x, float* __restrict__ out, int rows, int N,
 
 // ---- event-tensor prepack (reference modules/detection.py:133-134 cast + utils/padding.py:29-44) ----
 // src: [F][Cin][h][w] uint8 or float, unpadded.  dst: [F][H][W][Cp] T, zero padded bottom/right and in channels.
+// A workgroup transposes one 128-pixel piece of an image row through LDS: plane-major source rows come in as
+// whole 128/512-byte segments (uint8 as 4-byte words when the geometry allows), channel-last pixels go out as
+// consecutive 16-byte chunks — both sides of the transpose touch memory in full cache lines.
+constexpr int PREPACK_SEG = 128;
 template <class T, class S>
 __global__ void __launch_bounds__(256)
 prepack_kernel(const S* __restrict__ src, T* __restrict__ dst, int F, int Cin, int h, int w, int H, int W, int Cp) {
-    // one thread = one 8-channel chunk of one pixel; consecutive lanes = consecutive 16-byte chunks of dst, so every
-    // store instruction writes whole cache lines (a thread-per-pixel layout writes 16 B out of every 48 B per store)
+    constexpr int SEG = PREPACK_SEG;
+    constexpr int CMAX = 32;                                  // staged channels (host checks Cin <= CMAX)
+    __shared__ S plane[CMAX][SEG + 4];
+    const int tid = threadIdx.x;
+    const int segs = (W + SEG - 1) / SEG;
     const int cpp = Cp / 8;
-    const size_t total = (size_t)F * H * W * cpp;
-    for (size_t u = (size_t)blockIdx.x * 256 + threadIdx.x; u < total; u += (size_t)gridDim.x * 256) {
-        const int c0 = (int)(u % cpp) * 8;
-        const size_t pix = u / cpp;
-        const int x = (int)(pix % W);
-        const int y = (int)((pix / W) % H);
-        const int f = (int)(pix / ((size_t)W * H));
-        const bool in = (y < h) && (x < w);
-        float v[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int c = c0 + i;
-            v[i] = (in && c < Cin) ? (float)src[(((size_t)f * Cin + c) * h + y) * w + x] : 0.f;
+    const size_t n_items = (size_t)F * H * segs;
+    for (size_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int sg = (int)(item % segs);
+        const int y = (int)((item / segs) % H);
+        const int f = (int)(item / ((size_t)segs * H));
+        const int x0 = sg * SEG;
+        const int nx = (W - x0) < SEG ? (W - x0) : SEG;       // destination pixels of this piece
+        const int nsrc = y < h ? ((w - x0) < 0 ? 0 : ((w - x0) < SEG ? (w - x0) : SEG)) : 0;   // real source pixels
+        if (nsrc > 0) {
+            const S* row0 = src + (((size_t)f * Cin) * h + y) * w + x0;
+            const size_t pstride = (size_t)h * w;
+            if (sizeof(S) == 1 && (w % 4) == 0 && (nsrc % 4) == 0) {
+                const int wpr = nsrc / 4;                     // 4-byte words per plane row piece
+                for (int e = tid; e < Cin * wpr; e += 256) {
+                    const int c = e / wpr, q = e % wpr;
+                    *reinterpret_cast<uint32_t*>(&plane[c][q * 4]) =
+                        *reinterpret_cast<const uint32_t*>(row0 + c * pstride + q * 4);
+                }
+            } else {
+                for (int e = tid; e < Cin * nsrc; e += 256) {
+                    const int c = e / nsrc, q = e % nsrc;
+                    plane[c][q] = row0[c * pstride + q];
+                }
+            }
         }
-        frag_store<T>(dst + pix * Cp + c0, frag_from_float<T>(v));
+        __syncthreads();
+        T* drow = dst + (((size_t)f * H + y) * W + x0) * Cp;
+        for (int u = tid; u < nx * cpp; u += 256) {
+            const int px = u / cpp, c0 = (u % cpp) * 8;
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = (px < nsrc && c0 + i < Cin) ? (float)plane[c0 + i][px] : 0.f;
+            frag_store<T>(drow + (size_t)px * Cp + c0, frag_from_float<T>(v));
+        }
+        __syncthreads();
     }
 }
 

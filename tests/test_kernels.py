@@ -32,14 +32,16 @@ def f64(t):
 
 @pytest.mark.parametrize('dt', DTYPES)
 @pytest.mark.parametrize('u8', [True, False])
-def test_prepack(backend, dt, u8):
+@pytest.mark.parametrize('shape', [((3, 20, 5, 7), (8, 8)), ((2, 20, 6, 264), (8, 272)), ((1, 3, 4, 130), (4, 136))])
+def test_prepack(backend, dt, u8, shape):
+    (F, Cin, h, w), (H, W) = shape
     g = torch.Generator().manual_seed(0)
-    src = torch.randint(0, 11, (3, 20, 5, 7), generator=g, dtype=torch.uint8)
+    src = torch.randint(0, 11, (F, Cin, h, w), generator=g, dtype=torch.uint8)
     if not u8:
         src = src.float()
-    out = ops.prepack_input(src.to(backend), 8, 8, 24, dt)
-    want = torch.zeros(3, 8, 8, 24)
-    want[:, :5, :7, :20] = src.float().permute(0, 2, 3, 1)
+    out = ops.prepack_input(src.to(backend), H, W, 24, dt)
+    want = torch.zeros(F, H, W, 24)
+    want[:, :h, :w, :Cin] = src.float().permute(0, 2, 3, 1)
     close(out, want, dt, 'prepack', mult=0.0 if dt == torch.float32 else 1.0)
 
 
