@@ -17,6 +17,16 @@ elif op == 'fwd':           # y[M][256] = x W^T + b
 elif op == 'dgrad':         # dx[M][64] = dy W
     wt, dx = rnd(C, 4 * C), torch.empty(M, C, device=dev, dtype=dt)
     fn = lambda: ops.linear_dgrad(dy4, wt, out=dx)
+elif op in ('mlp_fwd', 'mlp_bwd'):
+    lw, lb = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    w1, w2 = rnd(4 * C, C) * 0.1, rnd(C, 4 * C) * 0.1
+    b1, b2, gam = torch.zeros(4 * C, device=dev), torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    if op == 'mlp_fwd':
+        fn = lambda: ops.mlp_fwd(x, lw, lb, w1, b1, w2, b2, gam, 1e-5, want_grad=True)
+    else:
+        dy, dlw, dlb = rnd(M, C), torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        w2gt, w1t = w2.t().contiguous(), w1.t().contiguous()
+        fn = lambda: ops.mlp_bwd_dgrad(dy, dy4, x, lw, w2gt, w1t, dlw, dlb, 1e-5)
 for _ in range(3):
     fn()
 torch.cuda.synchronize()

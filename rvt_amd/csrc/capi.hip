@@ -349,12 +349,19 @@ static int mlp_tm(int dtype, int C) {
     if (dtype == RVT_BF16 && C == 64 && tm_override == 128) return 128;
     return 64;
 }
-static int mlp_grid(int dtype, int C, int M, int tm) {
+}  // extern "C"
+// persistent grid = exactly the workgroups the chip holds at once for THIS kernel instantiation (registers + LDS)
+template <class K> static int mlp_grid(K kernel, int M, int tm) {
     static const int resident_override = getenv("RVT_GEMM_RESIDENT") ? atoi(getenv("RVT_GEMM_RESIDENT")) : 0;
     const int n_tiles = (M + tm - 1) / tm;
-    const int per_cu = (dtype == RVT_BF16 && C == 64 && tm == 64) ? 2 : 1;   // resident workgroups per CU (registers; see the kernels' launch bounds)
+    int per_cu = 2;
+#ifndef RVT_EMU
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 256, 0) == hipSuccess && nb > 0) per_cu = nb;
+#endif
     return imax(1, imin(n_tiles, resident_override > 0 ? resident_override : 256 * per_cu));
 }
+extern "C" {
 
 int rvt_mlp_fwd(const void* xmid, void* xout, void* g_out, void* gp_out, const float* ln_w, const float* ln_b,
                 const void* w1, const float* b1, const void* w2, const float* b2, const float* gamma, int dtype, int M,
@@ -363,10 +370,10 @@ int rvt_mlp_fwd(const void* xmid, void* xout, void* g_out, void* gp_out, const f
     RVT_CHECK((g_out == nullptr) == (gp_out == nullptr), "mlp_fwd: g_out and gp_out go together");
     hipStream_t st = (hipStream_t)stream;
     const int tm = mlp_tm(dtype, C);
-    const int grid = mlp_grid(dtype, C, M, tm);
 #define RVT_MLP_FWD(TT, CC, TMM)                                                                                           \
-    hipLaunchKernelGGL((mlp_fwd_kernel<TT, CC, TMM>), dim3(grid), dim3(256), 0, st, (const TT*)xmid, (TT*)xout, (TT*)g_out, \
-                       (TT*)gp_out, ln_w, ln_b, (const TT*)w1, b1, (const TT*)w2, b2, gamma, M, eps)
+    hipLaunchKernelGGL((mlp_fwd_kernel<TT, CC, TMM>), dim3(mlp_grid(mlp_fwd_kernel<TT, CC, TMM>, M, tm)), dim3(256), 0, st, \
+                       (const TT*)xmid, (TT*)xout, (TT*)g_out, (TT*)gp_out, ln_w, ln_b, (const TT*)w1, b1, (const TT*)w2,  \
+                       b2, gamma, M, eps)
     if (dtype == RVT_BF16 && C == 64 && tm == 128) RVT_MLP_FWD(bf16, 64, 128);
     else if (dtype == RVT_BF16 && C == 64) RVT_MLP_FWD(bf16, 64, 64);
     else if (dtype == RVT_BF16 && C == 128) RVT_MLP_FWD(bf16, 128, 64);
@@ -381,10 +388,10 @@ int rvt_mlp_bwd_dgrad(const void* dxout, const void* gp, const void* xmid, void*
     RVT_CHECK(rvt_mlp_fused_supported(dtype, C), "mlp_bwd_dgrad: fused MLP not built for dtype=%d C=%d", dtype, C);
     hipStream_t st = (hipStream_t)stream;
     const int tm = mlp_tm(dtype, C);
-    const int grid = mlp_grid(dtype, C, M, tm);
 #define RVT_MLP_BWD(TT, CC, TMM)                                                                                          \
-    hipLaunchKernelGGL((mlp_bwd_dgrad_kernel<TT, CC, TMM>), dim3(grid), dim3(256), 0, st, (const TT*)dxout, (const TT*)gp,   \
-                       (const TT*)xmid, (TT*)dh, (TT*)dxmid, ln_w, (const TT*)w2g_t, (const TT*)w1_t, dln_w, dln_b, M, eps)
+    hipLaunchKernelGGL((mlp_bwd_dgrad_kernel<TT, CC, TMM>), dim3(mlp_grid(mlp_bwd_dgrad_kernel<TT, CC, TMM>, M, tm)),       \
+                       dim3(256), 0, st, (const TT*)dxout, (const TT*)gp, (const TT*)xmid, (TT*)dh, (TT*)dxmid, ln_w,      \
+                       (const TT*)w2g_t, (const TT*)w1_t, dln_w, dln_b, M, eps)
     if (dtype == RVT_BF16 && C == 64 && tm == 128) RVT_MLP_BWD(bf16, 64, 128);
     else if (dtype == RVT_BF16 && C == 64) RVT_MLP_BWD(bf16, 64, 64);
     else if (dtype == RVT_BF16 && C == 128) RVT_MLP_BWD(bf16, 128, 64);

@@ -89,6 +89,9 @@ __device__ __forceinline__ void stage_read8(const float* stage, int ld, int srow
     }
 }
 
+#ifndef MLP_WAVES
+#define MLP_WAVES 2
+#endif
 template <class T> struct MlpGeom { static constexpr int JC = 64; };   // 64-column hidden chunks: ~57 KiB LDS at C=64 -> two workgroups per CU
 
 // TM = tokens per tile (64 or 128): 4 waves as 2x2, each wave TM/2 = 32*MI token rows.
@@ -103,9 +106,10 @@ template <class T, int C, int TM> struct MlpSmem {
     static constexpr int A_H = KT_J * TM * 128;                        // [TM tokens][JC]   (g in fwd, dh in bwd)
     static constexpr int B_2 = KT_J * C * 128;                         // [C][JC]           (W2[:, j] / W1^T[:, j])
     static constexpr int OFF_1 = A_X, OFF_H = OFF_1 + R1, OFF_2 = OFF_H + A_H;
-    static constexpr int BYTES = OFF_2 + B_2;
+    static constexpr int OFF_K = OFF_2 + B_2;                         // per-channel constants (fp32): ln_w, ln_b, gamma, b2 [C] + b1 [4C]
+    static constexpr int BYTES = OFF_K + 8 * C * 4;
     static_assert(BYTES <= 160 * 1024, "fused MLP tile does not fit the LDS");
-    static_assert(STG_B <= BYTES - OFF_1, "final staging does not fit behind the input tile");
+    static_assert(STG_B <= OFF_K - OFF_1, "final staging does not fit behind the input tile");
     static_assert(256 * 16 * 4 <= BYTES, "reduction scratch");
 };
 
@@ -168,7 +172,7 @@ template <int N> __device__ __forceinline__ void load_cols(const float* p, int c
 
 // ===================================================================================================== forward
 template <class T, int C, int TM>
-__global__ void __launch_bounds__(256, (sizeof(T) == 2 && C == 64 && TM == 64) ? 2 : 1)
+__global__ void __launch_bounds__(256, (sizeof(T) == 2 && C == 64 && TM == 64) ? MLP_WAVES : 1)
 mlp_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, T* __restrict__ g_out, T* __restrict__ gp_out,
                const float* __restrict__ ln_w, const float* __restrict__ ln_b, const T* __restrict__ W1,
                const float* __restrict__ b1, const T* __restrict__ W2, const float* __restrict__ b2,
@@ -194,9 +198,14 @@ mlp_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, T* __restrict__
     const int n_tiles = (M + TM - 1) / TM;
     const int cl = tid % G;                                // this thread's 8-channel chunk in the (row, chunk) layout
     const int cu = tid % UPR1;                             // ... and its 8-column unit of a hidden chunk
-    float lnw[8], lnb[8], gam[8], b2v[8];
-    load_cols<8>(ln_w, cl * 8, lnw); load_cols<8>(ln_b, cl * 8, lnb);
-    load_cols<8>(gamma, cl * 8, gam); load_cols<8>(b2, cl * 8, b2v);
+    // per-channel constants live in LDS for the whole launch: reading them is an LDS access (lgkmcnt), which never has
+    // to wait behind the global stores in flight
+    float* const kst = reinterpret_cast<float*>(smem + S::OFF_K);
+    const float* const k_lnw = kst, * const k_lnb = kst + C, * const k_gam = kst + 2 * C, * const k_b2 = kst + 3 * C;
+    const float* const k_b1 = kst + 4 * C;
+    for (int i = tid; i < C; i += 256) { kst[i] = ln_w[i]; kst[C + i] = ln_b[i]; kst[2 * C + i] = gamma[i]; kst[3 * C + i] = b2[i]; }
+    for (int i = tid; i < HID; i += 256) kst[4 * C + i] = b1[i];
+    __syncthreads();
 
     auto load_rows = [&](int tile, frag_t<T> (&r)[NFX]) {
 #pragma unroll
@@ -222,7 +231,8 @@ mlp_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, T* __restrict__
 #pragma unroll
             for (int e = 0; e < 8; e++) { const float d = v[e] - mean; qq += d * d; }
             const float rstd = 1.0f / sqrtf(group_sum(qq, G) / (float)C + eps);
-            float o[8];
+            float o[8], lnw[8], lnb[8];
+            load_cols<8>(k_lnw, cl * 8, lnw); load_cols<8>(k_lnb, cl * 8, lnb);
 #pragma unroll
             for (int e = 0; e < 8; e++) o[e] = ok ? (v[e] - mean) * rstd * lnw[e] + lnb[e] : 0.f;
             opm_store_frag<T>(Ax, TM, row, cl, frag_from_float<T>(o));
@@ -256,7 +266,7 @@ mlp_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, T* __restrict__
             if (!last) wp.load(W1, W2, j0 + JC, tid);
             else if (have2) wp.load(W1, W2, 0, tid);
             float b1v[8];
-            load_cols<8>(b1, j0 + cu * 8, b1v);
+            load_cols<8>(k_b1, j0 + cu * 8, b1v);
             sched_fence();
             f32x16 acc1[MI][NJ1];
 #pragma unroll
@@ -304,7 +314,8 @@ mlp_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, T* __restrict__
                 const int row = (tid + q * 256) / G;
                 if (((row >> 5) % MI) != i) continue;
                 if (m0 + row < M) {
-                    float v[8], res[8];
+                    float v[8], res[8], gam[8], b2v[8];
+                    load_cols<8>(k_gam, cl * 8, gam); load_cols<8>(k_b2, cl * 8, b2v);
                     frag_to_float<T>(raw[q], res);
                     stage_read8(stage, LD2, (row / (32 * MI)) * 32 + (row & 31), cl * 8, v);
 #pragma unroll
@@ -328,7 +339,7 @@ mlp_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, T* __restrict__
 // dv2[m][C]   = dh W1                                      W1^T stored [C][4C]                    ("fc1_wt")
 // dxmid       = dxout + LN2'(dv2; xmid)                    dln_w += dv2 * xhat, dln_b += dv2
 template <class T, int C, int TM>
-__global__ void __launch_bounds__(256, (sizeof(T) == 2 && C == 64 && TM == 64) ? 2 : 1)
+__global__ void __launch_bounds__(256, (sizeof(T) == 2 && C == 64 && TM == 64) ? MLP_WAVES : 1)
 mlp_bwd_dgrad_kernel(const T* __restrict__ dxout, const T* __restrict__ gp, const T* __restrict__ xmid, T* __restrict__ dh,
                      T* __restrict__ dxmid, const float* __restrict__ ln_w, const T* __restrict__ W2gT,
                      const T* __restrict__ W1T, float* __restrict__ dln_w, float* __restrict__ dln_b, int M, float eps) {
@@ -353,8 +364,10 @@ mlp_bwd_dgrad_kernel(const T* __restrict__ dxout, const T* __restrict__ gp, cons
     const int n_tiles = (M + TM - 1) / TM;
     const int cl = tid % G;                                 // every slot of this thread has the same channel chunk
     const int cu = tid % UPR1;
-    float lnw[8], aw[8], ab[8];
-    load_cols<8>(ln_w, cl * 8, lnw);
+    float aw[8], ab[8];
+    float* const k_lnw = reinterpret_cast<float*>(smem + S::OFF_K);   // LDS-resident constants, see the forward kernel
+    for (int i = tid; i < C; i += 256) k_lnw[i] = ln_w[i];
+    __syncthreads();
 #pragma unroll
     for (int e = 0; e < 8; e++) { aw[e] = 0.f; ab[e] = 0.f; }
 
@@ -489,7 +502,8 @@ mlp_bwd_dgrad_kernel(const T* __restrict__ dxout, const T* __restrict__ gp, cons
                     const int row = (tid + q * 256) / G;
                     const bool mine = ((row >> 5) % MI) == i;         // uniform over the G lanes of a row
                     const bool ok = mine && (m0 + row < M);
-                    float d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, xv[8], dxv[8], xh[8];
+                    float d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, xv[8], dxv[8], xh[8], lnw[8];
+                    load_cols<8>(k_lnw, cl * 8, lnw);
                     if (mine) stage_read8(stage, LD2, (row / (32 * MI)) * 32 + (row & 31), cl * 8, d);
                     frag_to_float<T>(rawx[q], xv);
                     frag_to_float<T>(rawdx[q], dxv);
