@@ -602,7 +602,7 @@ template <int BN, bool ONE_K> struct GemmSmem {
 };
 
 template <class T, int BN, bool TN, bool ONE_K, class ASrc, class AXf, class BSrc, class BXf, class Ep>
-__global__ void __launch_bounds__(256, (TN ? 1 : (BN == 64 && Ep::UNIT == 8 && sizeof(T) == 2 ? 3 : 2)))
+__global__ void __launch_bounds__(256, (TN ? 1 : (BN == 64 && Ep::UNIT == 8 && sizeof(T) == 2 ? 3 : (BN == 128 && sizeof(T) == 4 ? 1 : 2))))
 gemm_kernel(ASrc as, AXf axf, BSrc bs, BXf bxf, Ep ep, int M, int N, int K, int m_tiles, int n_tiles, int ksplit_len,
             float* a_colsum, int panel_major) {
     constexpr int BM = 128;
@@ -649,7 +649,6 @@ gemm_kernel(ASrc as, AXf axf, BSrc bs, BXf bxf, Ep ep, int M, int N, int K, int 
     constexpr int RSTEP = 256 / UPR;                     // rows covered by the 256 threads at once
     constexpr int UPT = (64 + RSTEP - 1) / RSTEP;        // units per thread per 64-row pass
     const int ep_cu = tid % UPR, ep_row0 = tid / UPR;
-    constexpr bool EARLY = ONE_K && !TN;
 
     f32x16 acc[2][WN];
     auto zero_acc = [&]() {
@@ -814,9 +813,9 @@ gemm_kernel(ASrc as, AXf axf, BSrc bs, BXf bxf, Ep ep, int M, int N, int K, int 
             //   2. the operand prefetch of the NEXT tile
             //   3. this tile's output stores
             // so the epilogue arithmetic waits for (1) only, and the move of (2) into LDS at the loop bottom waits with
-            // vmcnt(#stores) and never for a store acknowledgement.  When the whole contraction is one K tile (EARLY)
-            // both are issued before the MFMA phase — a full tile time ahead of their use; with a K loop its operand
-            // loads share the loader registers, so (1) and (2) are issued after the last K tile instead.
+            // vmcnt(#stores) and never for a store acknowledgement.  (1) and (2) are issued in front of the LAST K tile's
+            // MFMA phase (the K loop's own operand loads share the loader registers until then): a full tile time ahead
+            // of their use when the contraction is a single K tile, one MFMA phase plus the epilogue otherwise.
             typename Ep::Cols cols;
             typename Ep::Aux aux[2][UPT];
             int mt2 = 0, nt2 = 0;
@@ -832,23 +831,24 @@ gemm_kernel(ASrc as, AXf axf, BSrc bs, BXf bxf, Ep ep, int M, int N, int K, int 
             };
 
             lds_barrier();
-            if (EARLY) { side_fetch(m0, ncol, col_ok, cols, aux); sched_fence(); prefetch_next(); sched_fence(); }
-            for (int kt = 0; kt < nk; kt++) {
+            for (int kt = 0; kt + 1 < nk; kt++) {            // all K tiles but the last: stream the next one in
                 const int cur = kt & 1;
-                const bool more = kt + 1 < nk;
-                if (more) {
-                    la.load(as, axf, kbeg + (kt + 1) * BK, kend, tid);
-                    lb.load(bs, bxf, kbeg + (kt + 1) * BK, kend, tid);
-                }
+                la.load(as, axf, kbeg + (kt + 1) * BK, kend, tid);
+                lb.load(bs, bxf, kbeg + (kt + 1) * BK, kend, tid);
                 mma_stage(cur, false);
-                if (more) {
-                    la.store(smem + (cur ^ 1) * STAGE_BYTES, axf, tid);
-                    lb.store(smem + (cur ^ 1) * STAGE_BYTES + BM * 128, bxf, tid);
-                }
+                la.store(smem + (cur ^ 1) * STAGE_BYTES, axf, tid);
+                lb.store(smem + (cur ^ 1) * STAGE_BYTES + BM * 128, bxf, tid);
                 lds_barrier();
             }
-            if (!EARLY) { side_fetch(m0, ncol, col_ok, cols, aux); sched_fence(); prefetch_next(); }
-            sched_fence();      // the prefetch must be ISSUED here, not sunk below the epilogue
+            // last K tile (peeled, so that this is straight-line code): the loader registers are free from here on
+            side_fetch(m0, ncol, col_ok, cols, aux);
+            sched_fence();
+            prefetch_next();
+            sched_fence();      // the prefetch must be ISSUED here, not sunk below the MFMA phase / epilogue
+            if (nk > 0) {
+                mma_stage((nk - 1) & 1, false);
+                lds_barrier();
+            }
 
             epilogue(m0, ncol, col_ok, cols, aux);
             lds_barrier();            // staging buffer is reused by the next tile's operand stores
