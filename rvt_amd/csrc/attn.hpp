@@ -1,5 +1,8 @@
 // Partitioned multi-head self-attention core (reference maxvit.py:343-354 on the partitions of
-// maxvit.py:273-304), forward and backward, one 64-lane wave per (frame, partition, head).
+// maxvit.py:273-304), forward and backward, one 64-lane wave per (frame, partition, head); a workgroup = HG waves = HG
+// consecutive heads of ONE partition, so the 128-byte lines of a token row that two heads share ([q|k|v] of dh = 32
+// channels is 192 bytes per head) are fetched from HBM by one CU, once, instead of by workgroups on different XCDs.
+// The waves of a workgroup are independent (private LDS slices): they only ever synchronise with themselves.
 //
 // The qkv activations stay in IMAGE token order [F*H*W][3C] (per-head channel layout [q|k|v], dh each —
 // reference maxvit.py:347); window / grid partitioning is pure index arithmetic on the token rows that a
@@ -22,12 +25,22 @@
 
 namespace rvt {
 
+// LDS hand-off between the lanes of ONE wave (private slice): DS operations of a wave execute in issue order, so draining
+// lgkmcnt (plus a compiler barrier) is all the synchronisation there is to do — no s_barrier across the workgroup.
+__device__ __forceinline__ void wave_lds_sync() {
+#ifdef RVT_EMU
+    __syncthreads();              // emulator: waves are fibers; every wave of the block reaches each sync point (uniform code)
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+}
+
 struct AttnGeom {
     int F, H, W, C, dh, heads, ph, pw, L, window;   // L = ph*pw
     int nPw;        // partitions along x
     int P;          // partitions per frame
     float scale;
-    FastDiv dHeads, dP, dnPw, dpw;
+    FastDiv dGroups, dP, dnPw, dpw;   // dGroups: head groups (of HG heads) per partition
 };
 
 // image-order token row of slot l of partition p of frame f
@@ -121,15 +134,17 @@ template <int NB> __device__ __forceinline__ void make_kmask(float (&kmask)[16],
     for (int r = 0; r < 16; r++) kmask[r] = (32 * (NB - 1) + acc_row(r, lane) < L) ? 0.f : -1.0e30f;
 }
 
-template <class T, int NB>
-__global__ void __launch_bounds__(64)
+template <class T, int NB, int HG>
+__global__ void __launch_bounds__(64 * HG)
 attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, AttnGeom g) {
     constexpr int LP = 32 * NB, PITCH = LP + 8;
-    __shared__ __attribute__((aligned(16))) T Vt[32 * PITCH];
-    const int lane = threadIdx.x & 63, li = lane & 31, half = lane >> 5;
-    uint32_t fp, head, f, p;
-    g.dHeads.divmod(blockIdx.x, fp, head);
+    __shared__ __attribute__((aligned(16))) T Vt_all[HG][32 * PITCH];
+    const int lane = threadIdx.x & 63, li = lane & 31, half = lane >> 5, wv = threadIdx.x >> 6;
+    T* const Vt = Vt_all[wv];
+    uint32_t fp, grp, f, p;
+    g.dGroups.divmod(blockIdx.x, fp, grp);
     g.dP.divmod(fp, f, p);
+    const int head = (int)grp * HG + wv;
     const int C3 = 3 * g.C, dh = g.dh;
     const int qoff = head * 3 * dh, koff = qoff + dh, voff = qoff + 2 * dh;
 
@@ -152,7 +167,7 @@ attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, AttnGeom g) {
             frag_t<T> v = load_chunk<T>(qkv + (size_t)tok[b] * C3 + voff, chunk, dh, valid[b]);
             store_transposed<T>(Vt, PITCH, chunk, 32 * b + li, v);
         }
-    lds_barrier();
+    wave_lds_sync();
 
 #pragma unroll
     for (int bi = 0; bi < NB; bi++) {
@@ -190,18 +205,25 @@ attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, AttnGeom g) {
     }
 }
 
-template <class T, int NB>
-__global__ void __launch_bounds__(64, 2)      // <= 256 VGPR+AGPR: two waves per SIMD instead of one
+template <class T, int NB> struct AttnBwdLds {       // per wave
+    static constexpr int LP = 32 * NB, PITCH = LP + 8, PSP = 40;
+    static constexpr int BYTES = (3 * 32 * PITCH + LP * PSP) * (int)sizeof(T);
+};
+
+template <class T, int NB, int HG>
+__global__ void __launch_bounds__(64 * HG, 2)      // <= 256 VGPR+AGPR: two waves per SIMD instead of one
 attn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ dout, T* __restrict__ dqkv, AttnGeom g) {
     constexpr int LP = 32 * NB, PITCH = LP + 8, PSP = 40;
-    __shared__ __attribute__((aligned(16))) T Qt[32 * PITCH];
-    __shared__ __attribute__((aligned(16))) T Kt[32 * PITCH];
-    __shared__ __attribute__((aligned(16))) T dOt[32 * PITCH];
-    __shared__ __attribute__((aligned(16))) T PS[LP * PSP];
-    const int lane = threadIdx.x & 63, li = lane & 31, half = lane >> 5;
-    uint32_t fp, head, f, p;
-    g.dHeads.divmod(blockIdx.x, fp, head);
+    __shared__ __attribute__((aligned(16))) T Qt_all[HG][32 * PITCH];
+    __shared__ __attribute__((aligned(16))) T Kt_all[HG][32 * PITCH];
+    __shared__ __attribute__((aligned(16))) T dOt_all[HG][32 * PITCH];
+    __shared__ __attribute__((aligned(16))) T PS_all[HG][LP * PSP];
+    const int lane = threadIdx.x & 63, li = lane & 31, half = lane >> 5, wv = threadIdx.x >> 6;
+    T* const Qt = Qt_all[wv]; T* const Kt = Kt_all[wv]; T* const dOt = dOt_all[wv]; T* const PS = PS_all[wv];
+    uint32_t fp, grp, f, p;
+    g.dGroups.divmod(blockIdx.x, fp, grp);
     g.dP.divmod(fp, f, p);
+    const int head = (int)grp * HG + wv;
     const int C3 = 3 * g.C, dh = g.dh;
     const int qoff = head * 3 * dh, koff = qoff + dh, voff = qoff + 2 * dh, ooff = head * dh;
 
@@ -226,7 +248,7 @@ attn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ dout, T* __rest
             store_transposed<T>(dOt, PITCH, chunk, 32 * b + li,
                                 load_chunk<T>(dout + (size_t)tok[b] * g.C + ooff, chunk, dh, valid[b]));
         }
-    lds_barrier();
+    wave_lds_sync();
 
     f32x16 dk[NB], dv[NB];
 #pragma unroll
@@ -270,7 +292,7 @@ attn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ dout, T* __rest
         for (int bj = 0; bj < NB; bj++)
 #pragma unroll
             for (int r = 0; r < 16; r++) ds[bj][r] = pr[bj][r] * (dp[bj][r] - delta) * g.scale;
-        lds_barrier();
+        wave_lds_sync();
 #pragma unroll
         for (int bj = 0; bj < NB; bj++)
 #pragma unroll
@@ -279,12 +301,12 @@ attn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ dout, T* __rest
                 frag_t<T> b = frag_load<T>(dOt + li * PITCH + 32 * bi + ks * 16 + half * 8);
                 mma32(dv[bj], a, b);
             }
-        lds_barrier();
+        wave_lds_sync();
 #pragma unroll
         for (int bj = 0; bj < NB; bj++)
 #pragma unroll
             for (int r = 0; r < 16; r++) PS[(32 * bj + acc_row(r, lane)) * PSP + li] = (T)ds[bj][r];
-        lds_barrier();
+        wave_lds_sync();
 #pragma unroll
         for (int bj = 0; bj < NB; bj++)
 #pragma unroll
@@ -308,20 +330,20 @@ attn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ dout, T* __rest
                 if (d0 < dh) store4<T>(qrow + d0, dq[4 * gq], dq[4 * gq + 1], dq[4 * gq + 2], dq[4 * gq + 3]);
             }
         }
-        lds_barrier();   // PS is rewritten by the next query block
+        wave_lds_sync();   // PS is rewritten by the next query block
     }
     // dK, dV: accumulator rows = keys, col = d = lane&31.  Stage each through LDS (the P^T buffer, [key][40]) so that the
     // global writes are 16-byte row segments instead of 2-byte scalars.
     constexpr int CPR = 32 / 8;                       // 8-channel chunks per key row (dh <= 32)
 #pragma unroll
     for (int which = 0; which < 2; which++) {
-        lds_barrier();
+        wave_lds_sync();
 #pragma unroll
         for (int bj = 0; bj < NB; bj++)
 #pragma unroll
             for (int r = 0; r < 16; r++)
                 PS[(32 * bj + acc_row(r, lane)) * PSP + li] = (T)(which == 0 ? dk[bj][r] : dv[bj][r]);
-        lds_barrier();
+        wave_lds_sync();
         const int off = which == 0 ? koff : voff;
         for (int u = lane; u < LP * CPR; u += 64) {
             const int j = u / CPR, c = u % CPR;

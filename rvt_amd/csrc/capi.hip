@@ -409,22 +409,51 @@ static int make_attn_geom(AttnGeom& g, int F, int H, int W, int C, int dh, int p
     g.window = window;
     g.nPw = W / pw; g.P = (H / ph) * (W / pw);
     g.scale = 1.0f / sqrtf((float)dh);
-    g.dHeads = FastDiv(g.heads); g.dP = FastDiv(g.P); g.dnPw = FastDiv(g.nPw); g.dpw = FastDiv(pw);
+    g.dGroups = FastDiv(g.heads); g.dP = FastDiv(g.P); g.dnPw = FastDiv(g.nPw); g.dpw = FastDiv(pw);
     return 0;
 }
+}  // extern "C"
+
+// heads per workgroup: the largest of 4 / 2 / 1 that divides the head count and whose backward LDS slices fit
+constexpr int ATTN_LDS_BUDGET = 80 * 1024;
+template <class T, int NB> static int attn_head_group(int heads) {
+    for (int hg = 4; hg > 1; hg >>= 1)
+        if (heads % hg == 0 && hg * AttnBwdLds<T, NB>::BYTES <= ATTN_LDS_BUDGET) return hg;
+    return 1;
+}
+template <class T, int NB, int HG>
+static void launch_attn(bool bwd, const void* qkv, const void* dout, void* out, AttnGeom g, hipStream_t st) {
+    if constexpr (HG == 1 || HG * AttnBwdLds<T, NB>::BYTES <= ATTN_LDS_BUDGET) {
+        g.dGroups = FastDiv(g.heads / HG);
+        dim3 grid((unsigned)(g.F * g.P * (g.heads / HG)));
+        if (bwd)
+            hipLaunchKernelGGL((attn_bwd_kernel<T, NB, HG>), grid, dim3(64 * HG), 0, st, (const T*)qkv, (const T*)dout, (T*)out, g);
+        else
+            hipLaunchKernelGGL((attn_fwd_kernel<T, NB, HG>), grid, dim3(64 * HG), 0, st, (const T*)qkv, (T*)out, g);
+    }
+}
+template <class T, int NB>
+static void launch_attn_nb(bool bwd, const void* qkv, const void* dout, void* out, const AttnGeom& g, hipStream_t st) {
+    const int hg = attn_head_group<T, NB>(g.heads);
+    if (hg == 4) launch_attn<T, NB, 4>(bwd, qkv, dout, out, g, st);
+    else if (hg == 2) launch_attn<T, NB, 2>(bwd, qkv, dout, out, g, st);
+    else launch_attn<T, NB, 1>(bwd, qkv, dout, out, g, st);
+}
+template <class T>
+static void launch_attn_any(bool bwd, const void* qkv, const void* dout, void* out, const AttnGeom& g, hipStream_t st) {
+    const int NB = (g.L + 31) / 32;
+    if (NB == 1) launch_attn_nb<T, 1>(bwd, qkv, dout, out, g, st);
+    else if (NB == 2) launch_attn_nb<T, 2>(bwd, qkv, dout, out, g, st);
+    else launch_attn_nb<T, 3>(bwd, qkv, dout, out, g, st);
+}
+
+extern "C" {
 
 int rvt_attn_fwd(const void* qkv, void* out, int dtype, int F, int H, int W, int C, int dim_head, int ph, int pw,
                  int window, void* stream) {
     AttnGeom g;
     if (make_attn_geom(g, F, H, W, C, dim_head, ph, pw, window)) return 1;
-    hipStream_t st = (hipStream_t)stream;
-    dim3 grid((unsigned)(F * g.P * g.heads));
-    int NB = (g.L + 31) / 32;
-    DISPATCH_DTYPE(dtype, {
-        if (NB == 1) hipLaunchKernelGGL((attn_fwd_kernel<T, 1>), grid, dim3(64), 0, st, (const T*)qkv, (T*)out, g);
-        else if (NB == 2) hipLaunchKernelGGL((attn_fwd_kernel<T, 2>), grid, dim3(64), 0, st, (const T*)qkv, (T*)out, g);
-        else hipLaunchKernelGGL((attn_fwd_kernel<T, 3>), grid, dim3(64), 0, st, (const T*)qkv, (T*)out, g);
-    });
+    DISPATCH_DTYPE(dtype, (launch_attn_any<T>(false, qkv, nullptr, out, g, (hipStream_t)stream)));
     return check_launch("attn_fwd");
 }
 
@@ -432,17 +461,7 @@ int rvt_attn_bwd(const void* qkv, const void* dout, void* dqkv, int dtype, int F
                  int ph, int pw, int window, void* stream) {
     AttnGeom g;
     if (make_attn_geom(g, F, H, W, C, dim_head, ph, pw, window)) return 1;
-    hipStream_t st = (hipStream_t)stream;
-    dim3 grid((unsigned)(F * g.P * g.heads));
-    int NB = (g.L + 31) / 32;
-    DISPATCH_DTYPE(dtype, {
-        if (NB == 1)
-            hipLaunchKernelGGL((attn_bwd_kernel<T, 1>), grid, dim3(64), 0, st, (const T*)qkv, (const T*)dout, (T*)dqkv, g);
-        else if (NB == 2)
-            hipLaunchKernelGGL((attn_bwd_kernel<T, 2>), grid, dim3(64), 0, st, (const T*)qkv, (const T*)dout, (T*)dqkv, g);
-        else
-            hipLaunchKernelGGL((attn_bwd_kernel<T, 3>), grid, dim3(64), 0, st, (const T*)qkv, (const T*)dout, (T*)dqkv, g);
-    });
+    DISPATCH_DTYPE(dtype, (launch_attn_any<T>(true, qkv, dout, dqkv, g, (hipStream_t)stream)));
     return check_launch("attn_bwd");
 }
 
