@@ -94,6 +94,30 @@ def gemm_flops_of_call(name, args):
     return None
 
 
+def gemm_bytes_of_call(name, args, elt):
+    """Algorithmic HBM bytes of one launch: every operand and result crosses HBM exactly once.
+    Linear-family launches move the token-major activations ([M][N] and [M][K], `elt` bytes per element); the
+    weight / weight-gradient panel (N*K) is read or written once."""
+    if name in ('rvt_linear_fwd', 'rvt_linear_scale_res_fwd', 'rvt_linear_wgrad'):
+        M, N, K = args[-5], args[-4], args[-3]
+    elif name in ('rvt_linear_dgrad', 'rvt_linear_gelu_fwd'):
+        M, N, K = args[-4], args[-3], args[-2]
+    elif name in ('rvt_lstm_fwd', 'rvt_lstm_dgrad', 'rvt_lstm_wgrad'):
+        M, N, K = args[-3], 4 * args[-2], 2 * args[-2]
+    else:
+        return None
+    act = M * (N + K) * elt
+    if name == 'rvt_linear_scale_res_fwd':
+        act += M * N * elt                        # residual read
+    if name == 'rvt_linear_gelu_fwd':
+        act += M * N * elt                        # second output (GELU')
+    wbytes = N * K * (4 if name.endswith('wgrad') else elt)
+    return act + wbytes
+
+
+HBM_PEAK_GBS = 8000.0                             # MI355X HBM3E (MI355X_MICROARCH.md)
+
+
 def measured_traffic(entry_point):
     """HBM bytes per launch of `entry_point` from the committed rocprofv3 PMC passes (profiles/latest_traffic.json,
     written by profiles/summarize_rocprof.py: 2*FETCH_SIZE + WRITE_SIZE KiB, the gfx950 correction of the guide)."""
@@ -312,11 +336,20 @@ def main():
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
+    marks = []
     for _ in range(args.steps):
         step()
+        m = torch.cuda.Event(enable_timing=True)
+        m.record()
+        marks.append(m)
     e1.record()
     barrier()
     wall = time.perf_counter() - t0
+    per_step = [a.elapsed_time(b) for a, b in zip([e0] + marks[:-1], marks)]
+    if rank == 0:
+        print(f'[bench] per-step ms: {[round(x, 1) for x in per_step]}  reserved={torch.cuda.memory_reserved() / 2**30:.1f} GiB '
+              f'peak_alloc={torch.cuda.max_memory_allocated() / 2**30:.1f} GiB '
+              f'alloc_retries={torch.cuda.memory_stats().get("num_alloc_retries", 0)}', file=sys.stderr, flush=True)
     timer.uninstall()
     if world > 1:
         tmax = torch.tensor([wall], device=device, dtype=torch.float64)
@@ -334,6 +367,23 @@ def main():
         peak = PEAK_TFLOPS[args.dtype]
         achieved = dom_flops / (dom_ms * 1e-3) / 1e12
         path_tflops = events_per_s / world * wl['f_fwdbwd'] / 1e12
+        # which roof bounds the dominant kernel?  arithmetic intensity of its launches vs the machine balance
+        elt = 2 if args.dtype == 'bf16' else 4
+        dom_bytes = sum(gemm_bytes_of_call(dominant, r[2], elt) for r in recs)
+        balance = peak * 1e12 / (HBM_PEAK_GBS * 1e9)                     # FLOP per byte at which the roofs cross
+        common = {'kernel': dominant, 'traffic': measured_traffic(dominant), 'launches': len(recs),
+                  'avg_launch_ms': round(dom_ms / len(recs), 4),
+                  'share_of_step': round(dom_ms / (ms_per_step * args.steps), 3),
+                  'arithmetic_intensity_flop_per_byte': round(dom_flops / dom_bytes, 1),
+                  'algorithmic_bytes_per_launch': int(dom_bytes / len(recs)),
+                  'mfma_tflops': round(achieved, 2), 'mfma_frac': round(achieved / peak, 4)}
+        if dom_flops / dom_bytes < balance:
+            gbs = dom_bytes / (dom_ms * 1e-3) / 1e9
+            roof = {'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': round(gbs / HBM_PEAK_GBS, 4), **common}
+        else:
+            roof = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
+                    'frac': round(achieved / peak, 4), **common}
         out = {
             'metric': 'event-tensors/sec (fwd+bwd) RVT-Base T=21 1Mpx; % MFMA roofline' if args.workload == 'base_1mpx'
             else 'event-tensors/sec (fwd+bwd)',
@@ -345,10 +395,7 @@ def main():
                        'upstream_grads': 'random cotangents on stage 2-4 features of all T frames'},
             'mfma_roofline_frac_whole_step': round(path_tflops / peak, 4),
             'algorithmic_tflops_per_gpu': round(path_tflops, 2),
-            'roofline': {'bound': 'mfma', 'kernel': dominant, 'achieved': round(achieved, 2), 'peak': peak,
-                         'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4), 'traffic': measured_traffic(dominant),
-                         'launches': len(recs), 'avg_launch_ms': round(dom_ms / len(recs), 4),
-                         'share_of_step': round(dom_ms / (ms_per_step * args.steps), 3)},
+            'roofline': roof,
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.workload)

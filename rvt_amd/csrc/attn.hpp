@@ -158,14 +158,18 @@ attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, AttnGeom g) {
     float kmask[16];
     make_kmask<NB>(kmask, lane, g.L);
     const float scale_log2e = g.scale * 1.4426950408889634f;
-    // V^T -> LDS (zeros for padded keys so that 0 * garbage can never appear)
+    // all global reads in one batch (see the backward kernel); V^T -> LDS (zeros for padded keys so that 0 * garbage can
+    // never appear)
+    frag_t<T> qf[NB][2], kf[NB][2];
 #pragma unroll
     for (int b = 0; b < NB; b++)
 #pragma unroll
         for (int cc = 0; cc < 2; cc++) {
-            int chunk = half + 2 * cc;
-            frag_t<T> v = load_chunk<T>(qkv + (size_t)tok[b] * C3 + voff, chunk, dh, valid[b]);
-            store_transposed<T>(Vt, PITCH, chunk, 32 * b + li, v);
+            const int chunk = half + 2 * cc;
+            const T* row = qkv + (size_t)tok[b] * C3;
+            qf[b][cc] = load_chunk<T>(row + qoff, chunk, dh, valid[b]);
+            kf[b][cc] = load_chunk<T>(row + koff, chunk, dh, valid[b]);
+            store_transposed<T>(Vt, PITCH, chunk, 32 * b + li, load_chunk<T>(row + voff, chunk, dh, valid[b]));
         }
     wave_lds_sync();
 
@@ -177,13 +181,8 @@ attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, AttnGeom g) {
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) {
             if (ks * 16 < dh) {
-                const int chunk = ks * 2 + half;
-                frag_t<T> qf = load_chunk<T>(qkv + (size_t)tok[bi] * C3 + qoff, chunk, dh, valid[bi]);
 #pragma unroll
-                for (int bj = 0; bj < NB; bj++) {
-                    frag_t<T> kf = load_chunk<T>(qkv + (size_t)tok[bj] * C3 + koff, chunk, dh, valid[bj]);
-                    mma32(s[bj], kf, qf);
-                }
+                for (int bj = 0; bj < NB; bj++) mma32(s[bj], kf[bj][ks], qf[bi][ks]);
             }
         }
         float pr[NB][16];
@@ -237,16 +236,29 @@ attn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ dout, T* __rest
     float kmask[16];
     make_kmask<NB>(kmask, lane, g.L);
     const float scale_log2e = g.scale * 1.4426950408889634f;
+    // Every global read of the kernel is issued here, in one batch (the wave then never waits for memory again until its
+    // stores): lane (li, half) holds chunks {half, half+2} of rows 32b+li of Q, K, V and dO — exactly the MFMA operand
+    // fragments of K-step ks = cc, and the source of the transposed LDS copies.
+    frag_t<T> qf[NB][2], kf[NB][2], vf[NB][2], df[NB][2];
 #pragma unroll
     for (int b = 0; b < NB; b++)
 #pragma unroll
         for (int cc = 0; cc < 2; cc++) {
-            int chunk = half + 2 * cc;
+            const int chunk = half + 2 * cc;
             const T* row = qkv + (size_t)tok[b] * C3;
-            store_transposed<T>(Qt, PITCH, chunk, 32 * b + li, load_chunk<T>(row + qoff, chunk, dh, valid[b]));
-            store_transposed<T>(Kt, PITCH, chunk, 32 * b + li, load_chunk<T>(row + koff, chunk, dh, valid[b]));
-            store_transposed<T>(dOt, PITCH, chunk, 32 * b + li,
-                                load_chunk<T>(dout + (size_t)tok[b] * g.C + ooff, chunk, dh, valid[b]));
+            qf[b][cc] = load_chunk<T>(row + qoff, chunk, dh, valid[b]);
+            kf[b][cc] = load_chunk<T>(row + koff, chunk, dh, valid[b]);
+            vf[b][cc] = load_chunk<T>(row + voff, chunk, dh, valid[b]);
+            df[b][cc] = load_chunk<T>(dout + (size_t)tok[b] * g.C + ooff, chunk, dh, valid[b]);
+        }
+#pragma unroll
+    for (int b = 0; b < NB; b++)
+#pragma unroll
+        for (int cc = 0; cc < 2; cc++) {
+            const int chunk = half + 2 * cc;
+            store_transposed<T>(Qt, PITCH, chunk, 32 * b + li, qf[b][cc]);
+            store_transposed<T>(Kt, PITCH, chunk, 32 * b + li, kf[b][cc]);
+            store_transposed<T>(dOt, PITCH, chunk, 32 * b + li, df[b][cc]);
         }
     wave_lds_sync();
 
@@ -262,14 +274,10 @@ attn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ dout, T* __rest
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) {
             if (ks * 16 < dh) {
-                const int chunk = ks * 2 + half;
-                frag_t<T> qf = load_chunk<T>(qkv + (size_t)tok[bi] * C3 + qoff, chunk, dh, valid[bi]);
-                frag_t<T> df = load_chunk<T>(dout + (size_t)tok[bi] * g.C + ooff, chunk, dh, valid[bi]);
 #pragma unroll
                 for (int bj = 0; bj < NB; bj++) {
-                    const T* row = qkv + (size_t)tok[bj] * C3;
-                    mma32(s[bj], load_chunk<T>(row + koff, chunk, dh, valid[bj]), qf);
-                    mma32(dp[bj], load_chunk<T>(row + voff, chunk, dh, valid[bj]), df);
+                    mma32(s[bj], kf[bj][ks], qf[bi][ks]);
+                    mma32(dp[bj], vf[bj][ks], df[bi][ks]);
                 }
             }
         }
