@@ -1,0 +1,11 @@
+#!/bin/bash
+# kernel-trace + stats only (one pass).  usage: profiles/run_trace.sh <tag>
+TAG=${1:-t}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/trace_$TAG
+rm -rf $OUT; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/trace.log 2>&1
+python $ROOT/profiles/summarize_rocprof.py $OUT 2>/dev/null | head -45 > $OUT/summary.txt
+find $OUT -name '*.db' -delete; find $OUT -name '*.csv' -size +4M -delete
+cat $OUT/summary.txt

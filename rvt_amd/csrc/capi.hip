@@ -37,7 +37,7 @@ static inline int grid_for(size_t units, int cap = 2048) {
     return (int)(g > (size_t)cap ? cap : g);
 }
 // split the token contraction of a weight gradient so that the launch fills the chip
-// output-tile width of the weight-gradient kernels: 128x64 tiles run two workgroups per CU (registers), 128x128 one
+// output-tile width of the weight-gradient kernels
 static inline int wgrad_bn(int out_cols) {
     static const int forced = getenv("RVT_WGRAD_BN") ? atoi(getenv("RVT_WGRAD_BN")) : 0;                   // tuning knob
     if (forced == 64 || forced == 128) return forced;
@@ -46,10 +46,12 @@ static inline int wgrad_bn(int out_cols) {
 static inline int wgrad_ksplit(int out_rows, int out_cols, int tokens, int bn) {
     static const int split_override = getenv("RVT_WGRAD_BLOCKS") ? atoi(getenv("RVT_WGRAD_BLOCKS")) : 0;   // tuning knob
     int tiles = ((out_rows + 127) / 128) * ((out_cols + bn - 1) / bn);
-    // as many workgroups as are resident at once (measured: 2/CU for the 128x64 kernel 5.9 TB/s vs 4.2 at 1/CU; the
-    // 128x128 kernel holds one per CU and loses with more)
-    int want = imax(1, (split_override > 0 ? split_override : (bn == 64 ? 512 : 256)) / imax(1, tiles));
-    int maxs = imax(1, tokens / 512);
+    // as many workgroups as are resident at once: two per CU (measured on dW[512][128], 1.9 M tokens: 0.51 ms at 512
+    // workgroups vs 0.75 at 256); but at least 8192 tokens per K slice, or the partial tiles and their reduction
+    // cost more than the extra parallelism brings (dW[128][128]: 0.32 ms at 256 slices, 0.42 at 512)
+    int want = imax(1, (split_override > 0 ? split_override : 512) / imax(1, tiles));
+    static const int slice_tokens = getenv("RVT_WGRAD_SLICE_TOKENS") ? imax(64, atoi(getenv("RVT_WGRAD_SLICE_TOKENS"))) : 8192;   // (tests: small)
+    int maxs = imax(1, tokens / slice_tokens);
     int ks = imin(want, maxs);
     if (ks >= 16) ks = ks / 8 * 8;             // multiple of 8 slices: tiles of one slice can share an XCD's L2
     return ks;
