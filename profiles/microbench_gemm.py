@@ -65,7 +65,13 @@ for C, M in ((64, 7741440), (128, 1935360)):
     lw, lb = torch.ones(C, device=dev), torch.zeros(C, device=dev)
     ms = timeit(lambda: ops.layernorm_fwd(x, lw, lb, 1e-5, out=dxo))
     report(f'layernorm_fwd C={C}', ms, M * 2 * C * 2, 0)
-    del x, dy4, y4, dxo, x2
+    dyc = rnd(M, C)
+    dlw, dlb = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    ms = timeit(lambda: ops.layernorm_bwd(x, lw, dyc, None, dlw, dlb, 1e-5))
+    report(f'layernorm_bwd C={C}', ms, M * 3 * C * 2, 0)
+    ms = timeit(lambda: ops.layernorm_bwd(x, lw, dyc, x2, dlw, dlb, 1e-5))
+    report(f'layernorm_bwd C={C} +dres', ms, M * 4 * C * 2, 0)
+    del x, dy4, y4, dxo, x2, dyc
 
 # write-pattern probe: same K, output width = 64 / 128 (full rows per tile) vs 256 (two tiles per row)
 M, C = 7741440, 64

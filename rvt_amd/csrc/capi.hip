@@ -232,7 +232,7 @@ int rvt_layernorm_bwd(const void* x, const float* w, const void* dy, const void*
     hipStream_t st = (hipStream_t)stream;
     int G = pow2_ge(C / 8);
     int rows_per_block = 4 * (64 / G);
-    int grid = imin(1024, imax(1, (rows + rows_per_block - 1) / rows_per_block));
+    int grid = imin(2048, imax(1, (rows + rows_per_block - 1) / rows_per_block));     // 8 workgroups (32 waves) per CU
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ln_bwd_kernel<T>), dim3(grid), dim3(256), 0, st, (const T*)x, w,
                                              (const T*)dy, (const T*)dres, (T*)dx, dw, db, rows, C, G, eps));
     return check_launch("layernorm_bwd");

@@ -508,9 +508,15 @@ struct EpPartialStore {
 __global__ void __launch_bounds__(256)
 splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int nsplit, size_t count) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
-        float a = 0.f;
-        for (int s = 0; s < nsplit; s++) a += ws[(size_t)s * count + i];
-        out[i] += a;
+        // eight independent partial sums: the slice loop is a chain of dependent loads otherwise (nsplit x memory latency)
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int s = 0;
+        for (; s + 8 <= nsplit; s += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) a[u] += ws[(size_t)(s + u) * count + i];
+        }
+        for (; s < nsplit; s++) a[0] += ws[(size_t)s * count + i];
+        out[i] += ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     }
 }
 

@@ -68,44 +68,50 @@ ln_bwd_kernel(const T* __restrict__ x, const float* __restrict__ w, const T* __r
 #pragma unroll
     for (int i = 0; i < 8; i++) { wv[i] = cvalid ? w[cl * 8 + i] : 0.f; aw[i] = 0.f; ab[i] = 0.f; }
     const int n_iter = (rows + rpw * n_waves - 1) / (rpw * n_waves);
-    for (int it = 0; it < n_iter; it++) {
-        const int row = (it * n_waves + wave_global) * rpw + lane / G;
-        const bool valid = cvalid && row < rows;
-        float v[8], d[8];
+    // two row groups per trip: all loads of both are issued before any arithmetic, and ahead of the previous pair's
+    // stores being waited for (bytes in flight per wave are what bounds this kernel)
+    for (int it = 0; it < n_iter; it += 2) {
+        int row[2]; bool valid[2];
+        frag_t<T> fx[2], fd[2], fr[2];
 #pragma unroll
-        for (int i = 0; i < 8; i++) { v[i] = 0.f; d[i] = 0.f; }
-        if (valid) {
-            frag_to_float<T>(frag_load<T>(x + (size_t)row * C + cl * 8), v);
-            frag_to_float<T>(frag_load<T>(dy + (size_t)row * C + cl * 8), d);
+        for (int u = 0; u < 2; u++) {
+            row[u] = ((it + u) * n_waves + wave_global) * rpw + lane / G;
+            valid[u] = cvalid && (it + u) < n_iter && row[u] < rows;
+            const size_t o = valid[u] ? (size_t)row[u] * C + cl * 8 : 0;
+            fx[u] = frag_load<T>(x + o);
+            fd[u] = frag_load<T>(dy + o);
+            fr[u] = dres ? frag_load<T>(dres + o) : frag_zero<T>();
         }
-        float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; i++) s += v[i];
-        const float mean = group_sum(s, G) / (float)C;
-        float q = 0.f;
+        for (int u = 0; u < 2; u++) {
+            float v[8], d[8], r[8];
+            frag_to_float<T>(fx[u], v); frag_to_float<T>(fd[u], d); frag_to_float<T>(fr[u], r);
 #pragma unroll
-        for (int i = 0; i < 8; i++) { float t = valid ? v[i] - mean : 0.f; q += t * t; }
-        const float rstd = 1.0f / sqrtf(group_sum(q, G) / (float)C + eps);
-        float xh[8], gsum = 0.f, gxsum = 0.f;
+            for (int i = 0; i < 8; i++) { v[i] = valid[u] ? v[i] : 0.f; d[i] = valid[u] ? d[i] : 0.f; }
+            float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            xh[i] = valid ? (v[i] - mean) * rstd : 0.f;
-            float g = d[i] * wv[i];
-            gsum += g; gxsum += g * xh[i];
-            aw[i] += d[i] * xh[i]; ab[i] += d[i];
-        }
-        const float m1 = group_sum(gsum, G) / (float)C;
-        const float m2 = group_sum(gxsum, G) / (float)C;
-        if (valid) {
-            float o[8];
+            for (int i = 0; i < 8; i++) s += v[i];
+            const float mean = group_sum(s, G) / (float)C;
+            float q = 0.f;
 #pragma unroll
-            for (int i = 0; i < 8; i++) o[i] = rstd * (d[i] * wv[i] - m1 - xh[i] * m2);
-            if (dres) {
-                float r[8]; frag_to_float<T>(frag_load<T>(dres + (size_t)row * C + cl * 8), r);
+            for (int i = 0; i < 8; i++) { float t = valid[u] ? v[i] - mean : 0.f; q += t * t; }
+            const float rstd = 1.0f / sqrtf(group_sum(q, G) / (float)C + eps);
+            float xh[8], gsum = 0.f, gxsum = 0.f;
 #pragma unroll
-                for (int i = 0; i < 8; i++) o[i] += r[i];
+            for (int i = 0; i < 8; i++) {
+                xh[i] = valid[u] ? (v[i] - mean) * rstd : 0.f;
+                float g = d[i] * wv[i];
+                gsum += g; gxsum += g * xh[i];
+                aw[i] += d[i] * xh[i]; ab[i] += d[i];
             }
-            frag_store<T>(dx + (size_t)row * C + cl * 8, frag_from_float<T>(o));
+            const float m1 = group_sum(gsum, G) / (float)C;
+            const float m2 = group_sum(gxsum, G) / (float)C;
+            if (valid[u]) {
+                float o[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) o[i] = rstd * (d[i] * wv[i] - m1 - xh[i] * m2) + r[i];
+                frag_store<T>(dx + (size_t)row[u] * C + cl * 8, frag_from_float<T>(o));
+            }
         }
     }
     // fold the 64/G row-lanes of a wave that own the same columns, then the 4 waves through LDS:
