@@ -130,6 +130,7 @@ def stage_seq_forward(sw: StageWeights, g: StageGeom, inp: Tensor, h0: Optional[
             qkv = ops.linear_fwd(u, bw['qkv_w'], bw['qkv_b'])                     # maxvit.py:347
             a = ops.attn_fwd(qkv, F_, H, W, C, g.dim_head, g.ph, g.pw, window)    # maxvit.py:349-352
             xmid = ops.linear_scale_res_fwd(a, bw['proj_w'], bw['proj_b'], bw['g1'], x)        # :353, :268
+            v2 = None
             if use_fused_mlp(dt, C, 'fwd_train' if save else 'fwd_infer'):
                 xout, hg, hgp = ops.mlp_fwd(xmid, bw['n2_w'], bw['n2_b'], bw['fc1_w'], bw['fc1_b'], bw['fc2_w'],
                                             bw['fc2_b'], bw['g2'], g.eps, want_grad=save)
@@ -139,7 +140,9 @@ def stage_seq_forward(sw: StageWeights, g: StageGeom, inp: Tensor, h0: Optional[
                 hg, hgp = ops.linear_gelu_fwd(v2, bw['fc1_w'], bw['fc1_b'], want_grad=save)
                 xout = ops.linear_scale_res_fwd(hg, bw['fc2_w'], bw['fc2_b'], bw['g2'], xmid)            # :269
             if save:
-                sv.blocks.append(dict(xin=x, qkv=qkv, a=a, xmid=xmid, hg=hg, hgp=hgp))
+                # the LayerNorm outputs are the B operands of the qkv / fc1 weight gradients: kept (1 row of C per token
+                # each, 288 GB of HBM) rather than recomputed — a recompute is a read + a write + the re-read
+                sv.blocks.append(dict(xin=x, qkv=qkv, a=a, xmid=xmid, hg=hg, hgp=hgp, u=u, v2=v2))
             x = xout
 
     Hall = torch.empty((T + 1, B, H, W, C), dtype=dt, device=dev)
@@ -265,7 +268,7 @@ def stage_seq_backward(sw: StageWeights, g: StageGeom, sv: StageSaved, dH: Optio
             else:
                 dhd = ops.linear_dgrad(dx, bw['fc2_wt'], mul=s['hgp'])
             def fc1_wgrad_fn(dhd=dhd, s=s, bw=bw, bp=bp):
-                v2 = ops.layernorm_fwd(s['xmid'], bw['n2_w'], bw['n2_b'], g.eps)
+                v2 = s['v2'] if s['v2'] is not None else ops.layernorm_fwd(s['xmid'], bw['n2_w'], bw['n2_b'], g.eps)
                 dW1 = zeros(4 * C, C)
                 db1 = zeros(4 * C)
                 ops.linear_wgrad(dhd, v2, dW1, colsum_out=db1)
@@ -292,7 +295,7 @@ def stage_seq_backward(sw: StageWeights, g: StageGeom, sv: StageSaved, dH: Optio
             dqkv = ops.attn_bwd(s['qkv'], da, F_, H, W, C, g.dim_head, g.ph, g.pw, window)
             del da
             def qkv_wgrad_fn(dqkv=dqkv, s=s, bw=bw, bp=bp):
-                u = s['xin'] if bw['n1_w'] is None else ops.layernorm_fwd(s['xin'], bw['n1_w'], bw['n1_b'], g.eps)
+                u = s['u']
                 dWq = zeros(3 * C, C)
                 dbq = zeros(3 * C)
                 ops.linear_wgrad(dqkv, u, dWq, colsum_out=dbq)
