@@ -332,6 +332,12 @@ def main():
     torch.cuda.synchronize()
     timer.records.clear()
 
+    # a full (generation-2) Python GC pass over the module / autograd object graph takes 30-90 ms and lands inside one
+    # step in three (seen as one 47-110 ms step among 16.6 ms ones on the Tiny workload): collect now and move the
+    # survivors to the permanent generation, as any long-running training loop would
+    import gc
+    gc.collect()
+    gc.freeze()
     barrier()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -343,13 +349,15 @@ def main():
         m.record()
         marks.append(m)
     e1.record()
+    host_enqueue = time.perf_counter() - t0          # Python + launch time of the K steps (the GPU is still running)
     barrier()
     wall = time.perf_counter() - t0
     per_step = [a.elapsed_time(b) for a, b in zip([e0] + marks[:-1], marks)]
     if rank == 0:
         print(f'[bench] per-step ms: {[round(x, 1) for x in per_step]}  reserved={torch.cuda.memory_reserved() / 2**30:.1f} GiB '
               f'peak_alloc={torch.cuda.max_memory_allocated() / 2**30:.1f} GiB '
-              f'alloc_retries={torch.cuda.memory_stats().get("num_alloc_retries", 0)}', file=sys.stderr, flush=True)
+              f'alloc_retries={torch.cuda.memory_stats().get("num_alloc_retries", 0)} '
+              f'host_enqueue_ms_per_step={1e3 * host_enqueue / args.steps:.1f}', file=sys.stderr, flush=True)
     timer.uninstall()
     if world > 1:
         tmax = torch.tensor([wall], device=device, dtype=torch.float64)
