@@ -17,6 +17,15 @@ elif op == 'fwd':           # y[M][256] = x W^T + b
 elif op == 'dgrad':         # dx[M][64] = dy W
     wt, dx = rnd(C, 4 * C), torch.empty(M, C, device=dev, dtype=dt)
     fn = lambda: ops.linear_dgrad(dy4, wt, out=dx)
+elif op == 'dgrad_k1024':   # stage-3 fc1 input gradient: dx[M][256] = dh[M][1024] W   (MFMA-heavier K loop)
+    M3 = 483840
+    dh, wt, dx = rnd(M3, 1024), rnd(256, 1024), torch.empty(M3, 256, device=dev, dtype=dt)
+    fn = lambda: ops.linear_dgrad(dh, wt, out=dx)
+elif op == 'fwd_k512':      # stage-4 fc1: y[M][2048] = x[M][512] W^T
+    M4 = 120960
+    x4, w4, b4 = rnd(M4, 512), rnd(2048, 512), torch.zeros(2048, device=dev)
+    y4 = torch.empty(M4, 2048, device=dev, dtype=dt)
+    fn = lambda: ops.linear_fwd(x4, w4, b4, out=y4)
 elif op in ('mlp_fwd', 'mlp_bwd'):
     lw, lb = torch.ones(C, device=dev), torch.zeros(C, device=dev)
     w1, w2 = rnd(4 * C, C) * 0.1, rnd(C, 4 * C) * 0.1
@@ -30,3 +39,6 @@ elif op in ('mlp_fwd', 'mlp_bwd'):
 for _ in range(3):
     fn()
 torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+print(f'[{op}] one launch: {e0.elapsed_time(e1):.3f} ms')

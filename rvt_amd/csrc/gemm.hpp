@@ -611,7 +611,7 @@ template <int BN, bool ONE_K> struct GemmSmem {
 };
 
 template <class T, int BN, bool TN, bool ONE_K, class ASrc, class AXf, class BSrc, class BXf, class Ep>
-__global__ void __launch_bounds__(256, (TN ? TN_WAVES : (BN == 64 && Ep::UNIT == 8 && sizeof(T) == 2 ? 3 : (BN == 128 && sizeof(T) == 4 ? 1 : 2))))
+__global__ void __launch_bounds__(256, (TN ? (sizeof(T) == 2 && BXf::identity ? TN_WAVES : 1) : (BN == 64 && Ep::UNIT == 8 && sizeof(T) == 2 ? 3 : (BN == 128 && sizeof(T) == 4 ? 1 : 2))))
 gemm_kernel(ASrc as, AXf axf, BSrc bs, BXf bxf, Ep ep, int M, int N, int K, int m_tiles, int n_tiles, int ksplit_len,
             float* a_colsum, int panel_major) {
     constexpr int BM = 128;
