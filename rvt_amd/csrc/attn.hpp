@@ -210,7 +210,7 @@ template <class T, int NB> struct AttnBwdLds {       // per wave
 };
 
 template <class T, int NB, int HG>
-__global__ void __launch_bounds__(64 * HG, 2)      // <= 256 VGPR+AGPR: two waves per SIMD instead of one
+__global__ void __launch_bounds__(64 * HG, NB == 3 ? 1 : 2)      // <= 256 VGPR+AGPR: two waves per SIMD (three key blocks need more)
 attn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ dout, T* __restrict__ dqkv, AttnGeom g) {
     constexpr int LP = 32 * NB, PITCH = LP + 8, PSP = 40;
     __shared__ __attribute__((aligned(16))) T Qt_all[HG][32 * PITCH];
