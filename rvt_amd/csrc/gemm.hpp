@@ -34,6 +34,8 @@ namespace rvt {
 template <class T> struct PlainSrc {
     const T* p; int ld; int rows; int cols;
     static constexpr bool LINEAR = true;               // element (row, seg, off) = linear_base(seg)[row * linear_ld() + off]
+    static constexpr bool UNIT_LINEAR = false;
+    __device__ __forceinline__ bool unit_linear(int, int, const T*&, size_t&) const { return false; }
     __device__ __forceinline__ const T* linear_base(int) const { return p; }
     __device__ __forceinline__ int linear_ld() const { return ld; }
     typedef const T* Ctx;
@@ -48,6 +50,8 @@ template <class T> struct PlainSrc {
 template <class T> struct ConcatSrc {   // [x | h], both [rows][C]
     const T* x; const T* h; int C; int rows; int cols;  // cols = 2C
     static constexpr bool LINEAR = true;
+    static constexpr bool UNIT_LINEAR = false;
+    __device__ __forceinline__ bool unit_linear(int, int, const T*&, size_t&) const { return false; }
     __device__ __forceinline__ const T* linear_base(int seg) const { return seg ? h : x; }
     __device__ __forceinline__ int linear_ld() const { return C; }
     typedef int Ctx;
@@ -90,6 +94,23 @@ template <class T> struct Im2colSrc {
         return ok ? q : nullptr;
     }
     __device__ __forceinline__ const T* safe() const { return p; }
+    // Eight consecutive output pixels tok0..tok0+7 of tap `seg`: when they share an output row and none of them falls
+    // into the padding, their source pixels are `stride` apart on one input row — one address and a constant step
+    // instead of eight decode / bounds-check / wrap sequences (the transposing loader's unit, see TNLoader::load).
+    static constexpr bool UNIT_LINEAR = true;
+    __device__ __forceinline__ bool unit_linear(int tok0, int seg, const T*& p0, size_t& step) const {
+        if ((Wo & 7) != 0 || tok0 + 8 > rows) return false;           // units never straddle rows iff Wo % 8 == 0
+        uint32_t f, rem, oy, ox, ky, kx;
+        dHoWo.divmod((uint32_t)tok0, f, rem);
+        dWo.divmod(rem, oy, ox);
+        dkw.divmod((uint32_t)seg, ky, kx);
+        const int iy = (int)oy * stride - pad + (int)ky;
+        const int ix = (int)ox * stride - pad + (int)kx;
+        if (iy < 0 || iy >= H || ix < 0 || ix + 7 * stride >= W) return false;
+        p0 = p + ((size_t)f * H * W + (size_t)iy * W + ix) * Cin;
+        step = (size_t)stride * Cin;
+        return true;
+    }
     // next output pixel in raster order: x+1, wrapping to the next row / frame (no divisions)
     __device__ __forceinline__ Ctx advance(const Ctx& c) const {
         Ctx n = c;
@@ -113,6 +134,8 @@ template <class T> struct DgradSrc {
     int rows; int cols;                             // cols = nky*nkx*Cout
     FastDiv dHcWc, dWc, dCout;
     static constexpr bool LINEAR = false;
+    static constexpr bool UNIT_LINEAR = false;
+    __device__ __forceinline__ bool unit_linear(int, int, const T*&, size_t&) const { return false; }
     __device__ __forceinline__ const T* linear_base(int) const { return dy; }
     __device__ __forceinline__ int linear_ld() const { return 0; }
     struct Ctx { int f; int y; int x; };
@@ -291,6 +314,15 @@ template <class T, int ROWS, class Src, class Xf, bool HIGH> struct TNLoader {
             for (int j = 0; j < 8; j++) R.r[j] = frag_load<T>(p + (size_t)j * ldl);
             R.vmask = 0xffu;
             return;
+        }
+        if (Src::UNIT_LINEAR && tok0 + 8 <= kend) {
+            const T* p0; size_t step;
+            if (s.unit_linear(tok0, seg, p0, step)) {            // interior unit of an im2col source
+#pragma unroll
+                for (int j = 0; j < 8; j++) R.r[j] = frag_load<T>(p0 + off + (size_t)j * step);
+                R.vmask = 0xffu;
+                return;
+            }
         }
         unsigned vmask = 0;
         // tokens tok0..tok0+7 are consecutive source rows: decode the first, step the rest (validity is by index,
@@ -669,6 +701,7 @@ gemm_kernel(ASrc as, AXf axf, BSrc bs, BXf bxf, Ep ep, int M, int N, int K, int 
     // Bias gradient of a TN launch = column sums of its A operand over the K slice.  They ride on the matrix cores:
     // A_tile . ones accumulates sum_k A[row][k] in every column of a 32x32 block, so the loader does no per-element
     // work for them.  The two waves that share an A row panel (wn = 0/1) take one 32-row block each.
+    constexpr bool CAN_COLSUM = TN && !BSrc::UNIT_LINEAR;      // (conv weights have no bias: no column sums, 16 registers back)
     f32x16 colacc;
     acc_zero(colacc);
     frag_t<T> ones;
@@ -689,7 +722,7 @@ gemm_kernel(ASrc as, AXf axf, BSrc bs, BXf bxf, Ep ep, int M, int N, int K, int 
             for (int i = 0; i < 2; i++)
 #pragma unroll
                 for (int j = 0; j < WN; j++) mma32(acc[i][j], a[i], b[j]);
-            if (TN && with_colsum) {                     // workgroup-uniform
+            if (CAN_COLSUM && with_colsum) {             // workgroup-uniform
                 if (wn == 0) mma32(colacc, a[0], ones);
                 else mma32(colacc, a[1], ones);
             }
@@ -746,7 +779,7 @@ gemm_kernel(ASrc as, AXf axf, BSrc bs, BXf bxf, Ep ep, int M, int N, int K, int 
         const int ncol = n0 + ep_cu * UNIT;
         const bool col_ok = ep_row0 < 64 && ncol < N;
         typename LA::Regs R0, R1;
-        const bool want_colsum = a_colsum != nullptr && n0 == 0;
+        const bool want_colsum = CAN_COLSUM && a_colsum != nullptr && n0 == 0;
         zero_acc();
         la.init(as, m0, tid);
         lb.init(bs, n0, tid);
