@@ -201,6 +201,39 @@ __device__ __forceinline__ void gelu_both_f(float x, float& g, float& gp) {
     g = x * c;
     gp = fmaf(x * 0.3989422804014327f, e, c);
 }
+// ... and for eight values: the same evaluation on float2 lanes with explicit fused multiply-adds, which map onto the
+// packed-fp32 VALU ops of CDNA (v_pk_fma_f32 / v_pk_mul_f32: two values per instruction; exp, rcp and the sign select
+// stay scalar).  ~40 % fewer VALU instructions than eight scalar evaluations in the fc1 epilogues.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) {
+#ifdef RVT_EMU
+    return f32x2{fmaf(a[0], b[0], c[0]), fmaf(a[1], b[1], c[1])};
+#else
+    return __builtin_elementwise_fma(a, b, c);
+#endif
+}
+__device__ __forceinline__ void gelu_both_8(const float (&x)[8], float (&g)[8], float (&gp)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+        const f32x2 v = {x[i], x[i + 1]};
+        const f32x2 av = {fabsf(v[0]), fabsf(v[1])};
+        const f32x2 d = fma2(av, f32x2{0.23164189f, 0.23164189f}, f32x2{1.0f, 1.0f});
+        const f32x2 t = {fast_rcp(d[0]), fast_rcp(d[1])};
+        const f32x2 a = v * v * -0.72134752044448170f;
+        const f32x2 e = {fast_exp2(a[0]), fast_exp2(a[1])};
+        f32x2 poly = fma2(t, f32x2{0.5307027145f, 0.5307027145f}, f32x2{-0.7265760135f, -0.7265760135f});
+        poly = fma2(t, poly, f32x2{0.7107068705f, 0.7107068705f});
+        poly = fma2(t, poly, f32x2{-0.142248368f, -0.142248368f});
+        poly = fma2(t, poly, f32x2{0.127414796f, 0.127414796f});
+        const f32x2 q = (t * poly) * e;
+        const f32x2 omq = 1.0f - q;
+        const f32x2 c = {v[0] < 0.0f ? q[0] : omq[0], v[1] < 0.0f ? q[1] : omq[1]};
+        const f32x2 gg = v * c;
+        const f32x2 dd = fma2(v * 0.3989422804014327f, e, c);
+        g[i] = gg[0]; g[i + 1] = gg[1];
+        gp[i] = dd[0]; gp[i + 1] = dd[1];
+    }
+}
 __device__ __forceinline__ float sigmoid_f(float x) { return fast_rcp(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanh_f(float x) {
     // tanh via exp; saturates correctly for large |x|

@@ -466,7 +466,8 @@ template <class T> struct EpGeluDual {         // g = gelu(v + bias), gp = gelu'
     __device__ __forceinline__ void apply(int m, int n, float (&v)[8], const Aux&, const Cols& c) const {
         float a[8], b[8];
 #pragma unroll
-        for (int i = 0; i < 8; i++) gelu_both_f(v[i] + c.v[i], a[i], b[i]);
+        for (int i = 0; i < 8; i++) v[i] += c.v[i];
+        gelu_both_8(v, a, b);
         frag_store<T>(g + (size_t)m * ld + n, frag_from_float<T>(a));
         if (gp) frag_store<T>(gp + (size_t)m * ld + n, frag_from_float<T>(b));
     }

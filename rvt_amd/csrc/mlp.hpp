@@ -287,7 +287,8 @@ mlp_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, T* __restrict__
                     float v[8], a[8], b[8];
                     stage_read8(stage, LD1, srow, cu * 8, v);
 #pragma unroll
-                    for (int e = 0; e < 8; e++) gelu_both_f(v[e] + b1v[e], a[e], b[e]);
+                    for (int e = 0; e < 8; e++) v[e] += b1v[e];
+                    gelu_both_8(v, a, b);
                     const frag_t<T> gf = frag_from_float<T>(a);
                     opm_store_frag<T>(Ah, TM, row, cu, gf);
                     if (g_out != nullptr && m0 + row < M) {
