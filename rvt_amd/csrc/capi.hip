@@ -69,7 +69,7 @@ static inline size_t wgrad_ws_floats(int Mg, int Ng, int tokens, int bn, int bk,
 }
 template <class T, int BN, class ASrc, class BSrc, class BXf>
 static void launch_wgrad(const ASrc& a, const BSrc& b, const BXf& bxf, float* out, float* colsum_out, float* ws,
-                         int Mg, int Ng, int tokens, hipStream_t st) {
+                         int Mg, int Ng, int tokens, hipStream_t st, bool transpose_out = false) {
     const int BK = TileGeom<T>::BK;
     const int ks = wgrad_ksplit(Mg, Ng, tokens, BN);
     const int ns = gemm_slices(tokens, ks, BK);
@@ -83,10 +83,10 @@ static void launch_wgrad(const ASrc& a, const BSrc& b, const BXf& bxf, float* ou
     EpPartialStore ep{ws, Ng, tile_elems, 0};
     launch_gemm<T, BN, true>(a, XfNone(), b, bxf, ep, Mg, Ng, tokens, ks, st, ws_cs);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for(tile_elems, 1024)), dim3(256), 0, st, (const float*)ws, out, ns,
-                       tile_elems);
+                       tile_elems, transpose_out ? Ng : 0);
     if (colsum_out)
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for((size_t)Mg, 64)), dim3(256), 0, st, (const float*)ws_cs,
-                           colsum_out, ns, (size_t)Mg);
+                           colsum_out, ns, (size_t)Mg, 0);
 }
 
 #define DISPATCH_DTYPE(dtype, ...)                                   \
@@ -123,7 +123,12 @@ int rvt_is_emulator(void) {
 size_t rvt_wgrad_workspace_floats(int dtype, int out_rows, int out_cols, int tokens, int want_colsum) {
     int bn = wgrad_bn(out_cols);
     int bk = dtype == RVT_F32 ? TileGeom<float>::BK : TileGeom<bf16>::BK;
-    return wgrad_ws_floats(out_rows, out_cols, tokens, bn, bk, want_colsum);
+    size_t n = wgrad_ws_floats(out_rows, out_cols, tokens, bn, bk, want_colsum);
+    if (out_rows <= 64) {                    // rvt_conv_wgrad may compute the transposed product (see there)
+        size_t nt = wgrad_ws_floats(out_cols, out_rows, tokens, 64, bk, want_colsum);
+        if (nt > n) n = nt;
+    }
+    return n;
 }
 
 int rvt_prepack_input(const void* src, int src_u8, void* dst, int dtype, int F, int Cin, int h, int w, int H, int W,
@@ -177,7 +182,15 @@ int rvt_conv_wgrad(const void* in, const void* dy, float* dw, float* ws, int dty
     DISPATCH_DTYPE(dtype, {
         Im2colSrc<T> b = make_im2col<T>(in, F, H, W, Cin, k, stride, pad);
         PlainSrc<T> a{(const T*)dy, Cout, b.rows, Cout};
-        DISPATCH_WGRAD_BN(b.cols, (launch_wgrad<T, BN>(a, b, XfNone(), dw, nullptr, ws, Cout, b.cols, b.rows, st)));
+        if (Cout <= 64 && ws != nullptr) {
+            // narrow output-channel count (the stem): dW^T = im2col^T dy, so that the 128-row operand is the wide one
+            // (k*k*Cin patch columns) and dy fills a 64-column tile exactly — a [Cout <= 64][.] tile would leave half of
+            // every MFMA empty; the reduction writes the transpose back
+            constexpr int BN = 64;
+            launch_wgrad<T, BN>(b, a, XfNone(), dw, nullptr, ws, b.cols, Cout, b.rows, st, true);
+        } else {
+            DISPATCH_WGRAD_BN(b.cols, (launch_wgrad<T, BN>(a, b, XfNone(), dw, nullptr, ws, Cout, b.cols, b.rows, st)));
+        }
     });
     return check_launch("conv_wgrad");
 }

@@ -537,9 +537,9 @@ struct EpPartialStore {
     }
 };
 
-// out[i] += sum_s ws[s][i]
+// out[i] += sum_s ws[s][i]; with t_cols > 0 the partial tiles are [count / t_cols][t_cols] and `out` is their transpose
 __global__ void __launch_bounds__(256)
-splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int nsplit, size_t count) {
+splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int nsplit, size_t count, int t_cols) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
         // eight independent partial sums: the slice loop is a chain of dependent loads otherwise (nsplit x memory latency)
         float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -549,7 +549,9 @@ splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int 
             for (int u = 0; u < 8; u++) a[u] += ws[(size_t)(s + u) * count + i];
         }
         for (; s < nsplit; s++) a[0] += ws[(size_t)s * count + i];
-        out[i] += ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+        size_t o = i;
+        if (t_cols > 0) { const size_t r = i / t_cols, c = i % t_cols; o = c * (count / t_cols) + r; }
+        out[o] += ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     }
 }
 
@@ -702,7 +704,7 @@ gemm_kernel(ASrc as, AXf axf, BSrc bs, BXf bxf, Ep ep, int M, int N, int K, int 
     // Bias gradient of a TN launch = column sums of its A operand over the K slice.  They ride on the matrix cores:
     // A_tile . ones accumulates sum_k A[row][k] in every column of a 32x32 block, so the loader does no per-element
     // work for them.  The two waves that share an A row panel (wn = 0/1) take one 32-row block each.
-    constexpr bool CAN_COLSUM = TN && !BSrc::UNIT_LINEAR;      // (conv weights have no bias: no column sums, 16 registers back)
+    constexpr bool CAN_COLSUM = TN && !BSrc::UNIT_LINEAR && !ASrc::UNIT_LINEAR;      // (conv weights have no bias: no column sums, 16 registers back)
     f32x16 colacc;
     acc_zero(colacc);
     frag_t<T> ones;
