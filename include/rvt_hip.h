@@ -137,6 +137,14 @@ int rvt_token_mask_bwd(void* dx, const unsigned char* mask, float* dtoken, int d
  * st is [B][per_sample] of float32 (is_f32) or `dtype`. */
 int rvt_state_reset_masked(void* st, const unsigned char* mask, int dtype, int B, size_t per_sample, void* stream);
 
+/* Event stream -> stacked histogram, the uint8 event tensor the backbone consumes (data/utils/representations.py:76-117,
+ * StackedHistogram.construct): x, y, pol (0/1), time are int64 [n_events], time sorted ascending.
+ * out[(pol*bins + t_idx)][y][x] = min(count, count_cutoff) as uint8 [2*bins][H][W], with the reference's accumulator
+ * wrap-around (uint8 if fastmode else int16).  scratch: 2*bins*H*W uint32 (zeroed here).  Bit-exact. */
+int rvt_stacked_histogram(const long long* x, const long long* y, const long long* pol, const long long* time,
+                          size_t n_events, int bins, int H, int W, int count_cutoff, int fastmode, unsigned* scratch,
+                          unsigned char* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,6 +17,14 @@ elif op == 'fwd':           # y[M][256] = x W^T + b
 elif op == 'dgrad':         # dx[M][64] = dy W
     wt, dx = rnd(C, 4 * C), torch.empty(M, C, device=dev, dtype=dt)
     fn = lambda: ops.linear_dgrad(dy4, wt, out=dx)
+elif op in ('attn_fwd', 'attn_bwd'):    # stage-1 window attention core: 504 frames of 96x160 tokens, C=64, 2 heads of 32
+    F_, H, W = 504, 96, 160
+    qkv = rnd(F_ * H * W, 3 * C)
+    if op == 'attn_fwd':
+        fn = lambda: ops.attn_fwd(qkv, F_, H, W, C, 32, 6, 10, True)
+    else:
+        do = rnd(F_ * H * W, C)
+        fn = lambda: ops.attn_bwd(qkv, do, F_, H, W, C, 32, 6, 10, True)
 elif op == 'dgrad_k1024':   # stage-3 fc1 input gradient: dx[M][256] = dh[M][1024] W   (MFMA-heavier K loop)
     M3 = 483840
     dh, wt, dx = rnd(M3, 1024), rnd(256, 1024), torch.empty(M3, 256, device=dev, dtype=dt)

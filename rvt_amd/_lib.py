@@ -23,6 +23,7 @@ _is_emu = False
 
 _vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
 _SIGS = {
+    'rvt_stacked_histogram': [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     'rvt_prepack_input': [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     'rvt_conv_fwd': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     'rvt_conv_dgrad': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],

@@ -10,6 +10,7 @@
 #include "rowops.hpp"
 #include "attn.hpp"
 #include "mlp.hpp"
+#include "events.hpp"
 #include "../../include/rvt_hip.h"
 
 namespace rvt {
@@ -580,6 +581,22 @@ int rvt_token_mask_bwd(void* dx, const unsigned char* mask, float* dtoken, int d
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((token_mask_bwd_kernel<T>), dim3(gx, gy), dim3(256), 0, st, (T*)dx, mask, dtoken,
                                              M, C, NCP));
     return check_launch("token_mask_bwd");
+}
+
+int rvt_stacked_histogram(const long long* x, const long long* y, const long long* pol, const long long* time,
+                          size_t n_events, int bins, int H, int W, int count_cutoff, int fastmode, unsigned* scratch,
+                          unsigned char* out, void* stream) {
+    RVT_CHECK(bins >= 1 && H >= 1 && W >= 1 && count_cutoff >= 1 && count_cutoff <= 255,
+              "stacked_histogram: bad geometry bins=%d H=%d W=%d cutoff=%d", bins, H, W, count_cutoff);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t cells = (size_t)2 * bins * H * W;
+    hipMemsetAsync(scratch, 0, cells * sizeof(unsigned), st);
+    if (n_events > 0)
+        hipLaunchKernelGGL(hist_count_kernel, dim3(grid_for(n_events, 4096)), dim3(256), 0, st, x, y, pol, time, n_events, bins,
+                           H, W, scratch);
+    hipLaunchKernelGGL(hist_finalize_kernel, dim3(grid_for(cells, 4096)), dim3(256), 0, st, (const unsigned*)scratch, out,
+                       cells, count_cutoff, fastmode);
+    return check_launch("stacked_histogram");
 }
 
 int rvt_state_reset_masked(void* st_, const unsigned char* mask, int dtype, int B, size_t per_sample, void* stream) {
