@@ -35,6 +35,7 @@ template <class T> struct PlainSrc {
     const T* p; int ld; int rows; int cols;
     static constexpr bool LINEAR = true;               // element (row, seg, off) = linear_base(seg)[row * linear_ld() + off]
     static constexpr bool UNIT_LINEAR = false;
+    static constexpr bool SPATIAL_REUSE = false;
     __device__ __forceinline__ bool unit_linear(int, int, const T*&, size_t&) const { return false; }
     __device__ __forceinline__ const T* linear_base(int) const { return p; }
     __device__ __forceinline__ int linear_ld() const { return ld; }
@@ -51,6 +52,7 @@ template <class T> struct ConcatSrc {   // [x | h], both [rows][C]
     const T* x; const T* h; int C; int rows; int cols;  // cols = 2C
     static constexpr bool LINEAR = true;
     static constexpr bool UNIT_LINEAR = false;
+    static constexpr bool SPATIAL_REUSE = false;
     __device__ __forceinline__ bool unit_linear(int, int, const T*&, size_t&) const { return false; }
     __device__ __forceinline__ const T* linear_base(int seg) const { return seg ? h : x; }
     __device__ __forceinline__ int linear_ld() const { return C; }
@@ -70,6 +72,7 @@ template <class T> struct Im2colSrc {
     const T* p; int H, W, Cin, Ho, Wo, kw, stride, pad; int rows; int cols;  // cols = kh*kw*Cin
     FastDiv dHoWo, dWo, dkw, dCin;
     static constexpr bool LINEAR = false;
+    static constexpr bool SPATIAL_REUSE = true;
     __device__ __forceinline__ const T* linear_base(int) const { return p; }
     __device__ __forceinline__ int linear_ld() const { return 0; }
     struct Ctx { int base; int iy0; int ix0; };
@@ -135,6 +138,7 @@ template <class T> struct DgradSrc {
     FastDiv dHcWc, dWc, dCout;
     static constexpr bool LINEAR = false;
     static constexpr bool UNIT_LINEAR = false;
+    static constexpr bool SPATIAL_REUSE = true;
     __device__ __forceinline__ bool unit_linear(int, int, const T*&, size_t&) const { return false; }
     __device__ __forceinline__ const T* linear_base(int) const { return dy; }
     __device__ __forceinline__ int linear_ld() const { return 0; }
@@ -646,7 +650,7 @@ template <int BN, bool ONE_K> struct GemmSmem {
 };
 
 template <class T, int BN, bool TN, bool ONE_K, class ASrc, class AXf, class BSrc, class BXf, class Ep>
-__global__ void __launch_bounds__(256, (TN ? (sizeof(T) == 2 && BXf::identity ? TN_WAVES : 1) : (BN == 64 && Ep::UNIT == 8 && sizeof(T) == 2 ? 3 : (BN == 128 && sizeof(T) == 4 ? 1 : 2))))
+__global__ void __launch_bounds__(256, (TN ? (sizeof(T) == 2 && BXf::identity ? TN_WAVES : 1) : (BN == 64 && Ep::UNIT == 8 && sizeof(T) == 2 && AXf::identity ? 3 : (BN == 128 && sizeof(T) == 4 ? 1 : 2))))
 gemm_kernel(ASrc as, AXf axf, BSrc bs, BXf bxf, Ep ep, int M, int N, int K, int m_tiles, int n_tiles, int ksplit_len,
             float* a_colsum, int panel_major) {
     constexpr int BM = 128;
@@ -675,6 +679,17 @@ gemm_kernel(ASrc as, AXf axf, BSrc bs, BXf bxf, Ep ep, int M, int N, int K, int 
     // workgroup per (tile, K-slice)).  panel_major: a workgroup sweeps all N tiles of its 128-row panel so the
     // A panel comes from HBM once; otherwise tiles are dealt round-robin with N fastest.
     auto tile_of = [&](int seq, int& mt, int& nt) -> bool {
+        if (panel_major == 2) {
+            // gather sources (im2col / conv-dgrad): neighbouring output tiles re-read each other's input rows (a 7x7
+            // stride-4 window shares 3 of its 7 rows with the next output row).  Workgroups are dispatched round-robin
+            // over the 8 XCDs, so give every XCD one CONTIGUOUS eighth of the tile sequence and let its workgroups walk
+            // it side by side: the re-reads then hit that XCD's L2 instead of going back to HBM.
+            const int per = G >> 3, total = m_tiles * n_tiles, chunk = (total + 7) >> 3;
+            const int w = (bx >> 3) + seq * per;
+            const int t = (bx & 7) * chunk + w;
+            mt = t / n_tiles; nt = t - mt * n_tiles;
+            return w < chunk && t < total;
+        }
         if (panel_major) { mt = bx + (seq / n_tiles) * G; nt = seq % n_tiles; return mt < m_tiles; }
         const int t = bx + seq * G;
         mt = t / n_tiles; nt = t - mt * n_tiles;
@@ -949,6 +964,7 @@ inline void launch_gemm(const ASrc& as, const AXf& axf, const BSrc& bs, const BX
         const int resident = resident_override > 0 ? resident_override : 256 * per_cu;
         if (total > resident) gx = resident;
         panel_major = (n_tiles > 1 && m_tiles >= 4 * gx) ? 1 : 0;
+        if (ASrc::SPATIAL_REUSE && total > gx && (gx & 7) == 0) panel_major = 2;
     }
     if (one_k)                // whole contraction in one K tile: single operand stage, more workgroups per CU
         hipLaunchKernelGGL((gemm_kernel<T, BN, TN, true, ASrc, AXf, BSrc, BXf, Ep>), dim3(gx, nsplit), dim3(256), 0, stream,
