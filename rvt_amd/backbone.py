@@ -306,6 +306,9 @@ class _BackboneSeqFn(torch.autograd.Function):
                 state_grads[2 * si] = dh0.permute(0, 3, 1, 2)
                 state_grads[2 * si + 1] = dc0.permute(0, 3, 1, 2)
             ctx.svs[si] = None
+        finish = getattr(mod, '_stage_grad_finish', None)
+        if finish is not None:            # data parallel: order everything downstream after the per-stage all-reduces
+            finish()
         pgrads = []
         for i, n in enumerate(mod._param_names):
             gr = grads_by_name.get(n)

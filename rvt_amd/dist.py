@@ -18,8 +18,9 @@ import torch.distributed as dist
 
 
 class StageGradReducer:
-    """Attach with ``reducer.attach(model)``; call ``reducer.finish()`` after ``loss.backward()`` and
-    before the optimizer step."""
+    """Attach with ``reducer.attach(model)``.  The backbone's backward waits for the collectives itself before it
+    returns the gradients; ``reducer.finish()`` after ``loss.backward()`` is harmless (idempotent) and kept for callers
+    that drive the hook by hand."""
 
     def __init__(self, process_group=None, average: bool = True):
         self.pg = process_group
@@ -29,6 +30,10 @@ class StageGradReducer:
 
     def attach(self, model) -> 'StageGradReducer':
         model._stage_grad_hook = self.on_stage_done
+        # the backbone calls this at the very end of its backward, before the gradients (views of the buckets) are
+        # handed to autograd: whatever reads them next (AccumulateGrad may clone, the optimizer) is then stream-ordered
+        # after the collectives, while the collectives themselves still overlap the backward of the later stages
+        model._stage_grad_finish = self.finish
         return self
 
     @property
