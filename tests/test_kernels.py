@@ -291,6 +291,8 @@ CONV_CASES = [  # F, H, W, Cin, Cout, k, s, p
     (1, 16, 24, 20, 16, 7, 4, 3),     # stem: Cin=20 padded to 24
     (2, 8, 8, 16, 24, 2, 2, 0),       # non-overlapping patch (overlap=False)
     (1, 6, 10, 72, 136, 3, 2, 1),
+    (2, 8, 32, 16, 32, 3, 2, 1),      # output width 16: the weight gradient's unit-linear im2col path, Cout <= 64 (transposed product)
+    (1, 16, 64, 20, 72, 7, 4, 3),     # ... same with the stem geometry and Cout > 64 (direct product)
 ]
 
 
