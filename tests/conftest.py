@@ -6,7 +6,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # Test-size problems have only a handful of GEMM tiles; shrink the persistent grid (normally ~2-3 workgroups per CU)
 # so that the multi-tile walk + cross-tile prefetch of gemm_kernel is what the tests execute (emulator AND GPU).
-os.environ.setdefault('RVT_GEMM_RESIDENT', '3')
+os.environ.setdefault('RVT_GEMM_RESIDENT', '8')     # (a multiple of 8: also reaches the XCD-contiguous walk of the conv sources)
 # ... and let the weight-gradient kernels cut even test-size token counts into several K slices (production: >= 8192
 # tokens per slice), so the two-stage split-K path (partial tiles + reduction, column sums per slice) is exercised
 os.environ.setdefault('RVT_WGRAD_SLICE_TOKENS', '128')
