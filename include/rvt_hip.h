@@ -84,12 +84,13 @@ int rvt_colsum(const void* x, float* out, int dtype, int rows, int N, void* stre
 /* Fused MLP half of a block (maxvit.py:269 + :100-118), built for the HBM-bound stages:
  * rvt_mlp_fused_supported(dtype, C) != 0  (bf16: C in {64,128}; f32: C == 64).
  *   rvt_mlp_fwd:  xout = xmid + gamma * (GELU(LN(xmid) W1^T + b1) W2^T + b2) in one pass; if g_out/gp_out are non-NULL
- *                 also g = GELU(h), gp = GELU'(h) [M][4C] for backward (nothing else of the chain reaches HBM).
+ *                 also g = GELU(h), gp = GELU'(h) [M][4C] for backward, and if v2_out is non-NULL the LayerNorm output
+ *                 LN(xmid) [M][C] (B operand of the fc1 weight gradient); nothing else of the chain reaches HBM.
  *   rvt_mlp_bwd_dgrad: dh = (dxout (W2*gamma)) * gp;  dxmid = dxout + LN'(dh W1; xmid);  dln_w/dln_b += LayerNorm
  *                 parameter gradients.  w2g_t = (W2*gamma[:,None])^T stored [4C][C]; w1_t = W1^T stored [C][4C].
  * w1 [4C][C], w2 [C][4C] (dtype); ln/bias/gamma and dln_* float32. */
 int rvt_mlp_fused_supported(int dtype, int C);
-int rvt_mlp_fwd(const void* xmid, void* xout, void* g_out, void* gp_out, const float* ln_w, const float* ln_b,
+int rvt_mlp_fwd(const void* xmid, void* xout, void* g_out, void* gp_out, void* v2_out, const float* ln_w, const float* ln_b,
                 const void* w1, const float* b1, const void* w2, const float* b2, const float* gamma, int dtype, int M,
                 int C, float eps, void* stream);
 int rvt_mlp_bwd_dgrad(const void* dxout, const void* gp, const void* xmid, void* dh, void* dxmid, const float* ln_w,

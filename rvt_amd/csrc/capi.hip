@@ -379,7 +379,7 @@ template <class K> static int mlp_grid(K kernel, int M, int tm) {
 }
 extern "C" {
 
-int rvt_mlp_fwd(const void* xmid, void* xout, void* g_out, void* gp_out, const float* ln_w, const float* ln_b,
+int rvt_mlp_fwd(const void* xmid, void* xout, void* g_out, void* gp_out, void* v2_out, const float* ln_w, const float* ln_b,
                 const void* w1, const float* b1, const void* w2, const float* b2, const float* gamma, int dtype, int M,
                 int C, float eps, void* stream) {
     RVT_CHECK(rvt_mlp_fused_supported(dtype, C), "mlp_fwd: fused MLP not built for dtype=%d C=%d", dtype, C);
@@ -388,7 +388,8 @@ int rvt_mlp_fwd(const void* xmid, void* xout, void* g_out, void* gp_out, const f
     const int tm = mlp_tm(dtype, C);
 #define RVT_MLP_FWD(TT, CC, TMM)                                                                                           \
     hipLaunchKernelGGL((mlp_fwd_kernel<TT, CC, TMM>), dim3(mlp_grid(mlp_fwd_kernel<TT, CC, TMM>, M, tm)), dim3(256), 0, st, \
-                       (const TT*)xmid, (TT*)xout, (TT*)g_out, (TT*)gp_out, ln_w, ln_b, (const TT*)w1, b1, (const TT*)w2,  \
+                       (const TT*)xmid, (TT*)xout, (TT*)g_out, (TT*)gp_out, (TT*)v2_out, ln_w, ln_b, (const TT*)w1, b1,    \
+                       (const TT*)w2,                                                                                       \
                        b2, gamma, M, eps)
     if (dtype == RVT_BF16 && C == 64 && tm == 128) RVT_MLP_FWD(bf16, 64, 128);
     else if (dtype == RVT_BF16 && C == 64) RVT_MLP_FWD(bf16, 64, 64);

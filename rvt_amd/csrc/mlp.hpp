@@ -174,7 +174,7 @@ template <int N> __device__ __forceinline__ void load_cols(const float* p, int c
 template <class T, int C, int TM>
 __global__ void __launch_bounds__(256, (sizeof(T) == 2 && C == 64 && TM == 64) ? MLP_WAVES : 1)
 mlp_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, T* __restrict__ g_out, T* __restrict__ gp_out,
-               const float* __restrict__ ln_w, const float* __restrict__ ln_b, const T* __restrict__ W1,
+               T* __restrict__ v2_out, const float* __restrict__ ln_w, const float* __restrict__ ln_b, const T* __restrict__ W1,
                const float* __restrict__ b1, const T* __restrict__ W2, const float* __restrict__ b2,
                const float* __restrict__ gamma, int M, float eps) {
     typedef MlpSmem<T, C, TM> S;
@@ -235,7 +235,10 @@ mlp_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, T* __restrict__
             load_cols<8>(k_lnw, cl * 8, lnw); load_cols<8>(k_lnb, cl * 8, lnb);
 #pragma unroll
             for (int e = 0; e < 8; e++) o[e] = ok ? (v[e] - mean) * rstd * lnw[e] + lnb[e] : 0.f;
-            opm_store_frag<T>(Ax, TM, row, cl, frag_from_float<T>(o));
+            const frag_t<T> of = frag_from_float<T>(o);
+            opm_store_frag<T>(Ax, TM, row, cl, of);
+            if (v2_out != nullptr && ok)      // LN2(xmid): the B operand of the fc1 weight gradient (saved, not recomputed)
+                frag_store<T>(v2_out + (size_t)(tile * TM + row) * C + cl * 8, of);
         }
     };
 

@@ -132,8 +132,10 @@ def stage_seq_forward(sw: StageWeights, g: StageGeom, inp: Tensor, h0: Optional[
             xmid = ops.linear_scale_res_fwd(a, bw['proj_w'], bw['proj_b'], bw['g1'], x)        # :353, :268
             v2 = None
             if use_fused_mlp(dt, C, 'fwd_train' if save else 'fwd_infer'):
-                xout, hg, hgp = ops.mlp_fwd(xmid, bw['n2_w'], bw['n2_b'], bw['fc1_w'], bw['fc1_b'], bw['fc2_w'],
-                                            bw['fc2_b'], bw['g2'], g.eps, want_grad=save)
+                r = ops.mlp_fwd(xmid, bw['n2_w'], bw['n2_b'], bw['fc1_w'], bw['fc1_b'], bw['fc2_w'], bw['fc2_b'], bw['g2'],
+                                g.eps, want_grad=save, want_v2=save)
+                xout, hg, hgp = r[:3]
+                v2 = r[3] if save else None     # LN2(xmid), saved for the fc1 weight gradient
             else:
                 v2 = ops.layernorm_fwd(xmid, bw['n2_w'], bw['n2_b'], g.eps)
                 # MLP fc1 + exact GELU; GELU' is saved too so backward never re-evaluates erf (maxvit.py:100-112)

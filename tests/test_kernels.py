@@ -88,7 +88,7 @@ def test_mlp_fused(backend, dt, C, M):
     w2, b2 = rnd((C, 4 * C), backend, dt, 6, 0.1), rnd((C,), backend, torch.float32, 7, 0.2)
     gam = rnd((C,), backend, torch.float32, 8)
     dy = rnd((M, C), backend, dt, 9)
-    y, g, gp = ops.mlp_fwd(x, lw, lb, w1, b1, w2, b2, gam, 1e-5, want_grad=True)
+    y, g, gp, v2_saved = ops.mlp_fwd(x, lw, lb, w1, b1, w2, b2, gam, 1e-5, want_grad=True, want_v2=True)
     y_inf, g_none, _ = ops.mlp_fwd(x, lw, lb, w1, b1, w2, b2, gam, 1e-5, want_grad=False)
     assert g_none is None and torch.equal(y.cpu(), y_inf.cpu())
 
@@ -102,6 +102,7 @@ def test_mlp_fused(backend, dt, C, M):
     want.backward(f64(dy))
     mult = 1.0 if dt == torch.float32 else 2.0
     close(y, want, dt, 'mlp_fwd fused', mult=mult)
+    close(v2_saved, v2, dt, 'mlp_fwd saved LayerNorm output', mult=mult)
     close(g, h, dt, 'mlp_fwd g', mult=mult)
     hp = f64(pre.detach()).requires_grad_(True)
     F.gelu(hp).sum().backward()
