@@ -137,7 +137,8 @@ int rvt_prepack_input(const void* src, int src_u8, void* dst, int dtype, int F, 
     RVT_CHECK(Cp % 8 == 0 && Cp >= Cin && H >= h && W >= w, "prepack: bad shape Cp=%d Cin=%d", Cp, Cin);
     hipStream_t st = (hipStream_t)stream;
     RVT_CHECK(Cin <= 32, "prepack: Cin=%d > 32 staged channels", Cin);
-    size_t items = (size_t)F * H * ((W + PREPACK_SEG - 1) / PREPACK_SEG);
+    const int seg = src_u8 ? PrepackSeg<unsigned char>::value : PrepackSeg<float>::value;
+    size_t items = (size_t)F * H * ((W + seg - 1) / seg);
     int grid = (int)(items < 16384 ? (items < 1 ? 1 : items) : 16384);
     DISPATCH_DTYPE(dtype, {
         if (src_u8)
