@@ -2,6 +2,9 @@
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rvt_amd import ops
+if '--lib' in sys.argv:
+    from rvt_amd import _lib
+    _lib._install_test_library(_lib.load_library(os.path.abspath(sys.argv[sys.argv.index('--lib') + 1])))
 
 dev, dt = torch.device('cuda', 0), torch.bfloat16
 op = sys.argv[1] if len(sys.argv) > 1 else 'wgrad'
