@@ -846,7 +846,6 @@ gemm_kernel(ASrc as, AXf axf, BSrc bs, BXf bxf, Ep ep, int M, int N, int K, int 
         side_fetch(m0, ncol, col_ok, cols, aux);
         epilogue(m0, ncol, col_ok, cols, aux);
     } else {
-        typename LA::Regs nr;                            // (NT loaders keep their own registers)
         int seq = 0, mt, nt;
         bool have = tile_of(0, mt, nt);
         if (have && nk > 0) {
@@ -918,7 +917,6 @@ gemm_kernel(ASrc as, AXf axf, BSrc bs, BXf bxf, Ep ep, int M, int N, int K, int 
                 lb.store(smem + BM * 128, bxf, tid);
             }
         }
-        (void)nr;
     }
 }
 
