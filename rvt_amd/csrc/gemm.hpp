@@ -196,7 +196,6 @@ template <class T, class Xf> __device__ __forceinline__ frag_t<T> xf_apply(const
 template <class T, int ROWS, class Src, class Xf> struct NTLoader {
     static constexpr int FPR = TileGeom<T>::FPR;
     static constexpr int NF = ROWS * FPR / 256;
-    struct Regs {};                                       // (interface symmetry with TNLoader: NT keeps its registers itself)
     typename Src::Ctx ctx[NF];
     frag_t<T> r[NF];
     bool valid[NF];
