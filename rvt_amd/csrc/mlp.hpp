@@ -172,7 +172,7 @@ template <int N> __device__ __forceinline__ void load_cols(const float* p, int c
 
 // ===================================================================================================== forward
 template <class T, int C, int TM>
-__global__ void __launch_bounds__(256, (sizeof(T) == 2 && C == 64 && TM == 64) ? MLP_WAVES : 1)
+__global__ void __launch_bounds__(256, (sizeof(T) == 2 && TM == 64) ? MLP_WAVES : 1)
 mlp_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, T* __restrict__ g_out, T* __restrict__ gp_out,
                T* __restrict__ v2_out, const float* __restrict__ ln_w, const float* __restrict__ ln_b, const T* __restrict__ W1,
                const float* __restrict__ b1, const T* __restrict__ W2, const float* __restrict__ b2,

@@ -26,16 +26,19 @@ from .weights import StageWeights, unpack_conv_wgrad
 
 def use_fused_mlp(dtype, C: int, what: str) -> bool:
     """Which MLP halves go through the fused kernels of csrc/mlp.hpp (built for C in {64,128}).
-    Default = where they measured faster than the op-by-op chain on MI355X (profiles/microbench_mlp.py, bf16, ms):
-      C=64 : training forward 4.06 vs 4.30, inference forward 2.92 vs 4.30, backward dgrad chain 2.90 vs 4.57 -> fused
-      C=128: 3.26 vs 2.45 / 2.40 vs 2.45 / 2.51 vs 2.29 (weight panels are re-staged per 64-token tile)      -> chain
+    Default = where they measured faster than the op-by-op chain on MI355X (profiles/microbench_mlp.py, bf16, ms, fused
+    vs chain):
+      C=64 : training forward 3.00 / 3.72, inference forward 2.03 / 3.72, backward dgrad chain 2.31 / 3.51 -> fused
+      C=128: training forward 1.75 / 2.11, inference forward 1.53 / 2.11                                    -> fused
+             backward dgrad chain 2.19 / 1.89 (one workgroup per CU: registers)                            -> chain
+    The two directions are independent: the fused forward saves exactly what the chain backward reads (g, GELU', LN2 out).
     RVT_FUSED_MLP=1 forces every supported case (used by the parity tests), =0 disables all."""
     mode = os.environ.get('RVT_FUSED_MLP', 'auto')
     if mode == '0' or not ops.mlp_fused_supported(dtype, C):
         return False
     if mode == '1':
         return True
-    return C == 64
+    return C == 64 or (C == 128 and what.startswith('fwd'))
 
 
 class SideStream:
