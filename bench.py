@@ -240,6 +240,9 @@ def main():
     ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--no-optimizer', action='store_true')
     ap.add_argument('--op-breakdown', default=None, help='write a per-op HIP-event time table to this path')
+    ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
+                    help='replay the step as one captured hipGraph (rvt_amd/graph.py).  auto = on for a single GPU')
+    ap.add_argument('--force-reducer', action='store_true', help='run the RCCL bucket all-reduce even at world size 1')
     ap.add_argument('--stream-latency', action='store_true',
                     help='BASELINE configs[4] instead of the training step: T=1 streaming inference with persistent '
                          'ConvLSTM state, batch 64; prints per-step latency percentiles (not the headline metric)')
@@ -260,7 +263,7 @@ def main():
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
     import torch.distributed as dist
-    if world > 1:
+    if world > 1 or args.force_reducer:
         dist.init_process_group('nccl', device_id=device)      # "nccl" = RCCL on ROCm
 
     dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
@@ -268,9 +271,10 @@ def main():
         return stream_latency(wl, dtype, device, args)
     model = build_model(wl, dtype, device)
     params = [p for p in model.parameters()]
-    opt = None if args.no_optimizer else torch.optim.AdamW(params, lr=2e-4, fused=True)
+    use_graph = args.graph == 'on' or (args.graph == 'auto' and world == 1 and not args.force_reducer)
+    opt = None if args.no_optimizer else torch.optim.AdamW(params, lr=2e-4, fused=True, capturable=use_graph)
     from rvt_amd.dist import StageGradReducer
-    reducer = StageGradReducer().attach(model) if world > 1 else None
+    reducer = StageGradReducer(force=args.force_reducer).attach(model) if (world > 1 or args.force_reducer) else None
 
     xs = make_batch(wl, device, seed=1 + rank)
     T, B = wl['T'], wl['B']
@@ -338,26 +342,48 @@ def main():
     import gc
     gc.collect()
     gc.freeze()
-    barrier()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()
-    marks = []
-    for _ in range(args.steps):
-        step()
-        m = torch.cuda.Event(enable_timing=True)
-        m.record()
-        marks.append(m)
-    e1.record()
-    host_enqueue = time.perf_counter() - t0          # Python + launch time of the K steps (the GPU is still running)
-    barrier()
-    wall = time.perf_counter() - t0
-    per_step = [a.elapsed_time(b) for a, b in zip([e0] + marks[:-1], marks)]
+
+    def timed_region(fn):
+        barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        marks = []
+        for _ in range(args.steps):
+            fn()
+            m = torch.cuda.Event(enable_timing=True)
+            m.record()
+            marks.append(m)
+        e1.record()
+        host = time.perf_counter() - t0               # Python + launch time of the K steps (the GPU is still running)
+        barrier()
+        wall_ = time.perf_counter() - t0
+        return wall_, host, [a.elapsed_time(b) for a, b in zip([e0] + marks[:-1], marks)]
+
+    # eager pass: EXACTLY K steps with HIP events around every launch of the dominant entry point, on the stream it is
+    # launched on.  This is the `roofline` measurement, and the headline timing too unless the graph replay below runs.
+    wall, host_enqueue, per_step = timed_region(step)
+    eager_ms = 1e3 * wall / args.steps
+    timer.uninstall()
+    graph_note = 'off'
+    if use_graph:
+        # the same K steps replayed as ONE captured hipGraph per step (no Python, no per-kernel launch cost)
+        from rvt_amd.graph import GraphedStep
+        try:
+            gstep = GraphedStep(step, warmup=1, device=device)
+            for _ in range(2):
+                gstep()
+            wall, host_enqueue, per_step = timed_region(gstep)
+            graph_note = 'on'
+        except Exception as e:                        # never lose the eager measurement to a capture problem
+            graph_note = f'failed: {type(e).__name__}: {str(e)[:120]}'
+            print(f'[bench] hipGraph capture failed, reporting the eager timing: {e}', file=sys.stderr, flush=True)
     if rank == 0:
         print(f'[bench] per-step ms: {[round(x, 1) for x in per_step]}  reserved={torch.cuda.memory_reserved() / 2**30:.1f} GiB '
               f'peak_alloc={torch.cuda.max_memory_allocated() / 2**30:.1f} GiB '
               f'alloc_retries={torch.cuda.memory_stats().get("num_alloc_retries", 0)} '
-              f'host_enqueue_ms_per_step={1e3 * host_enqueue / args.steps:.1f}', file=sys.stderr, flush=True)
+              f'host_enqueue_ms_per_step={1e3 * host_enqueue / args.steps:.1f} eager_ms_per_step={eager_ms:.1f} '
+              f'graph={graph_note}', file=sys.stderr, flush=True)
     timer.uninstall()
     if world > 1:
         tmax = torch.tensor([wall], device=device, dtype=torch.float64)
@@ -381,7 +407,8 @@ def main():
         balance = peak * 1e12 / (HBM_PEAK_GBS * 1e9)                     # FLOP per byte at which the roofs cross
         common = {'kernel': dominant, 'traffic': measured_traffic(dominant), 'launches': len(recs),
                   'avg_launch_ms': round(dom_ms / len(recs), 4),
-                  'share_of_step': round(dom_ms / (ms_per_step * args.steps), 3),
+                  'share_of_step': round(dom_ms / (eager_ms * args.steps), 3),
+                  'timing': 'HIP events on the launch stream, eager pass of the same K steps',
                   'arithmetic_intensity_flop_per_byte': round(dom_flops / dom_bytes, 1),
                   'algorithmic_bytes_per_launch': int(dom_bytes / len(recs)),
                   'mfma_tflops': round(achieved, 2), 'mfma_frac': round(achieved / peak, 4)}
@@ -400,6 +427,8 @@ def main():
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': wl['label'], 'global_batch': world * B, 'seq_len': T,
                        'parallelism': f'dp{world}', 'optimizer': 'none' if opt is None else 'AdamW(fused)',
+                       'hipgraph': graph_note, 'eager_ms_per_step': round(eager_ms, 3),
+                       'host_enqueue_ms_per_step': round(1e3 * host_enqueue / args.steps, 2),
                        'upstream_grads': 'random cotangents on stage 2-4 features of all T frames'},
             'mfma_roofline_frac_whole_step': round(path_tflops / peak, 4),
             'algorithmic_tflops_per_gpu': round(path_tflops, 2),
@@ -408,7 +437,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.workload)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or args.force_reducer:
         dist.destroy_process_group()
 
 

@@ -138,6 +138,17 @@ int rvt_token_mask_bwd(void* dx, const unsigned char* mask, float* dtoken, int d
  * st is [B][per_sample] of float32 (is_f32) or `dtype`. */
 int rvt_state_reset_masked(void* st, const unsigned char* mask, int dtype, int B, size_t per_sample, void* stream);
 
+/* Parameter-side tables (rvt_amd/csrc/pack.hpp; host mirror rvt_amd/weights.py).  One launch walks an array of
+ * descriptors in DEVICE memory:
+ *   rvt_pack_table: element-wise gathers fp32 parameter -> kernel-side layout (cast, transpose with LayerScale folded in,
+ *     tap-major conv weights, stride-parity conv-dgrad panels, gate-interleaved ConvLSTM rows) and the accumulating unpack
+ *     of the raw conv weight gradient — what the reference leaves to autograd / .to() / permute (maxvit.py:51-53,160-168,
+ *     rnn.py:52-61).  total_blocks = sum over descriptors of ceil(n / 1024).
+ *   rvt_layerscale_grad_table: dW += gamma*S, db += gamma*cs, dgamma += rowsum(W*S) + b*cs for the proj / fc2 linears
+ *     whose input-gradient weights carry LayerScale.  total_blocks = sum of C (one block per output channel). */
+int rvt_pack_table(const void* descs, int n_desc, int total_blocks, int dtype, void* stream);
+int rvt_layerscale_grad_table(const void* descs, int n_desc, int total_blocks, void* stream);
+
 /* Event stream -> stacked histogram, the uint8 event tensor the backbone consumes (data/utils/representations.py:76-117,
  * StackedHistogram.construct): x, y, pol (0/1), time are int64 [n_events], time sorted ascending.
  * out[(pol*bins + t_idx)][y][x] = min(count, count_cutoff) as uint8 [2*bins][H][W], with the reference's accumulator

@@ -49,6 +49,8 @@ _SIGS = {
     'rvt_token_mask_fwd': [_vp, _vp, _vp, _i, _i, _i, _vp],
     'rvt_token_mask_bwd': [_vp, _vp, _vp, _i, _i, _i, _vp],
     'rvt_state_reset_masked': [_vp, _vp, _i, _i, _sz, _vp],
+    'rvt_pack_table': [_vp, _i, _i, _i, _vp],
+    'rvt_layerscale_grad_table': [_vp, _i, _i, _vp],
 }
 EXPORTS = sorted(list(_SIGS) + ['rvt_last_error', 'rvt_is_emulator', 'rvt_wgrad_workspace_floats',
                                'rvt_mlp_fused_supported'])
@@ -117,14 +119,33 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return t.data_ptr()
 
 
+class _Stream(int):
+    """hipStream_t handle (as an int for ctypes) that remembers the device it belongs to."""
+    dev = -1
+
+
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def stream_of(t: torch.Tensor) -> Optional[int]:
-    if t.is_cuda:
-        return torch.cuda.current_stream(t.device).cuda_stream
-    return None
+    """Current HIP stream of the tensor's device.  Every entry point takes it as its LAST argument; call() uses the
+    device it carries to make that device current for the launch (the C ABI has no device parameter: a kernel launched
+    on stream S runs on S's device, but occupancy queries and the null stream follow the thread's current device)."""
+    if not t.is_cuda:
+        return None
+    idx = t.device.index
+    s = _Stream(_raw_stream(idx) if _raw_stream is not None else torch.cuda.current_stream(t.device).cuda_stream)
+    s.dev = idx
+    return s
 
 
 def call(name: str, *args) -> None:
     lib = get_lib()
-    rc = getattr(lib, name)(*args)
+    st = args[-1] if args else None
+    if isinstance(st, _Stream) and st.dev != torch.cuda.current_device():
+        with torch.cuda.device(st.dev):
+            rc = getattr(lib, name)(*args)
+    else:
+        rc = getattr(lib, name)(*args)
     if rc != 0:
         raise RuntimeError(f'{name} failed: {lib.rvt_last_error().decode()}')

@@ -22,7 +22,7 @@ import torch.nn as nn
 
 from . import ops
 from .stage import SideStream, StageGeom, stage_seq_backward, stage_seq_forward
-from .weights import StageWeights, round8
+from .weights import ModelWeights, param_signature, param_versions, round8
 
 Tensor = torch.Tensor
 LstmState = Optional[Tuple[Tensor, Tensor]]
@@ -209,10 +209,39 @@ class RNNDetector(nn.Module):
         for st in prev_states:
             flat_states += [None, None] if st is None else [st[0], st[1]]
         params = [p for _, p in self.named_parameters()]
-        outs = _BackboneSeqFn.apply(self, xs, token_masks, *flat_states, *params)
+        # grad mode is read HERE: inside autograd.Function.forward it is always off, and needs_input_grad stays True for
+        # parameters under torch.no_grad() — validation / streaming inference must not take the training path
+        outs = _BackboneSeqFn.apply(self, xs, token_masks, torch.is_grad_enabled(), *flat_states, *params)
         feats = {s + 1: outs[2 * s] for s in range(self.num_stages)}
-        states = [(outs[2 * s][-1], outs[2 * s + 1]) for s in range(self.num_stages)]
+        # the returned state tensors are the caller's to keep (RNNStates stores them per worker) and to mutate in place
+        # (masked reset): `c` is a buffer of its own; `h` is cloned off the (T+1)-slot feature buffer when the caller
+        # is not going to differentiate through it, so that a kept state does not pin the whole sequence
+        states = []
+        for s in range(self.num_stages):
+            h, c = outs[2 * s][-1], outs[2 * s + 1]
+            states.append((h if h.requires_grad else h.clone(memory_format=torch.preserve_format), c))
         return feats, states
+
+    def invalidate_weight_cache(self) -> None:
+        """Force a rebuild of the kernel-side weight copies on the next forward (call after writing parameters through
+        ``.data`` in inference code; training forwards re-pack every step anyway)."""
+        self._mw_cache = None
+
+    def model_weights(self, params, geoms, dt: torch.dtype, need_grad: bool) -> ModelWeights:
+        sig = (dt, param_signature(params))
+        mw = getattr(self, '_mw_cache', None)
+        fresh = mw is None or mw.sig != sig or (need_grad and not mw.need_grad)
+        if fresh:
+            mw = ModelWeights(self, dict(zip(self._param_names, params)), geoms, dt, need_grad)
+            mw.sig, mw.versions = sig, None
+            self._mw_cache = mw
+        ver = param_versions(params)
+        # training: re-pack every step (optimizers may write through .data, which does not bump _version: one launch);
+        # inference: only when a parameter changed (streaming inference calls forward once per time step)
+        if fresh or need_grad or mw.versions != ver:
+            mw.pack()
+            mw.versions = ver
+        return mw
 
 
 def _to_cl(t: Tensor, dtype: torch.dtype) -> Tensor:
@@ -224,7 +253,7 @@ def _to_cl(t: Tensor, dtype: torch.dtype) -> Tensor:
 
 class _BackboneSeqFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, mod: RNNDetector, xs: Tensor, token_masks: Optional[Tensor], *rest):
+    def forward(ctx, mod: RNNDetector, xs: Tensor, token_masks: Optional[Tensor], grad_enabled: bool, *rest):
         ns = mod.num_stages
         states_in, params = rest[:2 * ns], rest[2 * ns:]
         names = mod._param_names
@@ -234,24 +263,17 @@ class _BackboneSeqFn(torch.autograd.Function):
         Hm, Wm = mod.in_res_hw if mod.in_res_hw is not None else (h, w)
         assert h <= Hm and w <= Wm, f'input {h}x{w} larger than model resolution {Hm}x{Wm}'
         geoms = mod.stage_geoms(Hm, Wm)
-        need_grad = any(ctx.needs_input_grad[3:])
+        need_grad = bool(grad_enabled) and any(ctx.needs_input_grad[4:])
         src = xs.reshape(T * B, Cin, h, w)
         if src.dtype not in (torch.uint8, torch.float32):
             src = src.float()
         inp = ops.prepack_input(src, Hm, Wm, round8(Cin), dt)
-        # kernel-side weight views are rebuilt only when a parameter changed (optimizer step, load_state_dict, .to()):
-        # streaming inference calls forward once per time step with frozen weights
-        key = (dt, need_grad, tuple((id(t), t._version) for t in params))
-        cache = getattr(mod, '_sw_cache', None)
-        if cache is None or cache[0] != key:
-            cache = (key, [StageWeights(p, f'stages.{si}.', geoms[si].C, geoms[si].Cin, geoms[si].k, geoms[si].stride,
-                                        geoms[si].pad, geoms[si].num_blocks, dt, need_grad) for si in range(ns)])
-            mod._sw_cache = cache
-        sws, svs, outs = [], [], []
+        mw = mod.model_weights(params, geoms, dt, need_grad)
+        svs, outs = [], []
         for si in range(ns):
             g = geoms[si]
             pre = f'stages.{si}.'
-            sw = cache[1][si]
+            sw = mw.stages[si]
             h0, c0 = states_in[2 * si], states_in[2 * si + 1]
             if h0 is not None:
                 h0, c0 = _to_cl(h0, dt), _to_cl(c0, torch.float32)
@@ -259,25 +281,38 @@ class _BackboneSeqFn(torch.autograd.Function):
             if si == 0 and token_masks is not None:
                 assert mod.stages[0].mask_token is not None, 'No mask token present in this stage'
                 tm, mt = token_masks.to(xs.device), p[pre + 'mask_token'].detach()
-            Hall, Call, sv = stage_seq_forward(sw, g, inp, h0, c0, T, B, need_grad, tm, mt)
-            sws.append(sw)
+            Hall, c_last, sv = stage_seq_forward(sw, g, inp, h0, c0, T, B, need_grad, tm, mt)
             svs.append(sv)
             inp = Hall[1:].reshape(T * B, g.H, g.W, g.C)
-            outs += [Hall[1:].permute(0, 1, 4, 2, 3), Call[T].permute(0, 3, 1, 2)]
-        ctx.mod, ctx.geoms, ctx.sws, ctx.svs, ctx.p = mod, geoms, sws, svs, p
+            outs += [Hall[1:].permute(0, 1, 4, 2, 3), c_last.permute(0, 3, 1, 2)]
+        ctx.mod, ctx.geoms, ctx.mw, ctx.svs, ctx.p = mod, geoms, mw, svs, p
         ctx.T, ctx.B = T, B
         ctx.set_materialize_grads(False)
+        mod._last_saved = svs if need_grad else None      # (tests: a no_grad forward keeps nothing)
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *gout):
-        mod, geoms, T, B = ctx.mod, ctx.geoms, ctx.T, ctx.B
+        mod, geoms, T, B, mw = ctx.mod, ctx.geoms, ctx.T, ctx.B, ctx.mw
         ns = mod.num_stages
         dt = mod.compute_dtype
-        grads_by_name: Dict[str, Tensor] = {}
+        p = ctx.p
         state_grads: List[Optional[Tensor]] = [None] * (2 * ns)
         d_from_above = None          # conv dgrad of stage s+1, already including this stage's own feature cotangent
         hook = getattr(mod, '_stage_grad_hook', None)
+        # Gradient buckets: a parameter whose .grad already IS its bucket view (the caller did not zero it) keeps
+        # accumulating — every kernel adds into the bucket — otherwise the stage's bucket starts from zero.
+        accumulate = []
+        for si in range(ns):
+            sg = mw.grads[si]
+            mine = [p[n].grad is not None and p[n].grad.data_ptr() == sg.g(n).data_ptr() for n in sg.names]
+            acc = all(mine)
+            accumulate.append(acc)
+            if not acc:
+                for n, m_ in zip(sg.names, mine):     # mixed: detach the accumulated ones from the bucket first
+                    if m_:
+                        p[n].grad = p[n].grad.clone()
+            sg.zero(keep_params=acc)
         # weight-gradient GEMMs run on a side stream, joined at the end of every stage (measured: deferring the join to
         # the end of backward is slower — 162 vs 145 ms/step — the caching allocator cannot recycle the operands the side
         # stream still holds and the extra resident work competes with the next stage's critical path)
@@ -295,27 +330,41 @@ class _BackboneSeqFn(torch.autograd.Function):
             if si > 0 and gout[2 * (si - 1)] is not None:
                 gp = geoms[si - 1]
                 prev_cot = _to_cl(gout[2 * (si - 1)], dt).view(T * B, gp.H, gp.W, gp.C)
-            d_in, dh0, dc0, grads = stage_seq_backward(ctx.sws[si], g, ctx.svs[si], dH, dc_last, T, B, si > 0,
-                                                       prev_cot, ctx.p, f'stages.{si}.', side=side,
-                                                       join=True)
+            d_in, dh0, dc0 = stage_seq_backward(mw.stages[si], g, ctx.svs[si], dH, dc_last, T, B, si > 0, prev_cot,
+                                                mw.grads[si], f'stages.{si}.', side=side,
+                                                finalize=lambda si=si: mw.finalize_stage_grads(si))
             d_from_above = d_in
             if hook is not None:          # e.g. rvt_amd.dist.StageGradReducer: start this stage's all-reduce now
-                hook(si, grads)
-            grads_by_name.update(grads)
-            if ctx.needs_input_grad[3 + 2 * si]:
+                hook(si, mw.grads[si].param_region)
+            if ctx.needs_input_grad[4 + 2 * si]:
                 state_grads[2 * si] = dh0.permute(0, 3, 1, 2)
                 state_grads[2 * si + 1] = dc0.permute(0, 3, 1, 2)
             ctx.svs[si] = None
         finish = getattr(mod, '_stage_grad_finish', None)
         if finish is not None:            # data parallel: order everything downstream after the per-stage all-reduces
             finish()
+        # Hand-off.  Default: the parameter's .grad BECOMES the bucket view (no copy, stable addresses — what a captured
+        # hipGraph and the fused optimizer want); a foreign .grad tensor gets the bucket added into it.  With
+        # mod.grads_through_autograd = True the views are returned to autograd instead (AccumulateGrad may clone).
+        through = getattr(mod, 'grads_through_autograd', False)
         pgrads = []
         for i, n in enumerate(mod._param_names):
-            gr = grads_by_name.get(n)
-            if gr is not None:
-                gr = gr.reshape(ctx.p[n].shape).to(ctx.p[n].dtype)
-            pgrads.append(gr if ctx.needs_input_grad[3 + 2 * ns + i] else None)
-        return (None, None, None, *state_grads, *pgrads)
+            if not ctx.needs_input_grad[4 + 2 * ns + i]:
+                pgrads.append(None)
+                continue
+            si = int(n.split('.')[1])
+            view = mw.grads[si].g(n)
+            if view.dtype != p[n].dtype:
+                view = view.to(p[n].dtype)
+            if through:
+                pgrads.append(view)
+                continue
+            pgrads.append(None)
+            if p[n].grad is None:
+                p[n].grad = view
+            elif p[n].grad.data_ptr() != view.data_ptr():
+                p[n].grad.add_(view)
+        return (None, None, None, None, *state_grads, *pgrads)
 
 
 def build_recurrent_backbone(backbone_cfg, compute_dtype: torch.dtype = torch.float32):

@@ -11,6 +11,7 @@
 #include "attn.hpp"
 #include "mlp.hpp"
 #include "events.hpp"
+#include "pack.hpp"
 #include "../../include/rvt_hip.h"
 
 namespace rvt {
@@ -368,14 +369,27 @@ static int mlp_tm(int dtype, int C) {
 }
 }  // extern "C"
 // persistent grid = exactly the workgroups the chip holds at once for THIS kernel instantiation (registers + LDS)
+// resident workgroups per CU of a kernel, queried once per kernel (the occupancy API is not free and must not run per
+// launch; keyed by the kernel's address because several instantiations share one function type)
+template <class K> static int resident_per_cu(K kernel, int threads, int fallback) {
+#ifdef RVT_EMU
+    return fallback;
+#else
+    struct Entry { const void* k; int v; };
+    static Entry cache[64];
+    static int n = 0;
+    const void* key = reinterpret_cast<const void*>(kernel);
+    for (int i = 0; i < n; i++) if (cache[i].k == key) return cache[i].v;
+    int nb = 0, v = fallback;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, threads, 0) == hipSuccess && nb > 0) v = nb;
+    if (n < 64) cache[n++] = Entry{key, v};
+    return v;
+#endif
+}
 template <class K> static int mlp_grid(K kernel, int M, int tm) {
     static const int resident_override = getenv("RVT_GEMM_RESIDENT") ? atoi(getenv("RVT_GEMM_RESIDENT")) : 0;
     const int n_tiles = (M + tm - 1) / tm;
-    int per_cu = 2;
-#ifndef RVT_EMU
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 256, 0) == hipSuccess && nb > 0) per_cu = nb;
-#endif
+    const int per_cu = resident_per_cu(kernel, 256, 2);
     return imax(1, imin(n_tiles, resident_override > 0 ? resident_override : 256 * per_cu));
 }
 extern "C" {
@@ -599,6 +613,22 @@ int rvt_stacked_histogram(const long long* x, const long long* y, const long lon
     hipLaunchKernelGGL(hist_finalize_kernel, dim3(grid_for(cells, 4096)), dim3(256), 0, st, (const unsigned*)scratch, out,
                        cells, count_cutoff, fastmode);
     return check_launch("stacked_histogram");
+}
+
+// ------------------------------------------------------------------------------ parameter-side tables
+int rvt_pack_table(const void* descs, int n_desc, int total_blocks, int dtype, void* stream) {
+    RVT_CHECK(n_desc >= 1 && total_blocks >= 1 && descs != nullptr, "pack_table: empty table");
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((pack_table_kernel<T>), dim3(total_blocks), dim3(256), 0, st,
+                                             (const PackDesc*)descs, n_desc));
+    return check_launch("pack_table");
+}
+
+int rvt_layerscale_grad_table(const void* descs, int n_desc, int total_blocks, void* stream) {
+    RVT_CHECK(n_desc >= 1 && total_blocks >= 1 && descs != nullptr, "layerscale_grad_table: empty table");
+    hipLaunchKernelGGL(layerscale_grad_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const LayerScaleDesc*)descs, n_desc);
+    return check_launch("layerscale_grad_table");
 }
 
 int rvt_state_reset_masked(void* st_, const unsigned char* mask, int dtype, int B, size_t per_sample, void* stream) {

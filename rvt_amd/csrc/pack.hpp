@@ -1,0 +1,146 @@
+// Parameter-side kernels: everything that turns the fp32 master parameters of the nn.Module (reference names and
+// shapes) into the layouts the compute kernels read, and the raw weight-gradient products back into
+// gradients of those parameters.  Both directions are TABLE driven: the host builds an array of descriptors once (the
+// pointers are persistent: parameter storage, packed-weight buffers, gradient buckets) and one launch walks all of
+// them, so an optimisation step costs one "pack" launch and one "finalize" launch per stage instead of a few hundred
+// framework micro-kernels.
+#pragma once
+#include "common.hpp"
+
+namespace rvt {
+
+// element-wise gather from one fp32 source into one destination
+enum PackKind {
+    PACK_COPY = 0,           // dst[i] = src[i]
+    PACK_TRANSPOSE = 1,      // src [R][K] -> dst [K][R], optionally * scale[r]      (d0 = R, d1 = K)
+    PACK_CONV_FWD = 2,       // src [Cout][Cin][k][k] -> dst [Cout][k*k*cp] tap-major, cin fastest, zero padded (d0..d3 = Cout,Cin,k,cp)
+    PACK_CONV_DGRAD = 3,     // src [Cout][Cin][k][k] -> dst [Cin][nky*nkx*Cout] of one stride-parity class (d0..d4 = Cout,Cin,k,nky,nkx)
+    PACK_LSTM_ROWS = 4,      // src [4C][K] -> dst rows interleaved n' = (c/8)*32 + gate*8 + c%8            (d0 = C, d1 = K)
+    PACK_CONV_WGRAD_ACC = 5  // src [Cout][k*k*cp] (raw fp32 product) -> dst [Cout][Cin][k][k] += ...      (d0..d3 = Cout,Cin,k,cp)
+};
+
+struct PackDesc {             // 96 bytes; mirrored by rvt_amd/weights.py (numpy structured dtype)
+    const float* src;
+    void* dst;
+    const float* scale;
+    long long n;              // destination elements
+    int kind;
+    int out_f32;              // destination is fp32 whatever the launch dtype
+    int d[5];
+    int ky[4], kx[4];
+    unsigned block0;          // first block of this descriptor within the launch
+};
+static_assert(sizeof(PackDesc) == 96, "PackDesc layout is part of the C ABI");
+
+template <class T>
+__global__ void __launch_bounds__(256)
+pack_table_kernel(const PackDesc* __restrict__ descs, int nd) {
+    // which descriptor does this block serve?  (block0 is ascending; nd is a few hundred at most)
+    int lo = 0, hi = nd - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].block0 <= blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const PackDesc d = descs[lo];
+    const long long i0 = ((long long)(blockIdx.x - d.block0) * 256 + threadIdx.x) * 4;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const long long i = i0 + u;
+        if (i >= d.n) return;
+        float v = 0.f;
+        long long o = i;
+        switch (d.kind) {
+        case PACK_COPY: v = d.src[i]; break;
+        case PACK_TRANSPOSE: {
+            const int R = d.d[0], K = d.d[1];
+            const int k = (int)(i / R), r = (int)(i % R);
+            v = d.src[(size_t)r * K + k];
+            if (d.scale) v *= d.scale[r];
+            break;
+        }
+        case PACK_CONV_FWD: {
+            const int Cin = d.d[1], k = d.d[2], cp = d.d[3];
+            const int kk = k * k * cp;
+            const int co = (int)(i / kk), rem = (int)(i % kk);
+            const int tap = rem / cp, ci = rem % cp;
+            const int ky = tap / k, kx = tap % k;
+            v = ci < Cin ? d.src[(((size_t)co * Cin + ci) * k + ky) * k + kx] : 0.f;
+            break;
+        }
+        case PACK_CONV_DGRAD: {
+            const int Cout = d.d[0], Cin = d.d[1], k = d.d[2], nkx = d.d[4];
+            const int per = d.d[3] * nkx * Cout;
+            const int ci = (int)(i / per), rem = (int)(i % per);
+            const int ab = rem / Cout, co = rem % Cout;
+            const int a = ab / nkx, b = ab % nkx;
+            v = d.src[(((size_t)co * Cin + ci) * k + d.ky[a & 3]) * k + d.kx[b & 3]];
+            break;
+        }
+        case PACK_LSTM_ROWS: {
+            const int C = d.d[0], K = d.d[1];
+            const int np = (int)(i / K), kc = (int)(i % K);
+            const int c = (np / 32) * 8 + np % 8, gate = (np % 32) / 8;
+            v = d.src[(size_t)(gate * C + c) * K + kc];
+            break;
+        }
+        case PACK_CONV_WGRAD_ACC: {
+            const int Cin = d.d[1], k = d.d[2], cp = d.d[3];
+            const int per = Cin * k * k;
+            const int co = (int)(i / per), rem = (int)(i % per);
+            const int ci = rem / (k * k), tap = rem % (k * k);
+            v = d.src[(size_t)co * (k * k * cp) + (size_t)tap * cp + ci];
+            float* o32 = reinterpret_cast<float*>(d.dst);
+            o32[o] += v;
+            continue;
+        }
+        default: break;
+        }
+        if (d.out_f32) reinterpret_cast<float*>(d.dst)[o] = v;
+        else reinterpret_cast<T*>(d.dst)[o] = (T)v;
+    }
+}
+
+// LayerScale (reference maxvit.py:51-53) folded out of the weight gradients: the branch is y = gamma * (a W^T + b) and the
+// weight-gradient GEMMs deliver the raw products S[c][k] = sum_tok dy[tok][c] a[tok][k] and cs[c] = sum_tok dy[tok][c] of
+// the *outer* cotangent dy (the dgrad weights carry gamma instead).  Then
+//   dW[c][k] += gamma[c] S[c][k],   db[c] += gamma[c] cs[c],   dgamma[c] += sum_k W[c][k] S[c][k] + b[c] cs[c].
+struct LayerScaleDesc {       // 80 bytes
+    const float* S; const float* cs; const float* W; const float* b; const float* gamma;
+    float* dW; float* db; float* dgamma;
+    int C, K;
+    unsigned block0; int pad;
+};
+static_assert(sizeof(LayerScaleDesc) == 80, "LayerScaleDesc layout is part of the C ABI");
+
+__global__ void __launch_bounds__(256)
+layerscale_grad_kernel(const LayerScaleDesc* __restrict__ descs, int nd) {
+    int lo = 0, hi = nd - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].block0 <= blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const LayerScaleDesc d = descs[lo];
+    const int c = (int)(blockIdx.x - d.block0);
+    if (c >= d.C) return;
+    const float g = d.gamma[c];
+    float acc = 0.f;
+    for (int k = threadIdx.x; k < d.K; k += 256) {
+        const float s = d.S[(size_t)c * d.K + k];
+        d.dW[(size_t)c * d.K + k] += g * s;
+        acc += d.W[(size_t)c * d.K + k] * s;
+    }
+    __shared__ float red[256];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int m = 128; m > 0; m >>= 1) {
+        if ((int)threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float cs = d.cs[c];
+        d.dgamma[c] += red[0] + d.b[c] * cs;
+        d.db[c] += g * cs;
+    }
+}
+
+}  // namespace rvt

@@ -4,14 +4,15 @@
 The reference leaves this to Lightning's DDPStrategy (train.py:60-67): one reducer over the whole
 detector whose buckets only become ready when autograd reaches t=0 of the time loop, i.e. at the very
 end of backward.  The stage-major backward (rvt_amd/stage.py) finishes stage 4 — 75 % of the backbone's
-parameter bytes — first, so here each stage's gradients are flattened into ONE bucket and all-reduced
-asynchronously the moment that stage's backward returns, overlapping stages 3..1.  xGMI is
-point-to-point (7 links x ~153 GB/s per GPU): four large buckets (38 / 9.6 / 2.4 / 0.8 MB fp32 for
-RVT-Base) keep every collective bandwidth- rather than latency-bound.
+parameter bytes — first, and every stage's parameter gradients already live in ONE persistent flat fp32
+bucket (rvt_amd/weights.py: the weight-gradient kernels accumulate straight into views of it), so the
+moment a stage's backward returns its bucket is all-reduced in place, asynchronously, overlapping stages 3..1.
+No flattening copy, no per-step allocation.  xGMI is point-to-point (7 links x ~153 GB/s per GPU): four large
+buckets (38 / 9.6 / 2.4 / 0.8 MB fp32 for RVT-Base) keep every collective bandwidth- rather than latency-bound.
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional
+from typing import List
 
 import torch
 import torch.distributed as dist
@@ -19,20 +20,20 @@ import torch.distributed as dist
 
 class StageGradReducer:
     """Attach with ``reducer.attach(model)``.  The backbone's backward waits for the collectives itself before it
-    returns the gradients; ``reducer.finish()`` after ``loss.backward()`` is harmless (idempotent) and kept for callers
-    that drive the hook by hand."""
+    hands the gradients (views of the buckets) to the parameters; ``reducer.finish()`` after ``loss.backward()`` is
+    harmless (idempotent) and kept for callers that drive the hook by hand."""
 
-    def __init__(self, process_group=None, average: bool = True):
+    def __init__(self, process_group=None, average: bool = True, force: bool = False):
         self.pg = process_group
         self.average = average
+        self.force = force          # run the collective even at world_size 1 (single-GPU smoke of the RCCL path)
         self._pending: List = []
-        self.buckets: Dict[int, torch.Tensor] = {}
 
     def attach(self, model) -> 'StageGradReducer':
         model._stage_grad_hook = self.on_stage_done
-        # the backbone calls this at the very end of its backward, before the gradients (views of the buckets) are
-        # handed to autograd: whatever reads them next (AccumulateGrad may clone, the optimizer) is then stream-ordered
-        # after the collectives, while the collectives themselves still overlap the backward of the later stages
+        # the backbone calls this at the very end of its backward, before the bucket views become the parameters'
+        # .grad: whatever reads them next (the optimizer) is then stream-ordered after the collectives, while the
+        # collectives themselves still overlap the backward of the later stages
         model._stage_grad_finish = self.finish
         return self
 
@@ -40,26 +41,23 @@ class StageGradReducer:
     def world_size(self) -> int:
         return dist.get_world_size(self.pg) if dist.is_initialized() else 1
 
-    def on_stage_done(self, stage_idx: int, grads: Dict[str, torch.Tensor]) -> None:
-        """Flatten this stage's parameter gradients into one bucket, point the dict entries at views of
-        it and start the all-reduce (async: the collective waits for the producing stream, the consumer
-        waits in finish())."""
-        if self.world_size == 1 or not grads:
+    def on_stage_done(self, stage_idx: int, bucket: torch.Tensor) -> None:
+        """All-reduce (mean) the flat fp32 gradient bucket of one stage in place.  Async: the collective waits for the
+        producing stream, the consumer waits in finish()."""
+        ws = self.world_size
+        if (ws == 1 and not self.force) or bucket.numel() == 0:
             return
-        names = list(grads)
-        flat = torch.cat([grads[n].reshape(-1).to(torch.float32) for n in names])
-        if self.average:
-            flat.div_(self.world_size)
-        off = 0
-        for n in names:
-            k = grads[n].numel()
-            grads[n] = flat[off:off + k].view(grads[n].shape)
-            off += k
-        self.buckets[stage_idx] = flat
-        self._pending.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        if not dist.is_initialized():
+            return
+        op = dist.ReduceOp.SUM
+        if self.average and ws > 1:
+            if dist.get_backend(self.pg) == 'nccl':
+                op = dist.ReduceOp.AVG              # RCCL divides in the collective: no extra pass over the bucket
+            else:
+                bucket.div_(ws)
+        self._pending.append(dist.all_reduce(bucket, op=op, group=self.pg, async_op=True))
 
     def finish(self) -> None:
         for w in self._pending:
             w.wait()
         self._pending.clear()
-        self.buckets.clear()

@@ -22,10 +22,11 @@ _WS = {}
 
 
 def _wgrad_ws(like: Tensor, out_rows: int, out_cols: int, tokens: int, want_colsum: bool) -> Tensor:
-    """Grow-only per-device scratch for the two-stage split-K reduction (kernels on one stream serialise, so a
-    single buffer is safe to share between consecutive weight-gradient launches)."""
+    """Grow-only scratch for the two-stage split-K reduction, one per (device, stream): kernels on one stream serialise,
+    so consecutive weight-gradient launches of that stream can share it; launches on different streams never do."""
     n = L.get_lib().rvt_wgrad_workspace_floats(L.dtype_code(like.dtype), out_rows, out_cols, tokens, int(want_colsum))
-    key = (like.device.type, like.device.index)
+    st = L.stream_of(like)
+    key = (like.device.type, like.device.index, 0 if st is None else int(st))
     ws = _WS.get(key)
     if ws is None or ws.numel() < n:
         ws = torch.empty(max(n, 1 << 20), dtype=torch.float32, device=like.device)

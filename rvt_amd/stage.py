@@ -21,7 +21,7 @@ import torch
 import os
 
 from . import ops
-from .weights import StageWeights, unpack_conv_wgrad
+from .weights import StageGrads, StageWeights
 
 
 def use_fused_mlp(dtype, C: int, what: str) -> bool:
@@ -112,7 +112,7 @@ class StageSaved:
 def stage_seq_forward(sw: StageWeights, g: StageGeom, inp: Tensor, h0: Optional[Tensor], c0: Optional[Tensor],
                       T: int, B: int, save: bool, token_mask: Optional[Tensor] = None,
                       mask_token: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Optional[StageSaved]]:
-    """inp: (T*B, H_in, W_in, cin_pad).  Returns Hall (T+1,B,H,W,C), Call (T+1,B,H,W,C) fp32, saved."""
+    """inp: (T*B, H_in, W_in, cin_pad).  Returns Hall (T+1,B,H,W,C), the final cell state (B,H,W,C) fp32, saved."""
     F_ = T * B
     H, W, C = g.H, g.W, g.C
     dt, dev = inp.dtype, inp.device
@@ -151,7 +151,9 @@ def stage_seq_forward(sw: StageWeights, g: StageGeom, inp: Tensor, h0: Optional[
             x = xout
 
     Hall = torch.empty((T + 1, B, H, W, C), dtype=dt, device=dev)
-    Call = torch.empty((T + 1, B, H, W, C), dtype=torch.float32, device=dev)
+    # cell states: all T+1 slots are kept for BPTT; a no-grad forward ping-pongs between two
+    nc = T + 1 if save else 2
+    Call = torch.empty((nc, B, H, W, C), dtype=torch.float32, device=dev)
     if h0 is None:
         Hall[0].zero_()                                                           # rnn.py:43-47
         Call[0].zero_()
@@ -166,48 +168,52 @@ def stage_seq_forward(sw: StageWeights, g: StageGeom, inp: Tensor, h0: Optional[
     if dws is not None:
         hconv = torch.empty((T if save else 1, B, H, W, C), dtype=dt, device=dev)
         if not dws['only_hidden']:
-            x_lstm = ops.dwconv(x, dws['w'][:C].contiguous(), dws['b'][:C].contiguous(), dws['k'])
+            x_lstm = ops.dwconv(x, dws['w'][:C], dws['b'][:C], dws['k'])
     xt = x_lstm.view(T, B, H, W, C)
     for t in range(T):                                                            # rnn.py:52-67, one launch per step
         h_in = Hall[t]
         if dws is not None:
-            wh = dws['w'] if dws['only_hidden'] else dws['w'][C:].contiguous()
-            bh = dws['b'] if dws['only_hidden'] else dws['b'][C:].contiguous()
+            wh = dws['w'] if dws['only_hidden'] else dws['w'][C:]
+            bh = dws['b'] if dws['only_hidden'] else dws['b'][C:]
             h_in = ops.dwconv(Hall[t], wh, bh, dws['k'], out=hconv[t if save else 0])
-        ops.lstm_fwd(xt[t], h_in, Call[t], sw.lstm_w, sw.lstm_b, Hall[t + 1], Call[t + 1],
+        ops.lstm_fwd(xt[t], h_in, Call[t % nc], sw.lstm_w, sw.lstm_b, Hall[t + 1], Call[(t + 1) % nc],
                      gates[t] if save else None)
+    # the final cell state is handed to the caller (RNNStates keeps it across steps): a buffer of its own when the
+    # T+1-slot array is what BPTT holds on to
+    c_last = Call[T % nc].clone() if save else Call[T % nc]
     if save:
         sv.x_last, sv.Hall, sv.Call, sv.gates = x, Hall, Call, gates
         sv.xin_lstm, sv.hconv = x_lstm, hconv
-    return Hall, Call, sv
+    return Hall, c_last, sv
 
 
 def stage_seq_backward(sw: StageWeights, g: StageGeom, sv: StageSaved, dH: Optional[Tensor], dc_last: Optional[Tensor],
                        T: int, B: int, need_input_grad: bool, prev_cot: Optional[Tensor],
-                       p: Dict[str, Tensor], pre: str, side: Optional[SideStream] = None,
-                       join: bool = True) -> Tuple[Optional[Tensor], Tensor, Tensor, Dict[str, Tensor]]:
+                       sg: StageGrads, pre: str, side: Optional[SideStream] = None,
+                       finalize=None) -> Tuple[Optional[Tensor], Tensor, Tensor]:
     """dH: (T,B,H,W,C) cotangent of Hall[1:] (None = zeros); dc_last: (B,H,W,C) fp32 cotangent of Call[T].
     prev_cot: cotangent already attached to this stage's INPUT frames (T*B,H_in,W_in,Cin) (added to the conv dgrad).
-    Returns (d_input or None, dh0, dc0, {param name: fp32 grad})."""
+    Parameter gradients are ACCUMULATED into the views of the stage's fp32 bucket `sg` (rvt_amd/weights.py); `finalize`
+    (LayerScale fold + conv unpack, two table launches) runs behind the weight-gradient GEMMs on their stream.
+    Returns (d_input or None, dh0, dc0)."""
     F_ = T * B
     H, W, C = g.H, g.W, g.C
     dt, dev = sv.y0.dtype, sv.y0.device
     f32 = torch.float32
-    grads: Dict[str, Tensor] = {}
-    zeros = lambda *shape: torch.zeros(shape, dtype=f32, device=dev)
+    G = sg.g
 
     # ---- ConvLSTM BPTT ------------------------------------------------------------------------------
     if dH is None:
         dH = torch.zeros((T, B, H, W, C), dtype=dt, device=dev)
     dz = torch.empty((T, B, H, W, 4 * C), dtype=dt, device=dev)
     dx = torch.empty((T, B, H, W, C), dtype=dt, device=dev)
-    dc_rec = zeros(B, H, W, C) if dc_last is None else dc_last.to(f32).contiguous().clone()
+    dc_rec = torch.zeros((B, H, W, C), dtype=f32, device=dev) if dc_last is None else dc_last.to(f32).contiguous().clone()
     dh_rec = None
     dh_buf = [torch.empty((B, H, W, C), dtype=dt, device=dev) for _ in range(2)]
     dws = sw.dws
     dhc = torch.empty((T, B, H, W, C), dtype=dt, device=dev) if dws is not None else None   # d(dwconv(h_{t-1}))
     if dws is not None:
-        wh = dws['w'] if dws['only_hidden'] else dws['w'][C:].contiguous()
+        wh = dws['w'] if dws['only_hidden'] else dws['w'][C:]
     for t in range(T - 1, -1, -1):
         ops.lstm_gates_bwd(dH[t], dh_rec, dc_rec, sv.gates[t], sv.Call[t + 1], sv.Call[t], dz[t])
         nxt = dh_buf[t & 1]
@@ -222,29 +228,22 @@ def stage_seq_backward(sw: StageWeights, g: StageGeom, sv: StageSaved, dH: Optio
     h_seg = sv.Hall[:T].reshape(F_, H, W, C) if dws is None else sv.hconv.view(F_, H, W, C)
 
     def lstm_wgrad_fn():
-        dwl = zeros(4 * C, 2 * C)
-        dbl = zeros(4 * C)
-        ops.lstm_wgrad(dz.view(F_, H, W, 4 * C), sv.xin_lstm, h_seg, dwl, dbl)
-        grads[pre + 'lstm.conv1x1.weight'] = dwl.reshape(4 * C, 2 * C, 1, 1)
-        grads[pre + 'lstm.conv1x1.bias'] = dbl
+        ops.lstm_wgrad(dz.view(F_, H, W, 4 * C), sv.xin_lstm, h_seg, G(pre + 'lstm.conv1x1.weight').view(4 * C, 2 * C),
+                       G(pre + 'lstm.conv1x1.bias'))
     side.run(lstm_wgrad_fn, dz, sv.xin_lstm, h_seg)
     dh0, dc0 = dh_rec, dc_rec
     dx = dx.view(F_, H, W, C)
     if dws is not None:
         kk = dws['k']
         cg = dws['w'].shape[0]
-        dwd, dbd = zeros(cg, kk * kk), zeros(cg)
+        dwd, dbd = G(pre + 'lstm.conv3x3_dws.weight').view(cg, kk * kk), G(pre + 'lstm.conv3x3_dws.bias')
         hprev = sv.Hall[:T].reshape(F_, H, W, C)
         if dws['only_hidden']:
             ops.dwconv_wgrad(hprev, dhc.view(F_, H, W, C), dwd, dbd, kk)
         else:
-            dwx, dbx, dwh, dbh = zeros(C, kk * kk), zeros(C), zeros(C, kk * kk), zeros(C)
-            ops.dwconv_wgrad(sv.x_last, dx, dwx, dbx, kk)                    # dx here = d(dwconv_x(x))
-            ops.dwconv_wgrad(hprev, dhc.view(F_, H, W, C), dwh, dbh, kk)
-            dwd, dbd = torch.cat([dwx, dwh]), torch.cat([dbx, dbh])
-            dx = ops.dwconv(dx, dws['w'][:C].contiguous(), None, kk, transpose=True)
-        grads[pre + 'lstm.conv3x3_dws.weight'] = dwd.reshape(cg, 1, kk, kk)
-        grads[pre + 'lstm.conv3x3_dws.bias'] = dbd
+            ops.dwconv_wgrad(sv.x_last, dx, dwd[:C], dbd[:C], kk)                 # dx here = d(dwconv_x(x))
+            ops.dwconv_wgrad(hprev, dhc.view(F_, H, W, C), dwd[C:], dbd[C:], kk)
+            dx = ops.dwconv(dx, dws['w'][:C], None, kk, transpose=True)
     del dz
 
     # ---- attention blocks, reversed ---------------------------------------------------------------------
@@ -256,16 +255,12 @@ def stage_seq_backward(sw: StageWeights, g: StageGeom, sv: StageSaved, dH: Optio
             bi_flat -= 1
             s = sv.blocks[bi_flat]
             bp = f'{pre}att_blocks.{pi}.{"att_window" if window else "att_grid"}.'
-            # MLP branch: xout = xmid + g2 * (gelu(hd) W2^T + b2)
-            def fc2_wgrad_fn(dx=dx, s=s, bw=bw, bp=bp):
-                S2 = zeros(C, 4 * C)
-                cs = zeros(C)
-                ops.linear_wgrad(dx, s['hg'], S2, colsum_out=cs)
-                grads[bp + 'mlp.net.2.weight'] = bw['g2'][:, None] * S2
-                grads[bp + 'mlp.net.2.bias'] = bw['g2'] * cs
-                grads[bp + 'ls2.gamma'] = (bw['fc2_w32'] * S2).sum(1) + p[bp + 'mlp.net.2.bias'].detach().to(f32) * cs
+            # MLP branch: xout = xmid + g2 * (gelu(hd) W2^T + b2).  The weight-gradient GEMM delivers the raw products
+            # S2 = dxout^T g and cs2 = colsum(dxout); LayerScale is folded in by the finalize table launch.
+            def fc2_wgrad_fn(dx=dx, s=s, bp=bp):
+                ops.linear_wgrad(dx, s['hg'], G(bp + 'S2'), colsum_out=G(bp + 'cs2'))
             side.run(fc2_wgrad_fn, dx, s['hg'])
-            dn2w, dn2b = zeros(C), zeros(C)
+            dn2w, dn2b = G(bp + 'norm2.weight'), G(bp + 'norm2.bias')
             fused = use_fused_mlp(dt, C, 'bwd')
             if fused:       # fc2 dgrad * gp, fc1 dgrad and LayerNorm-2 backward (+ residual) in one kernel
                 dhd, dxmid = ops.mlp_bwd_dgrad(dx, s['hgp'], s['xmid'], bw['n2_w'], bw['fc2_wt'], bw['fc1_wt'], dn2w, dn2b,
@@ -274,67 +269,43 @@ def stage_seq_backward(sw: StageWeights, g: StageGeom, sv: StageSaved, dH: Optio
                 dhd = ops.linear_dgrad(dx, bw['fc2_wt'], mul=s['hgp'])
             def fc1_wgrad_fn(dhd=dhd, s=s, bw=bw, bp=bp):
                 v2 = s['v2'] if s['v2'] is not None else ops.layernorm_fwd(s['xmid'], bw['n2_w'], bw['n2_b'], g.eps)
-                dW1 = zeros(4 * C, C)
-                db1 = zeros(4 * C)
-                ops.linear_wgrad(dhd, v2, dW1, colsum_out=db1)
-                grads[bp + 'mlp.net.0.0.weight'] = dW1
-                grads[bp + 'mlp.net.0.0.bias'] = db1
+                ops.linear_wgrad(dhd, v2, G(bp + 'mlp.net.0.0.weight'), colsum_out=G(bp + 'mlp.net.0.0.bias'))
             side.run(fc1_wgrad_fn, dhd, s['xmid'])
             if not fused:
                 dv2 = ops.linear_dgrad(dhd, bw['fc1_wt'])
                 dxmid = ops.layernorm_bwd(s['xmid'], bw['n2_w'], dv2, dx, dn2w, dn2b, g.eps)
                 del dv2
             del dhd
-            grads[bp + 'norm2.weight'] = dn2w
-            grads[bp + 'norm2.bias'] = dn2b
             # attention branch: xmid = xin + g1 * (a Wp^T + bp)
-            def proj_wgrad_fn(dxmid=dxmid, s=s, bw=bw, bp=bp):
-                S1 = zeros(C, C)
-                cs1 = zeros(C)
-                ops.linear_wgrad(dxmid, s['a'], S1, colsum_out=cs1)
-                grads[bp + 'self_attn.proj.weight'] = bw['g1'][:, None] * S1
-                grads[bp + 'self_attn.proj.bias'] = bw['g1'] * cs1
-                grads[bp + 'ls1.gamma'] = (bw['proj_w32'] * S1).sum(1) + p[bp + 'self_attn.proj.bias'].detach().to(f32) * cs1
+            def proj_wgrad_fn(dxmid=dxmid, s=s, bp=bp):
+                ops.linear_wgrad(dxmid, s['a'], G(bp + 'S1'), colsum_out=G(bp + 'cs1'))
             side.run(proj_wgrad_fn, dxmid, s['a'])
             da = ops.linear_dgrad(dxmid, bw['proj_wt'])
             dqkv = ops.attn_bwd(s['qkv'], da, F_, H, W, C, g.dim_head, g.ph, g.pw, window)
             del da
-            def qkv_wgrad_fn(dqkv=dqkv, s=s, bw=bw, bp=bp):
-                u = s['u']
-                dWq = zeros(3 * C, C)
-                dbq = zeros(3 * C)
-                ops.linear_wgrad(dqkv, u, dWq, colsum_out=dbq)
-                grads[bp + 'self_attn.qkv.weight'] = dWq
-                grads[bp + 'self_attn.qkv.bias'] = dbq
+            def qkv_wgrad_fn(dqkv=dqkv, s=s, bp=bp):
+                ops.linear_wgrad(dqkv, s['u'], G(bp + 'self_attn.qkv.weight'), colsum_out=G(bp + 'self_attn.qkv.bias'))
             side.run(qkv_wgrad_fn, dqkv, s['xin'])
             if bw['n1_w'] is None:
                 dx = ops.linear_dgrad(dqkv, bw['qkv_wt'], add=dxmid)
             else:
                 du = ops.linear_dgrad(dqkv, bw['qkv_wt'])
-                dn1w, dn1b = zeros(C), zeros(C)
-                dx = ops.layernorm_bwd(s['xin'], bw['n1_w'], du, dxmid, dn1w, dn1b, g.eps)
-                grads[bp + 'norm1.weight'] = dn1w
-                grads[bp + 'norm1.bias'] = dn1b
+                dx = ops.layernorm_bwd(s['xin'], bw['n1_w'], du, dxmid, G(bp + 'norm1.weight'), G(bp + 'norm1.bias'), g.eps)
                 del du
             del dqkv, dxmid
 
     # ---- token mask, down-sampling LayerNorm + conv ---------------------------------------------------------
     if sv.mask is not None:
-        dtok = zeros(C)
-        ops.token_mask_bwd(dx, sv.mask, dtok)                                     # also zeroes dx on masked tokens
-        grads[pre + 'mask_token'] = dtok.reshape(1, 1, 1, C)
-    dlw, dlb = zeros(C), zeros(C)
-    dy0 = ops.layernorm_bwd(sv.y0, sw.ln_w, dx, None, dlw, dlb, g.eps)
-    grads[pre + 'downsample_cf2cl.norm.weight'] = dlw
-    grads[pre + 'downsample_cf2cl.norm.bias'] = dlb
+        ops.token_mask_bwd(dx, sv.mask, G(pre + 'mask_token').view(C))            # also zeroes dx on masked tokens
+    dy0 = ops.layernorm_bwd(sv.y0, sw.ln_w, dx, None, G(pre + 'downsample_cf2cl.norm.weight'),
+                            G(pre + 'downsample_cf2cl.norm.bias'), g.eps)
     def conv_wgrad_fn():
-        dwc = zeros(C, g.k * g.k * sw.cin_pad)
-        ops.conv_wgrad(sv.inp, dy0, dwc, g.k, g.stride, g.pad)
-        grads[pre + 'downsample_cf2cl.conv.weight'] = unpack_conv_wgrad(dwc, g.Cin, g.k)
+        ops.conv_wgrad(sv.inp, dy0, G('raw/conv'), g.k, g.stride, g.pad)
+        if finalize is not None:
+            finalize()           # in stream order behind every weight-gradient GEMM of this stage
     side.run(conv_wgrad_fn, sv.inp, dy0)
     d_in = None
     if need_input_grad:
         d_in = ops.conv_dgrad(dy0, sw.conv_wd, prev_cot, g.H_in, g.W_in, g.Cin, g.k, g.stride, g.pad)
-    if join:
-        side.join()             # every parameter gradient of this stage is final from here on (DDP hook, optimizer)
-    return d_in, dh0, dc0, grads
+    side.join()             # every parameter gradient of this stage is final from here on (DDP hook, optimizer)
+    return d_in, dh0, dc0

@@ -23,7 +23,13 @@ class RNNStates:
     @classmethod
     def recursive_detach(cls, inp):
         if isinstance(inp, torch.Tensor):
-            return inp.detach()
+            d = inp.detach()
+            # a state that is a slice of a larger buffer (the (T+1)-slot feature array of the sequence kernels) would
+            # pin that whole buffer for as long as the state is kept: keep a copy of the slice instead
+            base = d._base
+            if base is not None and base.numel() > d.numel():
+                d = d.clone(memory_format=torch.preserve_format)
+            return d
         if isinstance(inp, list):
             return [cls.recursive_detach(x) for x in inp]
         if isinstance(inp, tuple):

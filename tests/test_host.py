@@ -109,16 +109,16 @@ red = StageGradReducer()
 class M: pass
 m = M(); red.attach(m)
 torch.manual_seed(0)
-ref = {s: {f'stages.{s}.w': torch.randn(5, 3), f'stages.{s}.b': torch.randn(7)} for s in range(4)}
-mine = {s: {k: v * (rank + 1) for k, v in g.items()} for s, g in ref.items()}
+ref = {s: torch.randn(5 * 3 + 7 + s) for s in range(4)}          # one flat fp32 bucket per stage
+mine = {s: v * (rank + 1) for s, v in ref.items()}
+ptrs = {s: v.data_ptr() for s, v in mine.items()}
 for s in (3, 2, 1, 0):                     # backward order: stage 4 first
     m._stage_grad_hook(s, mine[s])
 red.finish()
 scale = sum(r + 1 for r in range(world)) / world
 for s in range(4):
-    for k in ref[s]:
-        assert torch.allclose(mine[s][k], ref[s][k] * scale, atol=1e-6), (s, k)
-        assert mine[s][k].shape == ref[s][k].shape
+    assert torch.allclose(mine[s], ref[s] * scale, atol=1e-6), s
+    assert mine[s].data_ptr() == ptrs[s]                          # reduced in place: the bucket IS the .grad storage
 dist.destroy_process_group()
 print('OK', rank)
 '''
@@ -184,3 +184,113 @@ def test_backbone_data_parallel_world2_gloo(tmp_path):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert r.stdout.count('OK') == 2
+
+
+# ---- parameter-side tables, gradient buckets, grad-mode handling (CPU emulator build of the kernels) ----------------
+def _emu_model(name='micro', dtype=torch.float32):
+    from tests.backends import emu_library
+    from tests.test_backbone import build_model
+    _lib._install_test_library(emu_library())
+    return build_model(name, torch.device('cpu'), dtype)
+
+
+def test_pack_table_matches_reference_packings():
+    """rvt_pack_table (one launch) == the plain tensor restatements of every packing (rvt_amd/weights.py)."""
+    from rvt_amd import weights as Wt
+    from tests import casegen
+    try:
+        for dtype in (torch.float32, torch.bfloat16):
+            m = _emu_model('micro_dws_xh', dtype)
+            xs = torch.from_numpy(casegen.make_inputs('micro_dws_xh'))
+            m.forward_sequence(xs)                              # training-mode forward: builds + packs everything
+            mw = m._mw_cache
+            sd = {k: v.detach() for k, v in m.named_parameters()}
+            for si, sw in enumerate(mw.stages):
+                pre = f'stages.{si}.'
+                g = m.stage_geoms(64, 96)[si]
+                w = sd[pre + 'downsample_cf2cl.conv.weight']
+                assert torch.equal(sw.conv_w, Wt.pack_conv_fwd(w, sw.cin_pad, dtype))
+                if sw.conv_wd is not None:
+                    assert torch.equal(sw.conv_wd, Wt.pack_conv_dgrad(w, g.stride, g.pad, dtype))
+                wl = sd[pre + 'lstm.conv1x1.weight'].reshape(4 * g.C, 2 * g.C)
+                perm = Wt.lstm_gate_perm(g.C, 'cpu')
+                assert torch.equal(sw.lstm_w, wl[perm].to(dtype))
+                assert torch.equal(sw.lstm_b, sd[pre + 'lstm.conv1x1.bias'][perm])
+                assert torch.equal(sw.lstm_wn, wl.to(dtype)) and torch.equal(sw.lstm_wt, wl.t().to(dtype))
+                bw = sw.blocks[0][1]
+                bp = pre + 'att_blocks.0.att_grid.'
+                assert torch.equal(bw['qkv_w'], sd[bp + 'self_attn.qkv.weight'].to(dtype))
+                assert torch.equal(bw['fc1_wt'], sd[bp + 'mlp.net.0.0.weight'].t().to(dtype))
+                want = (sd[bp + 'mlp.net.2.weight'] * sd[bp + 'ls2.gamma'][:, None]).t().to(dtype)
+                assert torch.equal(bw['fc2_wt'], want)
+                want = (sd[bp + 'self_attn.proj.weight'] * sd[bp + 'ls1.gamma'][:, None]).t().to(dtype)
+                assert torch.equal(bw['proj_wt'], want)
+    finally:
+        _lib._install_test_library(None)
+
+
+def test_no_grad_forward_takes_inference_path_and_weight_cache_tracks_parameters():
+    from tests import casegen
+    try:
+        m = _emu_model()
+        xs = torch.from_numpy(casegen.make_inputs('micro'))
+        with torch.no_grad():
+            f0, st = m.forward_sequence(xs)
+        assert m._last_saved is None                             # nothing kept for a backward that cannot happen
+        assert all(sw.lstm_wt is None for sw in m._mw_cache.stages)
+        assert st[0][0]._base is None                            # states do not pin the (T+1)-slot feature buffer
+        f1, _ = m.forward_sequence(xs)                           # grad mode on: training path, same numbers
+        assert m._last_saved is not None
+        for s in range(1, 5):
+            assert torch.equal(f0[s], f1[s].detach())
+        # in-place update through .data does not bump _version: inference must be told, training re-packs by itself
+        p = m.stages[0].downsample_cf2cl.conv.weight
+        with torch.no_grad():
+            ref, _ = m.forward_sequence(xs)
+            p.data.mul_(1.5)
+            stale, _ = m.forward_sequence(xs)
+            assert torch.equal(stale[1], ref[1])
+            m.invalidate_weight_cache()
+            fresh, _ = m.forward_sequence(xs)
+            assert not torch.equal(fresh[1], ref[1])
+            # .to()/param.data = ... replaces the storage: picked up without being told
+            p.data = p.data.clone() * 2.0
+            moved, _ = m.forward_sequence(xs)
+            assert not torch.equal(moved[1], fresh[1])
+    finally:
+        _lib._install_test_library(None)
+
+
+def test_gradient_buckets_accumulate_and_reassign():
+    """.grad is a view of the stage's persistent bucket; a second backward without zeroing accumulates (like autograd),
+    after zero_grad(set_to_none=True) the bucket restarts from zero, a foreign .grad tensor gets the result added."""
+    from tests import casegen
+    try:
+        m = _emu_model()
+        xs = torch.from_numpy(casegen.make_inputs('micro'))
+        cots = [torch.from_numpy(a) for a in casegen.make_cotangents('micro')]
+
+        def bwd():
+            feats, _ = m.forward_sequence(xs)
+            torch.autograd.backward([feats[s + 1] for s in range(4)], cots)
+        bwd()
+        g1 = {n: p.grad.clone() for n, p in m.named_parameters()}
+        mw = m._mw_cache
+        n0 = 'stages.2.att_blocks.0.att_grid.ls2.gamma'
+        assert m.get_parameter(n0).grad.data_ptr() == mw.grads[2].g(n0).data_ptr()
+        bwd()                                                    # accumulate
+        for n, p in m.named_parameters():
+            assert torch.allclose(p.grad, 2 * g1[n], rtol=1e-5, atol=1e-7 * float(g1[n].abs().max())), n
+        m.zero_grad(set_to_none=True)
+        bwd()
+        for n, p in m.named_parameters():
+            assert torch.equal(p.grad, g1[n]), n
+        m.zero_grad(set_to_none=True)
+        w = m.get_parameter(n0)
+        w.grad = torch.ones_like(w)                              # foreign gradient tensor
+        bwd()
+        assert torch.allclose(w.grad, g1[n0] + 1.0)
+        other = 'stages.2.att_blocks.0.att_grid.ls1.gamma'
+        assert torch.equal(m.get_parameter(other).grad, g1[other])
+    finally:
+        _lib._install_test_library(None)
