@@ -119,6 +119,22 @@ int rvt_lstm_dgrad(const void* dz, const void* wt, void* dx, void* dh_rec, int d
 int rvt_lstm_wgrad(const void* dz, const void* x, const void* h_prev, float* dw, float* dz_colsum, float* ws, int dtype,
                    int M, int C, void* stream);
 
+/* The same ConvLSTM cell (rnn.py:43-67) with the TIME LOOP INSIDE the kernel, for the 1x1-conv variant (dws_conv False: the
+ * recurrence is independent per pixel): one launch per stage runs all T_steps of modules/detection.py:131-148 for that stage
+ * with h / c on chip.  rvt_lstm_scan_supported(dtype, C) != 0 for C in {32, 64, 128}.
+ *   fwd: x_all [T][M][C]; Hall [T+1][M][C], slot 0 = incoming h (caller-filled), slots 1..T written; c0 fp32 [M][C] or
+ *        NULL (zeros); c_last fp32 [M][C]; Csave [T][M][C] (dtype; slot t = c_t, what BPTT needs) or NULL (inference);
+ *        w [4C][2C] in the reference's NATURAL order (rows f,i,o,g; columns [x|h]); bias fp32 [4C].
+ *   bwd: reverse scan with the gates recomputed; dH [T][M][C] cotangent of Hall[1..] (NULL = zeros), dc_last fp32 [M][C]
+ *        (NULL = zeros); wt = w^T [2C][4C]; writes dx_all [T][M][C], dz_all [T][M][4C] (pre-activation gradients, natural
+ *        gate order, operand of rvt_lstm_wgrad), dh0 [M][C], dc0 fp32 [M][C]. */
+int rvt_lstm_scan_supported(int dtype, int C);
+int rvt_lstm_scan_fwd(const void* x_all, void* Hall, const float* c0, float* c_last, void* Csave, const void* w,
+                      const float* bias, int dtype, int M, int C, int T_steps, void* stream);
+int rvt_lstm_scan_bwd(const void* x_all, const void* Hall, const void* Csave, const float* c0, const void* dH,
+                      const float* dc_last, const void* w, const void* wt, const float* bias, void* dx_all, void* dz_all,
+                      void* dh0, float* dc0, int dtype, int M, int C, int T_steps, void* stream);
+
 /* Depth-wise k x k conv (k = 3; groups = channels, padding k/2, stride 1) of the DWS-ConvLSTM (rnn.py:25-29,50-54)
  * on channels-last maps: y[n][y][x][c] = b[c] + sum_taps w[c][ky][kx] x[...][c].  x / y rows have pitch ldx / ldy
  * elements (so a C-wide slice of a 2C-wide buffer can be addressed).  transpose=1 computes the input gradient

@@ -12,6 +12,7 @@
 #include "mlp.hpp"
 #include "events.hpp"
 #include "pack.hpp"
+#include "lstm_scan.hpp"
 #include "../../include/rvt_hip.h"
 
 namespace rvt {
@@ -543,6 +544,79 @@ int rvt_lstm_wgrad(const void* dz, const void* x, const void* h_prev, float* dw,
         DISPATCH_WGRAD_BN(2 * C, (launch_wgrad<T, BN>(a, b, XfNone(), dw, dz_colsum, ws, 4 * C, 2 * C, M, st)));
     });
     return check_launch("lstm_wgrad");
+}
+
+// ------------------------------------------------------------------------- ConvLSTM, time loop in the kernel
+// configurations built (waves per workgroup, weights resident in LDS or streamed from L2):
+//   bf16: C = 32 (4 waves, LDS), 64 (8 fwd / 4 bwd waves, LDS), 128 (weights from L2);  f32 (parity): C = 32, 64, 128 from L2
+int rvt_lstm_scan_supported(int dtype, int C) {
+    if (dtype != RVT_BF16 && dtype != RVT_F32) return 0;
+    return C == 32 || C == 64 || C == 128;
+}
+}  // extern "C"
+template <class K> static int scan_grid(K kernel, int threads, int M, int tm) {
+    static const int resident_override = getenv("RVT_GEMM_RESIDENT") ? atoi(getenv("RVT_GEMM_RESIDENT")) : 0;
+    const int n_tiles = (M + tm - 1) / tm;
+    const int per_cu = resident_per_cu(kernel, threads, 1);
+    return imax(1, imin(n_tiles, resident_override > 0 ? resident_override : 256 * per_cu));
+}
+template <class T, int C, int NW, int RB, bool W_LDS>
+static void launch_lstm_scan_fwd(const void* x_all, void* Hall, const float* c0, float* c_last, void* Csave, const void* W,
+                                 const float* bias, int M, int Tn, hipStream_t st) {
+    constexpr int TM = (NW / (C / 32)) * RB * 32;
+    auto k = lstm_scan_fwd_kernel<T, C, NW, RB, W_LDS>;
+    hipLaunchKernelGGL(k, dim3(scan_grid(k, 64 * NW, M, TM)), dim3(64 * NW), 0, st, (const T*)x_all, (T*)Hall, c0, c_last,
+                       (T*)Csave, (const T*)W, bias, M, Tn);
+}
+template <class T, int C, int NW, bool W_LDS>
+static void launch_lstm_scan_bwd(const void* x_all, const void* Hall, const void* Csave, const float* c0, const void* dH,
+                                 const float* dc_last, const void* W, const void* Wt, const float* bias, void* dx_all,
+                                 void* dz_all, void* dh0, float* dc0, int M, int Tn, hipStream_t st) {
+    constexpr int TM = (NW / (C / 32)) * 32;
+    auto k = lstm_scan_bwd_kernel<T, C, NW, W_LDS>;
+    hipLaunchKernelGGL(k, dim3(scan_grid(k, 64 * NW, M, TM)), dim3(64 * NW), 0, st, (const T*)x_all, (const T*)Hall,
+                       (const T*)Csave, c0, (const T*)dH, dc_last, (const T*)W, (const T*)Wt, bias, (T*)dx_all, (T*)dz_all,
+                       (T*)dh0, dc0, M, Tn);
+}
+extern "C" {
+
+int rvt_lstm_scan_fwd(const void* x_all, void* Hall, const float* c0, float* c_last, void* Csave, const void* w,
+                      const float* bias, int dtype, int M, int C, int T_steps, void* stream) {
+    RVT_CHECK(rvt_lstm_scan_supported(dtype, C), "lstm_scan_fwd: not built for dtype=%d C=%d", dtype, C);
+    RVT_CHECK(M >= 1 && T_steps >= 1, "lstm_scan_fwd: empty problem");
+    hipStream_t st = (hipStream_t)stream;
+#define RVT_SCAN_FWD(TT, CC, NWW, RBB, LDS) launch_lstm_scan_fwd<TT, CC, NWW, RBB, LDS>(x_all, Hall, c0, c_last, Csave, w, bias, M, T_steps, st)
+    if (dtype == RVT_BF16) {
+        if (C == 32) RVT_SCAN_FWD(bf16, 32, 4, 1, true);
+        else if (C == 64) RVT_SCAN_FWD(bf16, 64, 8, 1, true);
+        else RVT_SCAN_FWD(bf16, 128, 4, 1, false);
+    } else {             // (four waves: the f32 variants need more than the 256 registers an 8-wave workgroup leaves)
+        if (C == 32) RVT_SCAN_FWD(float, 32, 4, 1, false);
+        else if (C == 64) RVT_SCAN_FWD(float, 64, 4, 1, false);
+        else RVT_SCAN_FWD(float, 128, 4, 1, false);
+    }
+#undef RVT_SCAN_FWD
+    return check_launch("lstm_scan_fwd");
+}
+
+int rvt_lstm_scan_bwd(const void* x_all, const void* Hall, const void* Csave, const float* c0, const void* dH,
+                      const float* dc_last, const void* w, const void* wt, const float* bias, void* dx_all, void* dz_all,
+                      void* dh0, float* dc0, int dtype, int M, int C, int T_steps, void* stream) {
+    RVT_CHECK(rvt_lstm_scan_supported(dtype, C), "lstm_scan_bwd: not built for dtype=%d C=%d", dtype, C);
+    RVT_CHECK(M >= 1 && T_steps >= 1 && Csave != nullptr, "lstm_scan_bwd: empty problem / missing saved cell states");
+    hipStream_t st = (hipStream_t)stream;
+#define RVT_SCAN_BWD(TT, CC, NWW, LDS) launch_lstm_scan_bwd<TT, CC, NWW, LDS>(x_all, Hall, Csave, c0, dH, dc_last, w, wt, bias, dx_all, dz_all, dh0, dc0, M, T_steps, st)
+    if (dtype == RVT_BF16) {
+        if (C == 32) RVT_SCAN_BWD(bf16, 32, 4, true);
+        else if (C == 64) RVT_SCAN_BWD(bf16, 64, 4, true);
+        else RVT_SCAN_BWD(bf16, 128, 4, false);
+    } else {
+        if (C == 32) RVT_SCAN_BWD(float, 32, 4, false);
+        else if (C == 64) RVT_SCAN_BWD(float, 64, 4, false);
+        else RVT_SCAN_BWD(float, 128, 4, false);
+    }
+#undef RVT_SCAN_BWD
+    return check_launch("lstm_scan_bwd");
 }
 
 // ------------------------------------------------------------------------------------ depth-wise conv

@@ -135,6 +135,49 @@ template <class T> __device__ __forceinline__ frag_t<T> tile_load_frag(const cha
     return v;
 }
 
+// ---- LDS transpose read (gfx950 ds_read_b64_tr_b16) --------------------------------------------------------
+// Within every group of 16 lanes the sixteen 8-byte chunks the lanes address form a 16 x 4 matrix of 16-bit elements
+// (row = lane, 4 elements each); lane i receives, as element k = 0..3, element (i & 3) of the chunk addressed by lane
+// 4k + (i >> 2) of its group (mapped empirically: profiles/probes/tr_read_probe.hip).  This is what turns a row-major
+// [token][feature] LDS tile into MFMA operands whose contraction index is the TOKEN (in-kernel weight gradients,
+// products with W^T from a single LDS image of W): see load_frag_tr below.
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+__device__ __forceinline__ void tr_read4(const bf16* p, bf16 (&o)[4]) {
+#ifdef RVT_EMU
+    auto buf = emu::exchange(&p, sizeof(p));
+    const int lane = emu::g.cur->lane, grp = lane & ~15, i = lane & 15;
+    for (int k = 0; k < 4; k++) {
+        const bf16* q;
+        memcpy(&q, buf[grp + 4 * k + (i >> 2)], sizeof(q));
+        o[k] = q[i & 3];
+    }
+#else
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const short h = v[k]; o[k] = *reinterpret_cast<const bf16*>(&h); }
+#endif
+}
+// Transposed operand fragment: f[e] = X[tok0 + 8*(lane>>5) + e][feat0 + (lane&31)], e = 0..7, i.e. the A/B fragment of
+// an MFMA whose rows are FEATURES feat0..feat0+31 and whose contraction runs over TOKENS tok0..tok0+15.  `at(tok, feat)`
+// returns the LDS address of element (tok, feat); 4 consecutive features starting at a multiple of 4 must be contiguous
+// there (true for every swizzled tile in this directory: the swizzle moves whole 16-byte chunks).
+template <class T, class At> __device__ __forceinline__ frag_t<T> load_frag_tr(const At& at, int tok0, int feat0, int lane) {
+    frag_t<T> f;
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            bf16 o[4];
+            tr_read4(at(tok0 + 8 * (lane >> 5) + 4 * r + ((lane & 15) >> 2), feat0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3)), o);
+#pragma unroll
+            for (int k = 0; k < 4; k++) f[4 * r + k] = o[k];
+        }
+    } else {            // f32 parity mode: no 32-bit transpose read; eight scalar LDS reads
+#pragma unroll
+        for (int e = 0; e < 8; e++) f[e] = *at(tok0 + 8 * (lane >> 5) + e, feat0 + (lane & 31));
+    }
+    return f;
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also fences global memory: hipcc emits
 // `s_waitcnt vmcnt(0)` in front of the barrier, i.e. every wave waits until its outstanding global STORES are
 // acknowledged (CDNA counts stores on vmcnt).  In these kernels barriers only protect LDS tiles / staging buffers —

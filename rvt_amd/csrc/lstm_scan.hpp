@@ -1,0 +1,409 @@
+// ConvLSTM with the TIME LOOP INSIDE the kernel (reference models/layers/rnn.py:43-67 driven by the loop of
+// modules/detection.py:131-148), forward and BPTT backward, for the 1x1-conv cell every shipped config uses
+// (dws_conv: False, config/model/maxvit_yolox/default.yaml:39).
+//
+// With a 1x1 conv the recurrence is independent per pixel, so a workgroup owns a tile of TM pixels and walks t itself:
+//   forward : h_{t-1} (next step's A operand) lives in LDS, c_t in fp32 accumulator-layout registers; per step the
+//             kernel reads x_t once and writes h_t (the stage's output feature, needed anyway) and a T-typed copy of c_t
+//             (the only thing BPTT needs that cannot be recomputed): 3 activation rows per token-step instead of 11,
+//             one launch per stage instead of T.
+//   backward: gates are RECOMPUTED from (x_t, h_{t-1}) with the same GEMM, dc and dh_rec stay in registers across the
+//             reverse time loop, dz goes LDS -> (a) A operand of the dz.W product, whose W^T fragments come from the ONE
+//             LDS image of W through the transpose read, and (b) HBM once, for the weight-gradient GEMM.
+// Register layout trick: a wave computes, for ITS 32 channels, the four gate blocks f,i,o,g as four 32x32 MFMA column
+// blocks (B rows g*C + c of the natural weight layout), so the four gates of a (token, channel) land in the SAME lane at
+// the same accumulator index: the gate math needs no LDS staging and no shuffles, and c / dc / dh_rec persist in
+// registers in that layout.
+#pragma once
+#include "common.hpp"
+#include "mlp.hpp"
+
+namespace rvt {
+
+// address of element (row, kcol) of an LDS operand matrix [rows][K] (K-subtiles of [rows][128 B], swizzled 16-B chunks)
+template <class T> __device__ __forceinline__ T* opm_elem_ptr(char* base, int rows, int row, int kcol) {
+    constexpr int BK = TileGeom<T>::BK;
+    const int kt = kcol / BK, kc = kcol % BK;
+    const int byte = kc * (int)sizeof(T);
+    return reinterpret_cast<T*>(base + (size_t)kt * rows * 128 + lds_chunk_off(row, byte >> 4) + (byte & 15));
+}
+template <class T> __device__ __forceinline__ frag_t<T> opm_load_frag(const char* base, int rows, int row, int fcg) {
+    constexpr int FPR = TileGeom<T>::FPR;
+    return tile_load_frag<T>(base + (size_t)(fcg / FPR) * rows * 128, row, fcg % FPR);
+}
+
+template <class T, int C, int NW> struct LstmScanGeom {
+    static constexpr int NT = 64 * NW;
+    static constexpr int NWC = C / 32;                     // channel groups of 32 = waves along the channel axis
+    static constexpr int NWM = NW / NWC;                   // waves along the token axis
+    static constexpr int BK = TileGeom<T>::BK;
+    static constexpr int KTC = (C + BK - 1) / BK;          // K-subtiles of a [.][C] operand matrix
+    static_assert(C % 32 == 0 && NW % NWC == 0 && NWM >= 1, "wave layout");
+};
+
+// predicated 16/32-byte load: never dereferences when !ok
+template <class T> __device__ __forceinline__ frag_t<T> frag_load(const T* p, bool ok) {
+    if (!ok) return frag_zero<T>();
+    return *reinterpret_cast<const frag_t<T>*>(p);
+}
+// fp32 row segment -> T fragment (the incoming cell state of the backward scan)
+template <class T> __device__ __forceinline__ frag_t<T> frag_load_f32(const float* p) {
+    float v[8];
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    return frag_from_float<T>(v);
+}
+
+// cooperative copies between a global [M][C] matrix (rows m0.., zero beyond M) and an LDS operand matrix of TM rows,
+// staged through registers so that the global loads can be issued a whole time step ahead of their use
+template <class T, int C, int NT, int TM> __device__ __forceinline__ void lds_tile_from_regs(char* A, const frag_t<T>* r, int tid) {
+    constexpr int G = C / 8, NFX = (TM * G + NT - 1) / NT;
+#pragma unroll
+    for (int q = 0; q < NFX; q++) {                          // (fully unrolled: r[] must stay in registers)
+        const int f = tid + q * NT;
+        if (f < TM * G) opm_store_frag<T>(A, TM, f / G, f % G, r[q]);
+    }
+}
+template <class T, int C, int NT, int TM> __device__ __forceinline__ void tile_load_regs(frag_t<T>* r, const T* src, int m0, int M, int tid) {
+    constexpr int G = C / 8, NFX = (TM * G + NT - 1) / NT;
+#pragma unroll
+    for (int q = 0; q < NFX; q++) {
+        const int f = tid + q * NT;
+        const int row = f / G;
+        const bool ok = f < TM * G && m0 + row < M;
+        if (src == nullptr) { r[q] = frag_zero<T>(); continue; }         // (workgroup-uniform)
+        const frag_t<T> v = frag_load<T>(src + (ok ? (size_t)(m0 + row) * C + (f % G) * 8 : 0));   // branch-free: clamp, select
+        const frag_t<T> z = frag_zero<T>();
+        r[q] = ok ? v : z;
+    }
+}
+
+// ====================================================================================================== forward
+// x_all [Tn][M][C], Hall [Tn+1][M][C] (slot 0 = incoming h, filled by the caller; slots 1.. written here),
+// c0 fp32 [M][C] or null (zeros), c_last fp32 [M][C], Csave [Tn][M][C] (slot t = c_t as T) or null,
+// W [4C][2C] natural gate order f,i,o,g and input order [x|h] (rnn.py:52-61), bias fp32 [4C].
+template <class T, int C, int NW, int RB, bool W_LDS>
+__global__ void __launch_bounds__(64 * NW)
+lstm_scan_fwd_kernel(const T* __restrict__ x_all, T* __restrict__ Hall, const float* __restrict__ c0, float* __restrict__ c_last,
+                     T* __restrict__ Csave, const T* __restrict__ W, const float* __restrict__ bias, int M, int Tn) {
+    typedef LstmScanGeom<T, C, NW> Gm;
+    constexpr int NT = Gm::NT, NWC = Gm::NWC, NWM = Gm::NWM, KTC = Gm::KTC;
+    constexpr int TM = NWM * RB * 32;
+    constexpr int TILE = KTC * TM * 128;
+    constexpr int WPART = KTC * (4 * C) * 128;             // one [4C][C] half of W
+    constexpr int NFX = (TM * (C / 8) + NT - 1) / NT;
+    __shared__ __attribute__((aligned(16))) char smem[(W_LDS ? 2 * WPART : 0) + 4 * TILE];
+    char* const Wx = smem;
+    char* const Wh = smem + (W_LDS ? WPART : 0);
+    char* const Ax = smem + (W_LDS ? 2 * WPART : 0);
+    char* const Ah0 = Ax + TILE;
+    char* const Cs = Ax + 3 * TILE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, half = lane >> 5;
+    const int wn = wave % NWC, wm = wave / NWC;
+    const int ch = wn * 32 + li;                           // this lane's channel
+    const size_t MC = (size_t)M * C;
+
+    if (W_LDS) {                                           // W -> LDS once per workgroup: [4C][x part] and [4C][h part]
+        constexpr int G = C / 8;
+        for (int f = tid; f < 4 * C * 2 * G; f += NT) {
+            const int n = f / (2 * G), g8 = f % (2 * G);
+            const frag_t<T> v = frag_load<T>(W + (size_t)n * 2 * C + g8 * 8);
+            if (g8 < G) opm_store_frag<T>(Wx, 4 * C, n, g8, v);
+            else opm_store_frag<T>(Wh, 4 * C, n, g8 - G, v);
+        }
+    }
+    float bz[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) bz[g] = bias[g * C + ch];
+
+    const int n_tiles = (M + TM - 1) / TM;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int m0 = tile * TM;
+        frag_t<T> xr[NFX];
+        float creg[RB][16];
+        // prologue of the tile: h_{-1} -> Ah[0], x_0 -> Ax, c_{-1} -> registers (accumulator layout)
+        tile_load_regs<T, C, NT, TM>(xr, Hall, m0, M, tid);
+        lds_barrier();                                     // previous tile's copy-out / MFMA reads are done
+        lds_tile_from_regs<T, C, NT, TM>(Ah0, xr, tid);
+        tile_load_regs<T, C, NT, TM>(xr, x_all, m0, M, tid);
+        lds_tile_from_regs<T, C, NT, TM>(Ax, xr, tid);
+#pragma unroll
+        for (int i = 0; i < RB; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = m0 + (wm * RB + i) * 32 + acc_row(r, lane);
+                creg[i][r] = (c0 != nullptr && row < M) ? c0[(size_t)row * C + ch] : 0.f;
+            }
+        lds_barrier();
+        int cur = 0;
+        for (int t = 0; t < Tn; t++) {
+            char* const Ah = Ah0 + cur * TILE;
+            char* const An = Ah0 + (cur ^ 1) * TILE;
+            if (t + 1 < Tn) tile_load_regs<T, C, NT, TM>(xr, x_all + (size_t)(t + 1) * MC, m0, M, tid);
+            sched_fence();
+            f32x16 acc[RB][4];
+#pragma unroll
+            for (int i = 0; i < RB; i++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) acc_zero(acc[i][g]);
+            // (weights streamed from L2: keep the K loop rolled, or every B fragment of the step is hoisted and spilled)
+            constexpr int KUNROLL = W_LDS ? C / 16 : 1;
+#pragma unroll
+            for (int part = 0; part < 2; part++) {         // [x_t | h_{t-1}] . W^T, K order = x columns then h columns
+                const char* const A = part ? Ah : Ax;
+                const char* const Wl = part ? Wh : Wx;
+#pragma clang loop unroll_count(KUNROLL)
+                for (int kc = 0; kc < C; kc += 16) {
+                    const int fcg = kc / 8 + half;
+                    frag_t<T> a[RB], b[4];
+#pragma unroll
+                    for (int i = 0; i < RB; i++) a[i] = opm_load_frag<T>(A, TM, (wm * RB + i) * 32 + li, fcg);
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        if (W_LDS) b[g] = opm_load_frag<T>(Wl, 4 * C, g * C + ch, fcg);
+                        else b[g] = frag_load<T>(W + (size_t)(g * C + ch) * 2 * C + part * C + fcg * 8);
+                    }
+#pragma unroll
+                    for (int i = 0; i < RB; i++)
+#pragma unroll
+                        for (int g = 0; g < 4; g++) mma32(acc[i][g], a[i], b[g]);
+                }
+            }
+            // gates (rnn.py:57-67), in registers
+#pragma unroll
+            for (int i = 0; i < RB; i++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const float f = sigmoid_f(acc[i][0][r] + bz[0]);
+                    const float ig = sigmoid_f(acc[i][1][r] + bz[1]);
+                    const float o = sigmoid_f(acc[i][2][r] + bz[2]);
+                    const float g = tanh_f(acc[i][3][r] + bz[3]);
+                    const float cn = f * creg[i][r] + ig * g;
+                    creg[i][r] = cn;
+                    const float hn = o * tanh_f(cn);
+                    const int row = (wm * RB + i) * 32 + acc_row(r, lane);
+                    *opm_elem_ptr<T>(An, TM, row, ch) = (T)hn;
+                    if (Csave != nullptr) *opm_elem_ptr<T>(Cs, TM, row, ch) = (T)cn;
+                }
+            lds_barrier();                                 // h_t / c_t tiles complete; every wave is done with Ax
+            {                                              // tile rows -> HBM in 16-byte pieces
+                constexpr int G = C / 8;
+                T* const hdst = Hall + (size_t)(t + 1) * MC;
+                T* const cdst = Csave != nullptr ? Csave + (size_t)t * MC : nullptr;
+                for (int f = tid; f < TM * G; f += NT) {
+                    const int row = f / G, cg = f % G;
+                    if (m0 + row < M) {
+                        frag_store<T>(hdst + (size_t)(m0 + row) * C + cg * 8, opm_load_frag<T>(An, TM, row, cg));
+                        if (cdst != nullptr) frag_store<T>(cdst + (size_t)(m0 + row) * C + cg * 8, opm_load_frag<T>(Cs, TM, row, cg));
+                    }
+                }
+            }
+            if (t + 1 < Tn) lds_tile_from_regs<T, C, NT, TM>(Ax, xr, tid);
+            lds_barrier();
+            cur ^= 1;
+        }
+#pragma unroll
+        for (int i = 0; i < RB; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = m0 + (wm * RB + i) * 32 + acc_row(r, lane);
+                if (row < M) c_last[(size_t)row * C + ch] = creg[i][r];
+            }
+    }
+}
+
+// ===================================================================================================== backward
+// Reverse scan.  Inputs as the forward's plus dH [Tn][M][C] (cotangent of Hall[1..], null = zeros) and dc_last fp32 [M][C]
+// (null = zeros); Wt = W^T [2C][4C] (only read when !W_LDS).  Outputs: dx_all [Tn][M][C], dz_all [Tn][M][4C] (natural gate
+// order, for the weight-gradient GEMM), dh0 [M][C] (T), dc0 fp32 [M][C].
+template <class T, int C, int NW, bool W_LDS>
+__global__ void __launch_bounds__(64 * NW)
+lstm_scan_bwd_kernel(const T* __restrict__ x_all, const T* __restrict__ Hall, const T* __restrict__ Csave,
+                     const float* __restrict__ c0, const T* __restrict__ dH, const float* __restrict__ dc_last,
+                     const T* __restrict__ W, const T* __restrict__ Wt, const float* __restrict__ bias,
+                     T* __restrict__ dx_all, T* __restrict__ dz_all, T* __restrict__ dh0, float* __restrict__ dc0, int M, int Tn) {
+    typedef LstmScanGeom<T, C, NW> Gm;
+    constexpr int NT = Gm::NT, NWC = Gm::NWC, NWM = Gm::NWM, KTC = Gm::KTC, BK = Gm::BK;
+    constexpr int TM = NWM * 32;
+    constexpr int TILE = KTC * TM * 128;
+    constexpr int WPART = KTC * (4 * C) * 128;
+    constexpr int KT4 = (4 * C) / BK;
+    static_assert((4 * C) % BK == 0, "dz operand");
+    constexpr int DZ = KT4 * TM * 128;
+    constexpr int G = C / 8;
+    constexpr int NFX = (TM * G + NT - 1) / NT;
+    __shared__ __attribute__((aligned(16))) char smem[(W_LDS ? 2 * WPART : 0) + 5 * TILE + DZ];
+    char* const Wx = smem;
+    char* const Wh = smem + (W_LDS ? WPART : 0);
+    char* const Ax = smem + (W_LDS ? 2 * WPART : 0);
+    char* const Ah = Ax + TILE;
+    char* const Sc = Ax + 2 * TILE;
+    char* const Sd = Ax + 3 * TILE;
+    char* const Sx = Ax + 4 * TILE;
+    char* const Adz = Ax + 5 * TILE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, half = lane >> 5;
+    const int wn = wave % NWC, wm = wave / NWC;
+    const int ch = wn * 32 + li;
+    const size_t MC = (size_t)M * C;
+
+    if (W_LDS) {
+        for (int f = tid; f < 4 * C * 2 * G; f += NT) {
+            const int n = f / (2 * G), g8 = f % (2 * G);
+            const frag_t<T> v = frag_load<T>(W + (size_t)n * 2 * C + g8 * 8);
+            if (g8 < G) opm_store_frag<T>(Wx, 4 * C, n, g8, v);
+            else opm_store_frag<T>(Wh, 4 * C, n, g8 - G, v);
+        }
+    }
+    float bz[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) bz[g] = bias[g * C + ch];
+
+    // c_{t-1} as a T fragment tile: slot t-1 of Csave, or the incoming fp32 state for t = 0
+    auto load_cprev = [&](frag_t<T> (&r)[NFX], int t, int m0) {
+#pragma unroll
+        for (int q = 0; q < NFX; q++) {
+            const int f = tid + q * NT;
+            const int row = f / G;
+            const bool ok = f < TM * G && m0 + row < M;
+            const size_t o = ok ? (size_t)(m0 + row) * C + (f % G) * 8 : 0;
+            if (t > 0) r[q] = frag_load<T>(Csave + (size_t)(t - 1) * MC + o, ok);
+            else if (c0 != nullptr && ok) r[q] = frag_load_f32<T>(c0 + o);
+            else r[q] = frag_zero<T>();
+        }
+    };
+
+    const int n_tiles = (M + TM - 1) / TM;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int m0 = tile * TM;
+        frag_t<T> rx[NFX], rh[NFX], rc[NFX], rd[NFX];
+        float dh_rec[16], dc_rec[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = m0 + wm * 32 + acc_row(r, lane);
+            dh_rec[r] = 0.f;
+            dc_rec[r] = (dc_last != nullptr && row < M) ? dc_last[(size_t)row * C + ch] : 0.f;
+        }
+        {
+            const int t = Tn - 1;
+            tile_load_regs<T, C, NT, TM>(rx, x_all + (size_t)t * MC, m0, M, tid);
+            tile_load_regs<T, C, NT, TM>(rh, Hall + (size_t)t * MC, m0, M, tid);
+            load_cprev(rc, t, m0);
+            tile_load_regs<T, C, NT, TM>(rd, dH != nullptr ? dH + (size_t)t * MC : nullptr, m0, M, tid);
+        }
+        lds_barrier();                                     // previous tile fully consumed
+        lds_tile_from_regs<T, C, NT, TM>(Ax, rx, tid);
+        lds_tile_from_regs<T, C, NT, TM>(Ah, rh, tid);
+        lds_tile_from_regs<T, C, NT, TM>(Sc, rc, tid);
+        lds_tile_from_regs<T, C, NT, TM>(Sd, rd, tid);
+        for (int t = Tn - 1; t >= 0; t--) {
+            lds_barrier();                                 // tiles of step t are in LDS
+            if (t > 0) {
+                tile_load_regs<T, C, NT, TM>(rx, x_all + (size_t)(t - 1) * MC, m0, M, tid);
+                tile_load_regs<T, C, NT, TM>(rh, Hall + (size_t)(t - 1) * MC, m0, M, tid);
+                load_cprev(rc, t - 1, m0);
+                tile_load_regs<T, C, NT, TM>(rd, dH != nullptr ? dH + (size_t)(t - 1) * MC : nullptr, m0, M, tid);
+            }
+            sched_fence();
+            // ---- recompute the pre-activations: z = [x_t | h_{t-1}] W^T ----
+            f32x16 acc[4];
+#pragma unroll
+            for (int g = 0; g < 4; g++) acc_zero(acc[g]);
+            constexpr int KUNROLL = W_LDS ? C / 16 : 1;
+#pragma unroll
+            for (int part = 0; part < 2; part++) {
+                const char* const A = part ? Ah : Ax;
+                const char* const Wl = part ? Wh : Wx;
+#pragma clang loop unroll_count(KUNROLL)
+                for (int kc = 0; kc < C; kc += 16) {
+                    const int fcg = kc / 8 + half;
+                    const frag_t<T> a = opm_load_frag<T>(A, TM, wm * 32 + li, fcg);
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        frag_t<T> b;
+                        if (W_LDS) b = opm_load_frag<T>(Wl, 4 * C, g * C + ch, fcg);
+                        else b = frag_load<T>(W + (size_t)(g * C + ch) * 2 * C + part * C + fcg * 8);
+                        mma32(acc[g], a, b);
+                    }
+                }
+            }
+            // ---- gate backward (autograd of rnn.py:57-67) in registers; dz -> LDS as the next product's A operand ----
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = wm * 32 + acc_row(r, lane);
+                const float f = sigmoid_f(acc[0][r] + bz[0]);
+                const float ig = sigmoid_f(acc[1][r] + bz[1]);
+                const float o = sigmoid_f(acc[2][r] + bz[2]);
+                const float g = tanh_f(acc[3][r] + bz[3]);
+                const float cp = (float)*opm_elem_ptr<T>(Sc, TM, row, ch);
+                const float dh = (float)*opm_elem_ptr<T>(Sd, TM, row, ch) + dh_rec[r];
+                const float tc = tanh_f(f * cp + ig * g);
+                const float dc = dc_rec[r] + dh * o * (1.f - tc * tc);
+                *opm_elem_ptr<T>(Adz, TM, row, 0 * C + ch) = (T)(dc * cp * f * (1.f - f));
+                *opm_elem_ptr<T>(Adz, TM, row, 1 * C + ch) = (T)(dc * g * ig * (1.f - ig));
+                *opm_elem_ptr<T>(Adz, TM, row, 2 * C + ch) = (T)(dh * tc * o * (1.f - o));
+                *opm_elem_ptr<T>(Adz, TM, row, 3 * C + ch) = (T)(dc * ig * (1.f - g * g));
+                dc_rec[r] = dc * f;
+            }
+            lds_barrier();                                 // dz tile complete; Ax/Ah/Sc/Sd of step t consumed
+            // ---- [dx_t | dh_{t-1}] = dz W: this wave's 32 x-columns and its 32 h-columns ----
+            f32x16 acc2[2];
+            acc_zero(acc2[0]); acc_zero(acc2[1]);
+            constexpr int KUNROLL2 = W_LDS ? 4 : 1;
+#pragma clang loop unroll_count(KUNROLL2)
+            for (int kc = 0; kc < 4 * C; kc += 16) {
+                const frag_t<T> a = opm_load_frag<T>(Adz, TM, wm * 32 + li, kc / 8 + half);
+#pragma unroll
+                for (int part = 0; part < 2; part++) {
+                    frag_t<T> b;
+                    if (W_LDS) {       // B[j][n] = W[n][j]: transposed fragments of the LDS image of W (rows n, columns j)
+                        char* const Wl = part ? Wh : Wx;
+                        auto at = [&](int n, int j) -> const T* { return opm_elem_ptr<T>(Wl, 4 * C, n, j); };
+                        b = load_frag_tr<T>(at, kc, wn * 32, lane);
+                    } else {
+                        b = frag_load<T>(Wt + (size_t)(part * C + ch) * 4 * C + kc + half * 8);
+                    }
+                    mma32(acc2[part], a, b);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = wm * 32 + acc_row(r, lane);
+                *opm_elem_ptr<T>(Sx, TM, row, ch) = (T)acc2[0][r];
+                dh_rec[r] = acc2[1][r];
+            }
+            lds_barrier();                                 // dx tile complete; dz reads done
+            {
+                T* const xdst = dx_all + (size_t)t * MC;
+                for (int f = tid; f < TM * G; f += NT) {
+                    const int row = f / G, cg = f % G;
+                    if (m0 + row < M) frag_store<T>(xdst + (size_t)(m0 + row) * C + cg * 8, opm_load_frag<T>(Sx, TM, row, cg));
+                }
+                T* const zdst = dz_all + (size_t)t * MC * 4;
+                for (int f = tid; f < TM * 4 * G; f += NT) {
+                    const int row = f / (4 * G), cg = f % (4 * G);
+                    if (m0 + row < M) frag_store<T>(zdst + (size_t)(m0 + row) * 4 * C + cg * 8, opm_load_frag<T>(Adz, TM, row, cg));
+                }
+            }
+            if (t > 0) {
+                lds_tile_from_regs<T, C, NT, TM>(Ax, rx, tid);
+                lds_tile_from_regs<T, C, NT, TM>(Ah, rh, tid);
+                lds_tile_from_regs<T, C, NT, TM>(Sc, rc, tid);
+                lds_tile_from_regs<T, C, NT, TM>(Sd, rd, tid);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = m0 + wm * 32 + acc_row(r, lane);
+            if (row < M) {
+                dh0[(size_t)row * C + ch] = (T)dh_rec[r];
+                dc0[(size_t)row * C + ch] = dc_rec[r];
+            }
+        }
+    }
+}
+
+}  // namespace rvt

@@ -247,6 +247,33 @@ def lstm_wgrad(dz: Tensor, x: Tensor, h_prev: Tensor, dw: Tensor, colsum_out: Op
            L.dtype_code(dz.dtype), M, C, L.stream_of(dz))
 
 
+def lstm_scan_supported(dtype: torch.dtype, C: int) -> bool:
+    return bool(L.get_lib().rvt_lstm_scan_supported(L.dtype_code(dtype), C))
+
+
+def lstm_scan_fwd(x_all: Tensor, Hall: Tensor, c0: Optional[Tensor], c_last: Tensor, Csave: Optional[Tensor], w: Tensor,
+                  bias: Tensor) -> None:
+    """All T steps of the 1x1-conv ConvLSTM in one launch (time loop in the kernel).  x_all (T,...,C); Hall (T+1,...,C) with
+    slot 0 = incoming h; c0/c_last fp32 (...,C); Csave (T,...,C) or None; w [4C][2C] natural order, bias fp32 [4C]."""
+    T_, C = x_all.shape[0], x_all.shape[-1]
+    M = x_all[0].numel() // C
+    assert Hall.shape[0] == T_ + 1 and Hall.dtype == x_all.dtype and c_last.dtype == torch.float32
+    assert c0 is None or c0.dtype == torch.float32
+    L.call('rvt_lstm_scan_fwd', L.ptr(x_all), L.ptr(Hall), L.ptr(c0), L.ptr(c_last), L.ptr(Csave), L.ptr(w), L.ptr(bias),
+           L.dtype_code(x_all.dtype), M, C, T_, L.stream_of(x_all))
+
+
+def lstm_scan_bwd(x_all: Tensor, Hall: Tensor, Csave: Tensor, c0: Optional[Tensor], dH: Optional[Tensor],
+                  dc_last: Optional[Tensor], w: Tensor, wt: Tensor, bias: Tensor, dx_all: Tensor, dz_all: Tensor,
+                  dh0: Tensor, dc0: Tensor) -> None:
+    T_, C = x_all.shape[0], x_all.shape[-1]
+    M = x_all[0].numel() // C
+    assert dc0.dtype == torch.float32 and (dc_last is None or dc_last.dtype == torch.float32)
+    L.call('rvt_lstm_scan_bwd', L.ptr(x_all), L.ptr(Hall), L.ptr(Csave), L.ptr(c0), L.ptr(dH), L.ptr(dc_last), L.ptr(w),
+           L.ptr(wt), L.ptr(bias), L.ptr(dx_all), L.ptr(dz_all), L.ptr(dh0), L.ptr(dc0), L.dtype_code(x_all.dtype), M, C, T_,
+           L.stream_of(x_all))
+
+
 def dwconv(x: Tensor, w: Tensor, b: Optional[Tensor], k: int, transpose: bool = False, out: Optional[Tensor] = None) -> Tensor:
     """Depth-wise k x k conv on (N,H,W,C) channels-last (rnn.py:25-29); transpose=True -> input gradient."""
     N, H, W, C = x.shape

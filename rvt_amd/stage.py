@@ -41,6 +41,16 @@ def use_fused_mlp(dtype, C: int, what: str) -> bool:
     return C == 64 or (C == 128 and what.startswith('fwd'))
 
 
+def use_lstm_scan(dtype, C: int, dws) -> bool:
+    """ConvLSTM with the time loop inside the kernel (csrc/lstm_scan.hpp) instead of one launch per step: only the 1x1-conv
+    cell (dws_conv False — every shipped config); by default where the weights stay resident in LDS (C <= 64), C = 128
+    (weights streamed from L2) with RVT_LSTM_SCAN=1 (all supported widths; the parity tests) ; =0 disables."""
+    mode = os.environ.get('RVT_LSTM_SCAN', 'auto')
+    if mode == '0' or dws is not None or not ops.lstm_scan_supported(dtype, C):
+        return False
+    return True if mode == '1' else C <= 64
+
+
 class SideStream:
     """Weight-gradient GEMMs are off the critical path of backward (nothing downstream reads dW until the optimizer) and
     are read-only streams, while the input-gradient chain they hang off is write-heavy; running them on a second HIP
@@ -103,7 +113,7 @@ class StageGeom:
 
 class StageSaved:
     """Activations kept for backward (everything else is recomputed from these)."""
-    __slots__ = ('inp', 'y0', 'blocks', 'x_last', 'Hall', 'Call', 'gates', 'mask', 'xin_lstm', 'hconv')
+    __slots__ = ('inp', 'y0', 'blocks', 'x_last', 'Hall', 'Call', 'gates', 'mask', 'xin_lstm', 'hconv', 'Csave', 'c0')
 
     def __init__(self):
         self.blocks: List[Dict[str, Tensor]] = []
@@ -151,18 +161,29 @@ def stage_seq_forward(sw: StageWeights, g: StageGeom, inp: Tensor, h0: Optional[
             x = xout
 
     Hall = torch.empty((T + 1, B, H, W, C), dtype=dt, device=dev)
+    dws = sw.dws
+    if h0 is None:
+        Hall[0].zero_()                                                           # rnn.py:43-47
+    else:
+        Hall[0].copy_(h0)
+    if use_lstm_scan(dt, C, dws):
+        # all T steps in ONE launch: h / c stay on chip, BPTT keeps only a T-typed copy of the cell states
+        c_last = torch.empty((B, H, W, C), dtype=torch.float32, device=dev)
+        Csave = torch.empty((T, B, H, W, C), dtype=dt, device=dev) if save else None
+        ops.lstm_scan_fwd(x.view(T, B, H, W, C), Hall, c0, c_last, Csave, sw.lstm_wn, sw.lstm_bn)
+        if save:
+            sv.x_last, sv.Hall, sv.Call, sv.gates = x, Hall, None, None
+            sv.xin_lstm, sv.hconv, sv.Csave, sv.c0 = x, None, Csave, c0
+        return Hall, c_last, sv
     # cell states: all T+1 slots are kept for BPTT; a no-grad forward ping-pongs between two
     nc = T + 1 if save else 2
     Call = torch.empty((nc, B, H, W, C), dtype=torch.float32, device=dev)
     if h0 is None:
-        Hall[0].zero_()                                                           # rnn.py:43-47
         Call[0].zero_()
     else:
-        Hall[0].copy_(h0)
         Call[0].copy_(c0)
     gates = torch.empty((T, B, H, W, 4 * C), dtype=dt, device=dev) if save else None
     # DWS-ConvLSTM (rnn.py:50-54): depth-wise 3x3 on h_{t-1} only, or on cat(x, h_{t-1}) (the x half batched over T)
-    dws = sw.dws
     x_lstm = x
     hconv = None
     if dws is not None:
@@ -183,7 +204,7 @@ def stage_seq_forward(sw: StageWeights, g: StageGeom, inp: Tensor, h0: Optional[
     c_last = Call[T % nc].clone() if save else Call[T % nc]
     if save:
         sv.x_last, sv.Hall, sv.Call, sv.gates = x, Hall, Call, gates
-        sv.xin_lstm, sv.hconv = x_lstm, hconv
+        sv.xin_lstm, sv.hconv, sv.Csave, sv.c0 = x_lstm, hconv, None, None
     return Hall, c_last, sv
 
 
@@ -203,26 +224,34 @@ def stage_seq_backward(sw: StageWeights, g: StageGeom, sv: StageSaved, dH: Optio
     G = sg.g
 
     # ---- ConvLSTM BPTT ------------------------------------------------------------------------------
-    if dH is None:
-        dH = torch.zeros((T, B, H, W, C), dtype=dt, device=dev)
     dz = torch.empty((T, B, H, W, 4 * C), dtype=dt, device=dev)
     dx = torch.empty((T, B, H, W, C), dtype=dt, device=dev)
-    dc_rec = torch.zeros((B, H, W, C), dtype=f32, device=dev) if dc_last is None else dc_last.to(f32).contiguous().clone()
-    dh_rec = None
-    dh_buf = [torch.empty((B, H, W, C), dtype=dt, device=dev) for _ in range(2)]
     dws = sw.dws
-    dhc = torch.empty((T, B, H, W, C), dtype=dt, device=dev) if dws is not None else None   # d(dwconv(h_{t-1}))
-    if dws is not None:
-        wh = dws['w'] if dws['only_hidden'] else dws['w'][C:]
-    for t in range(T - 1, -1, -1):
-        ops.lstm_gates_bwd(dH[t], dh_rec, dc_rec, sv.gates[t], sv.Call[t + 1], sv.Call[t], dz[t])
-        nxt = dh_buf[t & 1]
-        if dws is None:
-            ops.lstm_dgrad(dz[t], sw.lstm_wt, dx[t], nxt)
-        else:
-            ops.lstm_dgrad(dz[t], sw.lstm_wt, dx[t], dhc[t])
-            ops.dwconv(dhc[t], wh, None, dws['k'], transpose=True, out=nxt)
-        dh_rec = nxt
+    if sv.Csave is not None:
+        # reverse scan in ONE launch: gates recomputed from (x_t, h_{t-1}), dc / dh_rec in registers across t
+        dh_rec = torch.empty((B, H, W, C), dtype=dt, device=dev)
+        dc_rec = torch.empty((B, H, W, C), dtype=f32, device=dev)
+        ops.lstm_scan_bwd(sv.xin_lstm.view(T, B, H, W, C), sv.Hall, sv.Csave, sv.c0, dH,
+                          None if dc_last is None else dc_last.to(f32).contiguous(), sw.lstm_wn, sw.lstm_wt, sw.lstm_bn,
+                          dx, dz, dh_rec, dc_rec)
+    else:
+        if dH is None:
+            dH = torch.zeros((T, B, H, W, C), dtype=dt, device=dev)
+        dc_rec = torch.zeros((B, H, W, C), dtype=f32, device=dev) if dc_last is None else dc_last.to(f32).contiguous().clone()
+        dh_rec = None
+        dh_buf = [torch.empty((B, H, W, C), dtype=dt, device=dev) for _ in range(2)]
+        dhc = torch.empty((T, B, H, W, C), dtype=dt, device=dev) if dws is not None else None   # d(dwconv(h_{t-1}))
+        if dws is not None:
+            wh = dws['w'] if dws['only_hidden'] else dws['w'][C:]
+        for t in range(T - 1, -1, -1):
+            ops.lstm_gates_bwd(dH[t], dh_rec, dc_rec, sv.gates[t], sv.Call[t + 1], sv.Call[t], dz[t])
+            nxt = dh_buf[t & 1]
+            if dws is None:
+                ops.lstm_dgrad(dz[t], sw.lstm_wt, dx[t], nxt)
+            else:
+                ops.lstm_dgrad(dz[t], sw.lstm_wt, dx[t], dhc[t])
+                ops.dwconv(dhc[t], wh, None, dws['k'], transpose=True, out=nxt)
+            dh_rec = nxt
     if side is None:
         side = SideStream(dz)
     h_seg = sv.Hall[:T].reshape(F_, H, W, C) if dws is None else sv.hconv.view(F_, H, W, C)

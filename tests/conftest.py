@@ -10,6 +10,8 @@ os.environ.setdefault('RVT_GEMM_RESIDENT', '8')     # (a multiple of 8: also rea
 # ... and let the weight-gradient kernels cut even test-size token counts into several K slices (production: >= 8192
 # tokens per slice), so the two-stage split-K path (partial tiles + reduction, column sums per slice) is exercised
 os.environ.setdefault('RVT_WGRAD_SLICE_TOKENS', '128')
+# ConvLSTM scan kernels for every width they are built for (production default: only where the weights fit the LDS)
+os.environ.setdefault('RVT_LSTM_SCAN', '1')
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

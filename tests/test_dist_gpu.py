@@ -31,8 +31,9 @@ def grads(reducer):
 red = StageGradReducer(force=True)           # run the RCCL all-reduce even though world_size == 1
 a = grads(red)
 b = grads(None)
-for n in a:
-    assert torch.equal(a[n], b[n]), n        # mean over one rank == identity
+for n in a:                                   # mean over one rank == identity (up to the order of the fp32 atomics that
+    err = float((a[n] - b[n]).abs().max()) / max(float(b[n].abs().max()), 1e-30)      # fold the LayerNorm gradients)
+    assert err < 1e-4, (n, err)
 assert len(red._pending) == 0
 dist.destroy_process_group()
 print('NCCL_OK')
