@@ -142,19 +142,22 @@ template <class T> __device__ __forceinline__ frag_t<T> tile_load_frag(const cha
 // [token][feature] LDS tile into MFMA operands whose contraction index is the TOKEN (in-kernel weight gradients,
 // products with W^T from a single LDS image of W): see load_frag_tr below.
 typedef __attribute__((ext_vector_type(4))) short s16x4;
-__device__ __forceinline__ void tr_read4(const bf16* p, bf16 (&o)[4]) {
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+__device__ __forceinline__ s16x4 tr_read4(const bf16* p) {
 #ifdef RVT_EMU
     auto buf = emu::exchange(&p, sizeof(p));
     const int lane = emu::g.cur->lane, grp = lane & ~15, i = lane & 15;
+    s16x4 o;
     for (int k = 0; k < 4; k++) {
         const bf16* q;
         memcpy(&q, buf[grp + 4 * k + (i >> 2)], sizeof(q));
-        o[k] = q[i & 3];
+        short h;
+        memcpy(&h, q + (i & 3), 2);
+        o[k] = h;
     }
+    return o;
 #else
-    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
-#pragma unroll
-    for (int k = 0; k < 4; k++) { const short h = v[k]; o[k] = *reinterpret_cast<const bf16*>(&h); }
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
 #endif
 }
 // Transposed operand fragment: f[e] = X[tok0 + 8*(lane>>5) + e][feat0 + (lane&31)], e = 0..7, i.e. the A/B fragment of
@@ -162,19 +165,26 @@ __device__ __forceinline__ void tr_read4(const bf16* p, bf16 (&o)[4]) {
 // returns the LDS address of element (tok, feat); 4 consecutive features starting at a multiple of 4 must be contiguous
 // there (true for every swizzled tile in this directory: the swizzle moves whole 16-byte chunks).
 template <class T, class At> __device__ __forceinline__ frag_t<T> load_frag_tr(const At& at, int tok0, int feat0, int lane) {
-    frag_t<T> f;
     if constexpr (sizeof(T) == 2) {
-#pragma unroll
-        for (int r = 0; r < 2; r++) {
-            bf16 o[4];
-            tr_read4(at(tok0 + 8 * (lane >> 5) + 4 * r + ((lane & 15) >> 2), feat0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3)), o);
-#pragma unroll
-            for (int k = 0; k < 4; k++) f[4 * r + k] = o[k];
-        }
+        const int tl = 8 * (lane >> 5) + ((lane & 15) >> 2), fl = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+        const s16x4 lo = tr_read4(at(tok0 + tl, feat0 + fl)), hi = tr_read4(at(tok0 + tl + 4, feat0 + fl));
+        const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        frag_t<T> f;
+        __builtin_memcpy(&f, &v, 16);
+        return f;
     } else {            // f32 parity mode: no 32-bit transpose read; eight scalar LDS reads
+        frag_t<T> f;
 #pragma unroll
         for (int e = 0; e < 8; e++) f[e] = *at(tok0 + 8 * (lane >> 5) + e, feat0 + (lane & 31));
+        return f;
     }
+}
+// the two per-lane addresses of load_frag_tr when the caller wants to hoist them out of a loop
+template <class T> __device__ __forceinline__ frag_t<T> frag_from_tr(const bf16* p_lo, const bf16* p_hi) {
+    const s16x4 lo = tr_read4(p_lo), hi = tr_read4(p_hi);
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    frag_t<T> f;
+    __builtin_memcpy(&f, &v, 16);
     return f;
 }
 
@@ -277,13 +287,18 @@ __device__ __forceinline__ void gelu_both_8(const float (&x)[8], float (&g)[8], 
         gp[i] = dd[0]; gp[i + 1] = dd[1];
     }
 }
-__device__ __forceinline__ float sigmoid_f(float x) { return fast_rcp(1.0f + __expf(-x)); }
+// sigmoid / tanh of the ConvLSTM gates (rnn.py:57-67) on the hardware exp2 / rcp: 4 and 5 instructions.
+//   sigmoid(x) = 1 / (1 + 2^(-x log2 e));   tanh(x) = 1 - 2 / (1 + 2^(2 x log2 e))   (saturates to -1 / +1 through 2^-inf = 0
+//   and 1/inf = 0; absolute error ~1e-7 like the (1-e)/(1+e) form it replaces — both cancel near 0, where |tanh| is tiny)
+__device__ __forceinline__ float sigmoid_f(float x) { return fast_rcp(1.0f + fast_exp2(x * -1.4426950408889634f)); }
 __device__ __forceinline__ float tanh_f(float x) {
-    // tanh via exp; saturates correctly for large |x|
-    const float ax = fabsf(x);
-    const float e = __expf(-2.0f * ax);
-    const float t = (1.0f - e) * fast_rcp(1.0f + e);
-    return x < 0.0f ? -t : t;
+    return fmaf(-2.0f, fast_rcp(1.0f + fast_exp2(x * 2.8853900817779268f)), 1.0f);
+}
+// gate pre-activation z + bias folded into the exp2 argument: sigmoid(z + b) with nb = -b log2 e, tanh(z + b) with
+// tb = 2 b log2 e (one fma instead of add + mul)
+__device__ __forceinline__ float sigmoid_zb(float z, float nb) { return fast_rcp(1.0f + fast_exp2(fmaf(z, -1.4426950408889634f, nb))); }
+__device__ __forceinline__ float tanh_zb(float z, float tb) {
+    return fmaf(-2.0f, fast_rcp(1.0f + fast_exp2(fmaf(z, 2.8853900817779268f, tb))), 1.0f);
 }
 
 // ---- error plumbing for the C ABI ------------------------------------------------------------------

@@ -616,10 +616,10 @@ template <class T> struct EpLstm {
         const float cp[8] = {aux.c0[0], aux.c0[1], aux.c0[2], aux.c0[3], aux.c1[0], aux.c1[1], aux.c1[2], aux.c1[3]};
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            f[i] = sigmoid_f(v[i] + b.v[i]);
-            ig[i] = sigmoid_f(v[8 + i] + b.v[8 + i]);
-            o[i] = sigmoid_f(v[16 + i] + b.v[16 + i]);
-            g[i] = tanh_f(v[24 + i] + b.v[24 + i]);
+            f[i] = sigmoid_zb(v[i], b.v[i] * -1.4426950408889634f);          // (same forms as the scan kernels: csrc/lstm_scan.hpp)
+            ig[i] = sigmoid_zb(v[8 + i], b.v[8 + i] * -1.4426950408889634f);
+            o[i] = sigmoid_zb(v[16 + i], b.v[16 + i] * -1.4426950408889634f);
+            g[i] = tanh_zb(v[24 + i], b.v[24 + i] * 2.8853900817779268f);
             cn[i] = f[i] * cp[i] + ig[i] * g[i];
             hn[i] = o[i] * tanh_f(cn[i]);
         }

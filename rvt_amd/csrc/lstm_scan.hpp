@@ -32,6 +32,16 @@ template <class T> __device__ __forceinline__ frag_t<T> opm_load_frag(const char
     return tile_load_frag<T>(base + (size_t)(fcg / FPR) * rows * 128, row, fcg % FPR);
 }
 
+// LDS byte offset of element (R0 + rowc(r), ch) of a swizzled tile, r = accumulator register index of the 32x32 MFMA C/D
+// layout, GIVEN the offset `base` of element (R0, ch) with R0 = 32*w + 4*(lane>>5): rowc(r) = (r&3) + 8*(r>>2) never
+// carries out of the low five row bits, so the two swizzle terms of lds_chunk_off split into a per-lane part (already in
+// `base`) XOR a function of r alone:  ((row>>1)&7) -> ((r>>1)&1) | ((r>>2)&1)<<2,  ((row>>4)&7) -> (r>>3).
+// One v_xor plus an immediate offset per access instead of a dozen integer ops, and ONE register instead of sixteen.
+__device__ __forceinline__ int acc_elem_off(int base, int r) {
+    const int k = (((r >> 1) & 1) | (((r >> 2) & 1) << 2)) ^ ((r >> 3) & 1);
+    return (base ^ (k << 4)) + ((r & 3) + 8 * (r >> 2)) * 128;
+}
+
 template <class T, int C, int NW> struct LstmScanGeom {
     static constexpr int NT = 64 * NW;
     static constexpr int NWC = C / 32;                     // channel groups of 32 = waves along the channel axis
@@ -114,9 +124,14 @@ lstm_scan_fwd_kernel(const T* __restrict__ x_all, T* __restrict__ Hall, const fl
             else opm_store_frag<T>(Wh, 4 * C, n, g8 - G, v);
         }
     }
-    float bz[4];
+    // gate biases folded into the exp2 arguments; LDS byte offsets of this lane's 16 (row, channel) elements per row block
+    // (fixed for the launch: computing the swizzle per element per step costs more VALU than the gate math itself)
+    const float nbf = bias[ch] * -1.4426950408889634f, nbi = bias[C + ch] * -1.4426950408889634f;
+    const float nbo = bias[2 * C + ch] * -1.4426950408889634f, tbg = bias[3 * C + ch] * 2.8853900817779268f;
+    int off0[RB];
 #pragma unroll
-    for (int g = 0; g < 4; g++) bz[g] = bias[g * C + ch];
+    for (int i = 0; i < RB; i++)
+        off0[i] = (int)(reinterpret_cast<char*>(opm_elem_ptr<T>(Ax, TM, (wm * RB + i) * 32 + 4 * half, ch)) - Ax);
 
     const int n_tiles = (M + TM - 1) / TM;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -176,16 +191,15 @@ lstm_scan_fwd_kernel(const T* __restrict__ x_all, T* __restrict__ Hall, const fl
             for (int i = 0; i < RB; i++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
-                    const float f = sigmoid_f(acc[i][0][r] + bz[0]);
-                    const float ig = sigmoid_f(acc[i][1][r] + bz[1]);
-                    const float o = sigmoid_f(acc[i][2][r] + bz[2]);
-                    const float g = tanh_f(acc[i][3][r] + bz[3]);
+                    const float f = sigmoid_zb(acc[i][0][r], nbf);
+                    const float ig = sigmoid_zb(acc[i][1][r], nbi);
+                    const float o = sigmoid_zb(acc[i][2][r], nbo);
+                    const float g = tanh_zb(acc[i][3][r], tbg);
                     const float cn = f * creg[i][r] + ig * g;
                     creg[i][r] = cn;
                     const float hn = o * tanh_f(cn);
-                    const int row = (wm * RB + i) * 32 + acc_row(r, lane);
-                    *opm_elem_ptr<T>(An, TM, row, ch) = (T)hn;
-                    if (Csave != nullptr) *opm_elem_ptr<T>(Cs, TM, row, ch) = (T)cn;
+                    *reinterpret_cast<T*>(An + acc_elem_off(off0[i], r)) = (T)hn;
+                    if (Csave != nullptr) *reinterpret_cast<T*>(Cs + acc_elem_off(off0[i], r)) = (T)cn;
                 }
             lds_barrier();                                 // h_t / c_t tiles complete; every wave is done with Ax
             {                                              // tile rows -> HBM in 16-byte pieces
@@ -258,9 +272,23 @@ lstm_scan_bwd_kernel(const T* __restrict__ x_all, const T* __restrict__ Hall, co
             else opm_store_frag<T>(Wh, 4 * C, n, g8 - G, v);
         }
     }
-    float bz[4];
-#pragma unroll
-    for (int g = 0; g < 4; g++) bz[g] = bias[g * C + ch];
+    const float nbf = bias[ch] * -1.4426950408889634f, nbi = bias[C + ch] * -1.4426950408889634f;
+    const float nbo = bias[2 * C + ch] * -1.4426950408889634f, tbg = bias[3 * C + ch] * 2.8853900817779268f;
+    // LDS byte offsets (fixed for the launch) of this lane's 16 (row, channel) elements in a [TM][C] tile, and the map from
+    // there to element (row, g*C + channel) of the [TM][4C] dz operand
+    const int off0 = (int)(reinterpret_cast<char*>(opm_elem_ptr<T>(Ax, TM, wm * 32 + 4 * half, ch)) - Ax);
+    auto dz_off = [&](int g, int r) -> int {
+        if constexpr (C % BK == 0) return g * KTC * TM * 128 + acc_elem_off(off0, r);    // gate g = K-subtiles g*KTC ..
+        else return (g / (BK / C)) * TM * 128 + acc_elem_off(off0 ^ ((g % (BK / C)) * C * (int)sizeof(T)), r);   // several gates per subtile
+    };
+    // transpose-read addresses of the W^T fragments (rows n = kc + tl (+4), columns j = wn*32 + fl): everything but the
+    // k-step is per-lane constant; the swizzle term of the k-step is (kc >> 4) & 7
+    const int tr_tl = 8 * (lane >> 5) + ((lane & 15) >> 2);
+    const int tr_col = wn * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    const int tr_sub = (tr_col / BK) * (4 * C) * 128;
+    const int tr_byte = (tr_col % BK) * (int)sizeof(T);
+    const int tr_row_lo = tr_sub + tr_tl * 128 + (tr_byte & 15), tr_row_hi = tr_row_lo + 4 * 128;
+    const int tr_c_lo = (tr_byte >> 4) ^ ((tr_tl >> 1) & 7), tr_c_hi = (tr_byte >> 4) ^ (((tr_tl + 4) >> 1) & 7);
 
     // c_{t-1} as a T fragment tile: slot t-1 of Csave, or the incoming fp32 state for t = 0
     auto load_cprev = [&](frag_t<T> (&r)[NFX], int t, int m0) {
@@ -333,19 +361,18 @@ lstm_scan_bwd_kernel(const T* __restrict__ x_all, const T* __restrict__ Hall, co
             // ---- gate backward (autograd of rnn.py:57-67) in registers; dz -> LDS as the next product's A operand ----
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int row = wm * 32 + acc_row(r, lane);
-                const float f = sigmoid_f(acc[0][r] + bz[0]);
-                const float ig = sigmoid_f(acc[1][r] + bz[1]);
-                const float o = sigmoid_f(acc[2][r] + bz[2]);
-                const float g = tanh_f(acc[3][r] + bz[3]);
-                const float cp = (float)*opm_elem_ptr<T>(Sc, TM, row, ch);
-                const float dh = (float)*opm_elem_ptr<T>(Sd, TM, row, ch) + dh_rec[r];
+                const float f = sigmoid_zb(acc[0][r], nbf);
+                const float ig = sigmoid_zb(acc[1][r], nbi);
+                const float o = sigmoid_zb(acc[2][r], nbo);
+                const float g = tanh_zb(acc[3][r], tbg);
+                const float cp = (float)*reinterpret_cast<const T*>(Sc + acc_elem_off(off0, r));
+                const float dh = (float)*reinterpret_cast<const T*>(Sd + acc_elem_off(off0, r)) + dh_rec[r];
                 const float tc = tanh_f(f * cp + ig * g);
                 const float dc = dc_rec[r] + dh * o * (1.f - tc * tc);
-                *opm_elem_ptr<T>(Adz, TM, row, 0 * C + ch) = (T)(dc * cp * f * (1.f - f));
-                *opm_elem_ptr<T>(Adz, TM, row, 1 * C + ch) = (T)(dc * g * ig * (1.f - ig));
-                *opm_elem_ptr<T>(Adz, TM, row, 2 * C + ch) = (T)(dh * tc * o * (1.f - o));
-                *opm_elem_ptr<T>(Adz, TM, row, 3 * C + ch) = (T)(dc * ig * (1.f - g * g));
+                *reinterpret_cast<T*>(Adz + dz_off(0, r)) = (T)(dc * cp * f * (1.f - f));
+                *reinterpret_cast<T*>(Adz + dz_off(1, r)) = (T)(dc * g * ig * (1.f - ig));
+                *reinterpret_cast<T*>(Adz + dz_off(2, r)) = (T)(dh * tc * o * (1.f - o));
+                *reinterpret_cast<T*>(Adz + dz_off(3, r)) = (T)(dc * ig * (1.f - g * g));
                 dc_rec[r] = dc * f;
             }
             lds_barrier();                                 // dz tile complete; Ax/Ah/Sc/Sd of step t consumed
@@ -360,9 +387,15 @@ lstm_scan_bwd_kernel(const T* __restrict__ x_all, const T* __restrict__ Hall, co
                 for (int part = 0; part < 2; part++) {
                     frag_t<T> b;
                     if (W_LDS) {       // B[j][n] = W[n][j]: transposed fragments of the LDS image of W (rows n, columns j)
-                        char* const Wl = part ? Wh : Wx;
-                        auto at = [&](int n, int j) -> const T* { return opm_elem_ptr<T>(Wl, 4 * C, n, j); };
-                        b = load_frag_tr<T>(at, kc, wn * 32, lane);
+                        const char* const Wl = part ? Wh : Wx;
+                        if constexpr (sizeof(T) == 2) {
+                            const int u = (kc >> 4) & 7;
+                            b = frag_from_tr<T>(reinterpret_cast<const bf16*>(Wl + kc * 128 + tr_row_lo + ((tr_c_lo ^ u) << 4)),
+                                                reinterpret_cast<const bf16*>(Wl + kc * 128 + tr_row_hi + ((tr_c_hi ^ u) << 4)));
+                        } else {
+                            auto at = [&](int n, int j) -> const T* { return opm_elem_ptr<T>(const_cast<char*>(Wl), 4 * C, n, j); };
+                            b = load_frag_tr<T>(at, kc, wn * 32, lane);
+                        }
                     } else {
                         b = frag_load<T>(Wt + (size_t)(part * C + ch) * 4 * C + kc + half * 8);
                     }
@@ -371,8 +404,7 @@ lstm_scan_bwd_kernel(const T* __restrict__ x_all, const T* __restrict__ Hall, co
             }
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int row = wm * 32 + acc_row(r, lane);
-                *opm_elem_ptr<T>(Sx, TM, row, ch) = (T)acc2[0][r];
+                *reinterpret_cast<T*>(Sx + acc_elem_off(off0, r)) = (T)acc2[0][r];
                 dh_rec[r] = acc2[1][r];
             }
             lds_barrier();                                 // dx tile complete; dz reads done

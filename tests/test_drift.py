@@ -9,10 +9,11 @@ from rvt_amd import RNNDetector, backbone_config
 
 pytestmark = pytest.mark.gpu
 
-# measured on MI355X (profiles/r2_drift.txt): worst per-step feature drift 1.1e-2 of the tensor scale, flat in t (the LSTM
-# gates are contractive); gradients 2.5e-2 of their l2 norm.  Bounds = ~2x the measurement.
-FEATURE_BOUND = 2.5e-2
-GRAD_BOUND = 5e-2
+# measured on MI355X (profiles/r2_drift.txt): worst per-step feature drift 2.1e-2 of the tensor scale (stages 3-4), flat in
+# t after the first few steps (the LSTM gates are contractive: no growth over 21 recurrent steps); final cell states 9.5e-3;
+# parameter gradients 1.35e-2 of their l2 norm.  Bounds = ~2x the measurement.
+FEATURE_BOUND = 4e-2
+GRAD_BOUND = 3e-2
 
 
 def test_bf16_drift_over_21_steps():
