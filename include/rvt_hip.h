@@ -97,6 +97,18 @@ int rvt_mlp_bwd_dgrad(const void* dxout, const void* gp, const void* xmid, void*
                       const void* w2g_t, const void* w1_t, float* dln_w, float* dln_b, int dtype, int M, int C, float eps,
                       void* stream);
 
+/* Backward of the MLP half with NOTHING but the block input saved (rvt_mlp_bwd_fused_supported: C == 64): LN2, fc1, GELU
+ * and GELU' are recomputed on chip, and besides dxmid = dxout + LN2'(...) the kernel accumulates the weight gradients in
+ * registers across its persistent tile walk:  dw1[4C][C] += dh^T LN2(xmid),  db1[4C] += colsum(dh),
+ * s2[C][4C] += dxout^T GELU(h),  cs2[C] += colsum(dxout)  (s2 / cs2 are the RAW fc2 products: LayerScale is folded in by
+ * rvt_layerscale_grad_table),  dln_w / dln_b += LayerNorm parameter gradients.  w1 [4C][C]; w2g_t = (W2*gamma[:,None])^T
+ * [4C][C]; w1_t = W1^T [C][4C].  ws: rvt_mlp_bwd_fused_ws_floats(dtype, C, M) floats (per-workgroup partials). */
+int rvt_mlp_bwd_fused_supported(int dtype, int C);
+size_t rvt_mlp_bwd_fused_ws_floats(int dtype, int C, int M);
+int rvt_mlp_bwd_fused(const void* dxout, const void* xmid, void* dxmid, const float* ln_w, const float* ln_b, const void* w1,
+                      const float* b1, const void* w2g_t, const void* w1_t, float* dln_w, float* dln_b, float* dw1, float* db1,
+                      float* s2, float* cs2, float* ws, int dtype, int M, int C, float eps, void* stream);
+
 /* Partitioned multi-head attention core (maxvit.py:252-265,273-304,343-354 minus the two linears):
  * qkv [F*H*W][3C] in image token order, per-head layout [q|k|v]; out [F*H*W][C].  window=1: ph x pw
  * windows; window=0: dilated grid with grid size (ph,pw). */

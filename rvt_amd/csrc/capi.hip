@@ -433,6 +433,48 @@ int rvt_mlp_bwd_dgrad(const void* dxout, const void* gp, const void* xmid, void*
     return check_launch("mlp_bwd_dgrad");
 }
 
+// Everything-on-chip backward of the MLP half (csrc/mlp.hpp, mlp_bwd_fused_kernel): input gradient, LayerNorm backward
+// and the weight gradients from (dxout, xmid) alone.  Built where the whole set of weight-gradient accumulators fits
+// the register file of one workgroup: C == 64.
+int rvt_mlp_bwd_fused_supported(int dtype, int C) {
+    return (dtype == RVT_BF16 || dtype == RVT_F32) && C == 64;
+}
+}  // extern "C"
+template <class T> static int mlp_bwd_fused_grid(int M) {
+    return mlp_grid(mlp_bwd_fused_kernel<T, 64>, M, 64);
+}
+extern "C" {
+size_t rvt_mlp_bwd_fused_ws_floats(int dtype, int C, int M) {
+    if (!rvt_mlp_bwd_fused_supported(dtype, C)) return 0;
+    const size_t grid = dtype == RVT_BF16 ? mlp_bwd_fused_grid<bf16>(M) : mlp_bwd_fused_grid<float>(M);
+    return grid * ((size_t)2 * 4 * C * C + 2 * 4 * C + C);
+}
+
+int rvt_mlp_bwd_fused(const void* dxout, const void* xmid, void* dxmid, const float* ln_w, const float* ln_b, const void* w1,
+                      const float* b1, const void* w2g_t, const void* w1_t, float* dln_w, float* dln_b, float* dw1, float* db1,
+                      float* s2, float* cs2, float* ws, int dtype, int M, int C, float eps, void* stream) {
+    RVT_CHECK(rvt_mlp_bwd_fused_supported(dtype, C), "mlp_bwd_fused: not built for dtype=%d C=%d", dtype, C);
+    RVT_CHECK(ws != nullptr && M >= 1, "mlp_bwd_fused: workspace required");
+    hipStream_t st = (hipStream_t)stream;
+    int grid = 0;
+    DISPATCH_DTYPE(dtype, {
+        grid = mlp_bwd_fused_grid<T>(M);
+        hipLaunchKernelGGL((mlp_bwd_fused_kernel<T, 64>), dim3(grid), dim3(256), 0, st, (const T*)dxout, (const T*)xmid, (T*)dxmid,
+                           ln_w, ln_b, (const T*)w1, b1, (const T*)w2g_t, (const T*)w1_t, dln_w, dln_b, ws, M, eps);
+    });
+    // fold the per-workgroup partials (plain stores above; device-scope float atomics are memory-side on this part)
+    const size_t wc = (size_t)4 * C * C;
+    const float* p = ws;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for(wc, 1024)), dim3(256), 0, st, p, dw1, grid, wc, 0);
+    p += (size_t)grid * wc;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for(wc, 1024)), dim3(256), 0, st, p, s2, grid, wc, 0);
+    p += (size_t)grid * wc;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for((size_t)4 * C, 64)), dim3(256), 0, st, p, db1, 2 * grid, (size_t)4 * C, 0);
+    p += (size_t)2 * grid * 4 * C;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for((size_t)C, 64)), dim3(256), 0, st, p, cs2, grid, (size_t)C, 0);
+    return check_launch("mlp_bwd_fused");
+}
+
 // ----------------------------------------------------------------------------------------- attention
 static int make_attn_geom(AttnGeom& g, int F, int H, int W, int C, int dh, int ph, int pw, int window) {
     RVT_CHECK(C % 8 == 0 && dh % 8 == 0 && dh <= 32 && C % dh == 0, "attn: bad C=%d dim_head=%d", C, dh);

@@ -188,6 +188,40 @@ template <class T> __device__ __forceinline__ frag_t<T> frag_from_tr(const bf16*
     return f;
 }
 
+// Hoisted addressing of load_frag_tr for a swizzled LDS operand matrix (K-subtiles of [rows][128 B]) and ONE block of 32
+// features starting at feat0: everything but the token step is a per-lane constant, and for tok0 a multiple of 16 the two
+// swizzle terms of lds_chunk_off reduce to a per-lane part XOR (tok0 >> 4) & 7.  bf16: two ds_read_b64_tr_b16 and three
+// integer ops per fragment; f32 (parity mode): the generic eight scalar reads.
+template <class T> struct TrFeat {
+    int row_lo, c_lo, c_hi, feat0_, rows_;
+    __device__ __forceinline__ void init(int feat0, int rows, int lane) {
+        feat0_ = feat0; rows_ = rows;
+        constexpr int BK = TileGeom<T>::BK;
+        const int tl = 8 * (lane >> 5) + ((lane & 15) >> 2);
+        const int col = feat0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+        const int byte = (col % BK) * (int)sizeof(T);
+        row_lo = (col / BK) * rows * 128 + tl * 128 + (byte & 15);
+        c_lo = (byte >> 4) ^ ((tl >> 1) & 7);
+        c_hi = (byte >> 4) ^ (((tl + 4) >> 1) & 7);
+    }
+    __device__ __forceinline__ frag_t<T> load(const char* tile, int tok0, int lane) const {
+        if constexpr (sizeof(T) == 2) {
+            const int u = (tok0 >> 4) & 7;
+            const char* const b = tile + tok0 * 128 + row_lo;
+            return frag_from_tr<T>(reinterpret_cast<const bf16*>(b + ((c_lo ^ u) << 4)),
+                                   reinterpret_cast<const bf16*>(b + 512 + ((c_hi ^ u) << 4)));
+        } else {
+            constexpr int BK = TileGeom<T>::BK;
+            const int rows = rows_;
+            auto at = [&](int tok, int feat) -> const T* {
+                const int byte = (feat % BK) * (int)sizeof(T);
+                return reinterpret_cast<const T*>(tile + (size_t)(feat / BK) * rows * 128 + lds_chunk_off(tok, byte >> 4) + (byte & 15));
+            };
+            return load_frag_tr<T>(at, tok0, feat0_, lane);
+        }
+    }
+};
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also fences global memory: hipcc emits
 // `s_waitcnt vmcnt(0)` in front of the barrier, i.e. every wave waits until its outstanding global STORES are
 // acknowledged (CDNA counts stores on vmcnt).  In these kernels barriers only protect LDS tiles / staging buffers —

@@ -20,28 +20,6 @@
 
 namespace rvt {
 
-// address of element (row, kcol) of an LDS operand matrix [rows][K] (K-subtiles of [rows][128 B], swizzled 16-B chunks)
-template <class T> __device__ __forceinline__ T* opm_elem_ptr(char* base, int rows, int row, int kcol) {
-    constexpr int BK = TileGeom<T>::BK;
-    const int kt = kcol / BK, kc = kcol % BK;
-    const int byte = kc * (int)sizeof(T);
-    return reinterpret_cast<T*>(base + (size_t)kt * rows * 128 + lds_chunk_off(row, byte >> 4) + (byte & 15));
-}
-template <class T> __device__ __forceinline__ frag_t<T> opm_load_frag(const char* base, int rows, int row, int fcg) {
-    constexpr int FPR = TileGeom<T>::FPR;
-    return tile_load_frag<T>(base + (size_t)(fcg / FPR) * rows * 128, row, fcg % FPR);
-}
-
-// LDS byte offset of element (R0 + rowc(r), ch) of a swizzled tile, r = accumulator register index of the 32x32 MFMA C/D
-// layout, GIVEN the offset `base` of element (R0, ch) with R0 = 32*w + 4*(lane>>5): rowc(r) = (r&3) + 8*(r>>2) never
-// carries out of the low five row bits, so the two swizzle terms of lds_chunk_off split into a per-lane part (already in
-// `base`) XOR a function of r alone:  ((row>>1)&7) -> ((r>>1)&1) | ((r>>2)&1)<<2,  ((row>>4)&7) -> (r>>3).
-// One v_xor plus an immediate offset per access instead of a dozen integer ops, and ONE register instead of sixteen.
-__device__ __forceinline__ int acc_elem_off(int base, int r) {
-    const int k = (((r >> 1) & 1) | (((r >> 2) & 1) << 2)) ^ ((r >> 3) & 1);
-    return (base ^ (k << 4)) + ((r & 3) + 8 * (r >> 2)) * 128;
-}
-
 template <class T, int C, int NW> struct LstmScanGeom {
     static constexpr int NT = 64 * NW;
     static constexpr int NWC = C / 32;                     // channel groups of 32 = waves along the channel axis

@@ -34,6 +34,28 @@ template <class T> __device__ __forceinline__ void opm_store_frag(char* base, in
     tile_store_frag<T>(opm_subtile<T>(base, rows, fcg / FPR), row, fcg % FPR, v);
 }
 
+// address of element (row, kcol) of an LDS operand matrix [rows][K] (K-subtiles of [rows][128 B], swizzled 16-B chunks)
+template <class T> __device__ __forceinline__ T* opm_elem_ptr(char* base, int rows, int row, int kcol) {
+    constexpr int BK = TileGeom<T>::BK;
+    const int kt = kcol / BK, kc = kcol % BK;
+    const int byte = kc * (int)sizeof(T);
+    return reinterpret_cast<T*>(base + (size_t)kt * rows * 128 + lds_chunk_off(row, byte >> 4) + (byte & 15));
+}
+template <class T> __device__ __forceinline__ frag_t<T> opm_load_frag(const char* base, int rows, int row, int fcg) {
+    constexpr int FPR = TileGeom<T>::FPR;
+    return tile_load_frag<T>(base + (size_t)(fcg / FPR) * rows * 128, row, fcg % FPR);
+}
+
+// LDS byte offset of element (R0 + rowc(r), ch) of a swizzled tile, r = accumulator register index of the 32x32 MFMA C/D
+// layout, GIVEN the offset `base` of element (R0, ch) with R0 = 32*w + 4*(lane>>5): rowc(r) = (r&3) + 8*(r>>2) never
+// carries out of the low five row bits, so the two swizzle terms of lds_chunk_off split into a per-lane part (already in
+// `base`) XOR a function of r alone:  ((row>>1)&7) -> ((r>>1)&1) | ((r>>2)&1)<<2,  ((row>>4)&7) -> (r>>3).
+// One v_xor plus an immediate offset per access instead of a dozen integer ops, and ONE register instead of sixteen.
+__device__ __forceinline__ int acc_elem_off(int base, int r) {
+    const int k = (((r >> 1) & 1) | (((r >> 2) & 1) << 2)) ^ ((r >> 3) & 1);
+    return (base ^ (k << 4)) + ((r & 3) + 8 * (r >> 2)) * 128;
+}
+
 // stage a row-major global block [rows][kcols] (leading dimension ld elements) into an operand matrix; all 256 threads
 template <class T> __device__ __forceinline__ void opm_stage(char* base, const T* g, int ld, int rows, int kcols, int tid) {
     const int fpr_g = kcols / 8;
@@ -553,6 +575,296 @@ mlp_bwd_dgrad_kernel(const T* __restrict__ dxout, const T* __restrict__ gp, cons
             for (int t = tid; t < 256; t += G) { sw += red[t * 16 + e]; sb += red[t * 16 + 8 + e]; }
             atomicAdd(dln_w + cl * 8 + e, sw);
             atomicAdd(dln_b + cl * 8 + e, sb);
+        }
+    }
+}
+
+
+// ====================================================================== backward, everything on chip (C = 64)
+// mlp_bwd_fused_kernel: the whole backward of the MLP half from (dxout, xmid) alone.  Nothing but the block input was
+// kept by the forward: LN2, fc1 and GELU / GELU' are RECOMPUTED per hidden chunk, the two input-gradient products and
+// the LayerNorm backward follow as in mlp_bwd_dgrad_kernel, and the weight gradients
+//     S2[c][j]  = sum_tok dxout[tok][c] g[tok][j]        (raw: LayerScale is folded in afterwards, pack.hpp)
+//     dW1[j][c] = sum_tok dh[tok][j] v2[tok][c],   db1[j] = sum_tok dh[tok][j],   cs2[c] = sum_tok dxout[tok][c]
+// are accumulated IN REGISTERS across all the tiles a persistent workgroup walks (the contraction index is the token:
+// both operands come out of the row-major LDS tiles through the transpose read) and leave as one partial per workgroup.
+// HBM traffic per token: read dxout + xmid, write dxmid — 3 rows of C instead of 5 + 11 + 5 + 5 for the separate
+// input-gradient kernel and the two weight-gradient GEMMs (which re-read g, dh, v2 that the forward had to store).
+// Accumulator-layout trick: fc1 (recomputed) and the fc2 input gradient use the SAME wave tiling, so h and dg of a
+// (token, hidden column) meet in one lane at one accumulator index: GELU' * dg needs no staging, g and dh go to LDS
+// as the next products' operands with 2-byte stores at analytic offsets (acc_elem_off).
+template <class T, int C> struct MlpFusedSmem {
+    static constexpr int TM = 64, JC = 64;
+    static constexpr int KT_C = C / TileGeom<T>::BK, KT_J = JC / TileGeom<T>::BK;
+    static constexpr int T_C = KT_C * TM * 128;           // [TM][C]
+    static constexpr int T_J = KT_J * TM * 128;           // [TM][JC]
+    static constexpr int P_1 = KT_C * JC * 128;           // [JC][C] weight panel
+    static constexpr int P_2 = KT_J * C * 128;            // [C][JC] weight panel
+    static constexpr int OFF_AX = 0, OFF_AV = T_C, OFF_B0 = 2 * T_C, OFF_B1 = OFF_B0 + P_1, OFF_B2 = OFF_B1 + P_1;
+    static constexpr int OFF_AG = OFF_B2 + P_2, OFF_AH = OFF_AG + T_J, OFF_K = OFF_AH + T_J;
+    static constexpr int STG = 64 * (C + 4) * 4;          // final fp32 staging, overlays the three weight panels
+    static_assert(STG <= 2 * P_1 + P_2 + 2 * T_J, "staging overlay");
+    static constexpr int BYTES = OFF_K + (2 * C + 4 * C) * 4;
+    static_assert(BYTES <= 160 * 1024, "LDS");
+};
+
+template <class T, int C>
+__global__ void __launch_bounds__(256, 1)      // 128 accumulator registers of weight gradients: one workgroup per CU, no spills
+mlp_bwd_fused_kernel(const T* __restrict__ dxout, const T* __restrict__ xmid, T* __restrict__ dxmid,
+                     const float* __restrict__ ln_w, const float* __restrict__ ln_b, const T* __restrict__ W1,
+                     const float* __restrict__ b1, const T* __restrict__ W2gT, const T* __restrict__ W1T,
+                     float* __restrict__ dln_w, float* __restrict__ dln_b, float* __restrict__ ws, int M, float eps) {
+    typedef MlpFusedSmem<T, C> S;
+    constexpr int TM = S::TM, JC = S::JC, HID = 4 * C, NCH = HID / JC;
+    constexpr int G = C / 8, NFX = TM * G / 256;
+    constexpr int F1 = C / 8, F2 = JC / 8, N1 = JC * F1 / 256, N2 = C * F2 / 256;
+    constexpr int LD2 = C + 4;
+    static_assert(C == 64 && JC == 64 && TM == 64, "wave tiling below is 2x2 waves of 32x32 for 64x64 products");
+    __shared__ __attribute__((aligned(16))) char smem[S::BYTES];
+    char* const Ax = smem + S::OFF_AX;      // dxout tile
+    char* const Av = smem + S::OFF_AV;      // LN2(xmid) tile
+    char* const B0 = smem + S::OFF_B0;      // W1 rows j0..        [JC][C]   (fc1 recompute)
+    char* const B1 = smem + S::OFF_B1;      // (W2 gamma)^T rows j0.. [JC][C] (fc2 input gradient)
+    char* const B2 = smem + S::OFF_B2;      // W1^T[:, j0..]       [C][JC]   (fc1 input gradient)
+    char* const Ag = smem + S::OFF_AG;      // g = GELU(h) chunk
+    char* const Ah = smem + S::OFF_AH;      // dh chunk
+    float* const stage = reinterpret_cast<float*>(smem + S::OFF_B0);
+    float* const kst = reinterpret_cast<float*>(smem + S::OFF_K);
+    const float* const k_lnw = kst, * const k_lnb = kst + C, * const k_b1 = kst + 2 * C;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, half = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n_tiles = (M + TM - 1) / TM;
+    const int cl = tid % G;
+    for (int i = tid; i < C; i += 256) { kst[i] = ln_w[i]; kst[C + i] = ln_b[i]; }
+    for (int i = tid; i < HID; i += 256) kst[2 * C + i] = b1[i];
+    __syncthreads();
+
+    // persistent accumulators (whole launch): weight gradients per hidden chunk in the MFMA C/D layout, db1 per lane
+    // column, LayerNorm parameter gradients and cs2 per (thread, 8-channel chunk)
+    f32x16 dW2acc[NCH], dW1acc[NCH];
+    float db1acc[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) { acc_zero(dW2acc[c]); acc_zero(dW1acc[c]); db1acc[c] = 0.f; }
+    float aw[8], ab[8], acs[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) { aw[e] = 0.f; ab[e] = 0.f; acs[e] = 0.f; }
+
+    // accumulator-layout LDS offset of element (wm*32 + 4*half, wn*32 + li) of a [TM][JC] tile, and the transposed-fragment
+    // address constants of the feature blocks this wave contracts over tokens
+    const int off0 = (int)(reinterpret_cast<char*>(opm_elem_ptr<T>(Ag, TM, wm * 32 + 4 * half, wn * 32 + li)) - Ag);
+    TrFeat<T> trm, trn;
+    trm.init(wm * 32, TM, lane);
+    trn.init(wn * 32, TM, lane);
+
+    auto load_rows = [&](int tile, frag_t<T> (&rdx)[NFX], frag_t<T> (&rx)[NFX]) {
+#pragma unroll
+        for (int q = 0; q < NFX; q++) {
+            const int row = (tid + q * 256) / G;
+            const bool ok = tile * TM + row < M;
+            const size_t o = (size_t)(ok ? tile * TM + row : 0) * C + cl * 8;
+            rdx[q] = frag_load<T>(dxout + o);
+            rx[q] = frag_load<T>(xmid + o);
+        }
+    };
+    float mean[NFX], rstd[NFX];
+    // dxout tile -> A operand; LayerNorm of the xmid tile -> A operand of the fc1 recompute; column sums of dxout
+    auto stage_tile = [&](int tile, const frag_t<T> (&rdx)[NFX], const frag_t<T> (&rx)[NFX]) {
+#pragma unroll
+        for (int q = 0; q < NFX; q++) {
+            const int row = (tid + q * 256) / G;
+            const bool ok = tile * TM + row < M;
+            const frag_t<T> z = frag_zero<T>();
+            opm_store_frag<T>(Ax, TM, row, cl, ok ? rdx[q] : z);
+            float v[8], d[8];
+            frag_to_float<T>(rx[q], v);
+            frag_to_float<T>(rdx[q], d);
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; e++) { s += v[e]; acs[e] += ok ? d[e] : 0.f; }
+            mean[q] = group_sum(s, G) / (float)C;
+            float qq = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; e++) { const float dd = v[e] - mean[q]; qq += dd * dd; }
+            rstd[q] = 1.0f / sqrtf(group_sum(qq, G) / (float)C + eps);
+            float o[8], lnw[8], lnb[8];
+            load_cols<8>(k_lnw, cl * 8, lnw); load_cols<8>(k_lnb, cl * 8, lnb);
+#pragma unroll
+            for (int e = 0; e < 8; e++) o[e] = ok ? (v[e] - mean[q]) * rstd[q] * lnw[e] + lnb[e] : 0.f;
+            opm_store_frag<T>(Av, TM, row, cl, frag_from_float<T>(o));
+        }
+    };
+    struct Panels {                       // register image of one hidden chunk's three weight panels
+        frag_t<T> r0[N1], r1[N1], r2[N2];
+    };
+    auto load_panels = [&](Panels& p, int j0) {
+#pragma unroll
+        for (int i = 0; i < N1; i++) {
+            const int f = tid + i * 256;
+            p.r0[i] = frag_load<T>(W1 + (size_t)(j0 + f / F1) * C + (f % F1) * 8);
+            p.r1[i] = frag_load<T>(W2gT + (size_t)(j0 + f / F1) * C + (f % F1) * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < N2; i++) {
+            const int f = tid + i * 256;
+            p.r2[i] = frag_load<T>(W1T + (size_t)(f / F2) * HID + j0 + (f % F2) * 8);
+        }
+    };
+    auto store_panels = [&](const Panels& p) {
+#pragma unroll
+        for (int i = 0; i < N1; i++) {
+            const int f = tid + i * 256;
+            opm_store_frag<T>(B0, JC, f / F1, f % F1, p.r0[i]);
+            opm_store_frag<T>(B1, JC, f / F1, f % F1, p.r1[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < N2; i++) {
+            const int f = tid + i * 256;
+            opm_store_frag<T>(B2, C, f / F2, f % F2, p.r2[i]);
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < n_tiles) {
+        frag_t<T> rawdx[NFX], rawx[NFX], ndx[NFX], nx[NFX];
+        Panels wp;
+        load_rows(tile, rawdx, rawx);
+        load_panels(wp, 0);
+        stage_tile(tile, rawdx, rawx);
+        store_panels(wp);
+
+        for (; tile < n_tiles; tile += gridDim.x) {
+            const int m0 = tile * TM;
+            const int tile2 = tile + gridDim.x;
+            const bool have2 = tile2 < n_tiles;
+            constexpr bool PREFETCH_ROWS = sizeof(T) == 2;             // (f32 parity mode: registers)
+            if (PREFETCH_ROWS && have2) load_rows(tile2, ndx, nx);
+
+            f32x16 acc2[1][1];
+            acc_zero(acc2[0][0]);
+#pragma unroll
+            for (int ch = 0; ch < NCH; ch++) {
+                const int j0 = ch * JC;
+                const bool last = ch == NCH - 1;
+                lds_barrier();                                         // this chunk's panels and the tiles are in LDS
+                if (!last) load_panels(wp, j0 + JC);
+                else if (have2) load_panels(wp, 0);
+                const float b1c = k_b1[j0 + wn * 32 + li];
+                sched_fence();
+                // h = v2 W1_j^T (recomputed) and dg = dxout (W2 gamma)_j: same tiling -> same lane, same register
+                f32x16 acch[1][1], acc1[1][1];
+                acc_zero(acch[0][0]); acc_zero(acc1[0][0]);
+                opm_mma<T, 1, 1>(acch, Av, TM, wm * 32, B0, JC, wn * 32, C, lane);
+                opm_mma<T, 1, 1>(acc1, Ax, TM, wm * 32, B1, JC, wn * 32, C, lane);
+                float colsum = 0.f;
+#pragma unroll
+                for (int hb = 0; hb < 2; hb++) {
+                    float hv[8], gv[8], gpv[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e++) hv[e] = acch[0][0][hb * 8 + e] + b1c;
+                    gelu_both_8(hv, gv, gpv);
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        const int r = hb * 8 + e;
+                        const float dh = acc1[0][0][r] * gpv[e];
+                        colsum += dh;
+                        const int o = acc_elem_off(off0, r);
+                        *reinterpret_cast<T*>(Ag + o) = (T)gv[e];
+                        *reinterpret_cast<T*>(Ah + o) = (T)dh;
+                    }
+                }
+                db1acc[ch] += colsum;
+                lds_barrier();                                         // g / dh chunk complete; B0 / B1 consumed
+                opm_mma<T, 1, 1>(acc2, Ah, TM, wm * 32, B2, C, wn * 32, JC, lane);
+                // weight gradients: contraction over the TM tokens of the tile, operands transposed on the way out of LDS
+#pragma unroll
+                for (int k0 = 0; k0 < TM; k0 += 16) {
+                    mma32(dW2acc[ch], trm.load(Ax, k0, lane), trn.load(Ag, k0, lane));       // rows c, columns j
+                    mma32(dW1acc[ch], trm.load(Ah, k0, lane), trn.load(Av, k0, lane));       // rows j, columns c
+                }
+                lds_barrier();                                         // Ag / Ah / B2 free for the next chunk
+                if (!last) store_panels(wp);
+                sched_fence();            // keep the unrolled chunks apart: interleaving them only multiplies live registers
+            }
+
+            // ---- LayerNorm backward + residual, in the load layout (all lanes of a row group take part in the shuffles) ----
+            stage_pass<1, 1>(stage, LD2, acc2, 0, wm, wn, lane);
+            lds_barrier();
+#pragma unroll
+            for (int q = 0; q < NFX; q++) {
+                const int row = (tid + q * 256) / G;
+                const bool ok = m0 + row < M;
+                float d[8], xv[8], dxv[8], xh[8], lnw[8];
+                load_cols<8>(k_lnw, cl * 8, lnw);
+                stage_read8(stage, LD2, row, cl * 8, d);
+                frag_to_float<T>(rawx[q], xv);
+                frag_to_float<T>(rawdx[q], dxv);
+                float gsum = 0.f, gxsum = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    d[e] = ok ? d[e] : 0.f;
+                    xh[e] = ok ? (xv[e] - mean[q]) * rstd[q] : 0.f;
+                    const float g_ = d[e] * lnw[e];
+                    gsum += g_; gxsum += g_ * xh[e];
+                    aw[e] += d[e] * xh[e]; ab[e] += d[e];
+                }
+                const float m1 = group_sum(gsum, G) / (float)C;
+                const float m2 = group_sum(gxsum, G) / (float)C;
+                if (ok) {
+                    float o[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e++) o[e] = dxv[e] + rstd[q] * (d[e] * lnw[e] - m1 - xh[e] * m2);
+                    frag_store<T>(dxmid + (size_t)(m0 + row) * C + cl * 8, frag_from_float<T>(o));
+                }
+            }
+            lds_barrier();
+            if (have2) {
+                store_panels(wp);
+                if (PREFETCH_ROWS) {
+#pragma unroll
+                    for (int q = 0; q < NFX; q++) { rawdx[q] = ndx[q]; rawx[q] = nx[q]; }
+                } else {
+                    load_rows(tile2, rawdx, rawx);
+                }
+                stage_tile(tile2, rawdx, rawx);
+            }
+        }
+    }
+
+    // ---- partial results of this workgroup: ws = [dW1: grid x 4C x C][S2: grid x C x 4C][db1: 2 grid x 4C][cs2: grid x C] ----
+    {
+        const size_t nwg = gridDim.x, wg = blockIdx.x;
+        float* const p_dw1 = ws + wg * (size_t)(HID * C);
+        float* const p_s2 = ws + nwg * (size_t)(HID * C) + wg * (size_t)(C * HID);
+        float* const p_db1 = ws + 2 * nwg * (size_t)(HID * C) + (wg * 2 + wm) * (size_t)HID;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ch++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int rr = wm * 32 + acc_row(r, lane), cc = wn * 32 + li;
+                p_dw1[(size_t)(ch * JC + rr) * C + cc] = dW1acc[ch][r];            // rows j, columns c
+                p_s2[(size_t)rr * HID + ch * JC + cc] = dW2acc[ch][r];            // rows c, columns j
+            }
+            const float v = db1acc[ch] + __shfl_xor(db1acc[ch], 32);
+            if (half == 0) p_db1[ch * JC + wn * 32 + li] = v;
+        }
+    }
+    // LayerNorm parameter gradients and cs2: fold the 256/G threads that own the same channel chunk
+    lds_barrier();
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int e = 0; e < 8; e++) { red[tid * 24 + e] = aw[e]; red[tid * 24 + 8 + e] = ab[e]; red[tid * 24 + 16 + e] = acs[e]; }
+    lds_barrier();
+    if (tid < G) {
+        float* const p_cs2 = ws + 2 * (size_t)gridDim.x * (HID * C) + 2 * (size_t)gridDim.x * HID + (size_t)blockIdx.x * C;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            float sw = 0.f, sb = 0.f, sc = 0.f;
+            for (int t = tid; t < 256; t += G) { sw += red[t * 24 + e]; sb += red[t * 24 + 8 + e]; sc += red[t * 24 + 16 + e]; }
+            atomicAdd(dln_w + cl * 8 + e, sw);
+            atomicAdd(dln_b + cl * 8 + e, sb);
+            p_cs2[cl * 8 + e] = sc;
         }
     }
 }

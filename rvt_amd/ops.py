@@ -166,6 +166,33 @@ def mlp_bwd_dgrad(dxout: Tensor, gp: Tensor, xmid: Tensor, ln_w: Tensor, w2g_t: 
     return dh, dxmid
 
 
+def mlp_bwd_fused_supported(dtype: torch.dtype, C: int) -> bool:
+    return bool(L.get_lib().rvt_mlp_bwd_fused_supported(L.dtype_code(dtype), C))
+
+
+def mlp_bwd_fused(dxout: Tensor, xmid: Tensor, ln_w: Tensor, ln_b: Tensor, w1: Tensor, b1: Tensor, w2g_t: Tensor, w1_t: Tensor,
+                  dln_w: Tensor, dln_b: Tensor, dw1: Tensor, db1: Tensor, s2: Tensor, cs2: Tensor, eps: float) -> Tensor:
+    """Whole backward of the MLP half from (dxout, xmid): returns dxmid; accumulates dln_w/dln_b, dw1 [4C][C], db1 [4C] and
+    the raw fc2 products s2 [C][4C], cs2 [C] (all fp32, +=)."""
+    C = xmid.shape[-1]
+    M = xmid.numel() // C
+    dt = L.dtype_code(xmid.dtype)
+    n = L.get_lib().rvt_mlp_bwd_fused_ws_floats(dt, C, M)
+    st = L.stream_of(xmid)
+    key = ('mlpbwd', xmid.device.type, xmid.device.index, 0 if st is None else int(st))
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < n:
+        ws = torch.empty(n, dtype=torch.float32, device=xmid.device)
+        _WS[key] = ws
+    dxmid = torch.empty_like(xmid)
+    for t in (dw1, db1, s2, cs2, dln_w, dln_b):
+        assert t.dtype == torch.float32
+    L.call('rvt_mlp_bwd_fused', L.ptr(dxout), L.ptr(xmid), L.ptr(dxmid), L.ptr(ln_w), L.ptr(ln_b), L.ptr(w1), L.ptr(b1),
+           L.ptr(w2g_t), L.ptr(w1_t), L.ptr(dln_w), L.ptr(dln_b), L.ptr(dw1), L.ptr(db1), L.ptr(s2), L.ptr(cs2), L.ptr(ws), dt,
+           M, C, float(eps), st)
+    return dxmid
+
+
 def linear_dgrad(dy: Tensor, wt: Tensor, gelu_pre: Optional[Tensor] = None, add: Optional[Tensor] = None,
                  mul: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
     """dx = dy @ wt.T with wt = W^T stored [K][N] (optionally folded with LayerScale), then * gelu'(gelu_pre),

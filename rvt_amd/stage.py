@@ -25,15 +25,20 @@ from .weights import StageGrads, StageWeights
 
 
 def use_fused_mlp(dtype, C: int, what: str) -> bool:
-    """Which MLP halves go through the fused kernels of csrc/mlp.hpp (built for C in {64,128}).
-    Default = where they measured faster than the op-by-op chain on MI355X (profiles/microbench_mlp.py, bf16, ms, fused
-    vs chain):
-      C=64 : training forward 3.00 / 3.72, inference forward 2.03 / 3.72, backward dgrad chain 2.31 / 3.51 -> fused
-      C=128: training forward 1.75 / 2.11, inference forward 1.53 / 2.11                                    -> fused
-             backward dgrad chain 2.19 / 1.89 (one workgroup per CU: registers)                            -> chain
-    The two directions are independent: the fused forward saves exactly what the chain backward reads (g, GELU', LN2 out).
-    RVT_FUSED_MLP=1 forces every supported case (used by the parity tests), =0 disables all."""
+    """Which MLP halves go through the fused kernels of csrc/mlp.hpp.
+      'bwd_fused' (C = 64): the whole backward — recompute of LN2 / fc1 / GELU, both input-gradient products, LayerNorm
+          backward AND the weight gradients (accumulated in registers) — from (dxout, xmid) alone; the forward then saves
+          nothing but the block input (3 + 2 rows of C per token through HBM for the MLP half instead of 32).
+      'fwd_train' / 'fwd_infer' / 'bwd' (C in {64,128}): fused forward (optionally saving GELU, GELU', LN2 out) and the
+          fused input-gradient chain.  Measured on MI355X (profiles/microbench_mlp.py, bf16, ms, fused vs op-by-op chain):
+          C=64 : training forward 3.00 / 3.72, inference forward 2.03 / 3.72, backward dgrad chain 2.31 / 3.51 -> fused
+          C=128: training forward 1.75 / 2.11, inference forward 1.53 / 2.11                                    -> fused
+                 backward dgrad chain 2.19 / 1.89 (one workgroup per CU: registers)                            -> chain
+    RVT_FUSED_MLP=1 forces every supported case (used by the parity tests), =0 disables all; RVT_MLP_BWD_FUSED=0 disables
+    only the everything-on-chip backward."""
     mode = os.environ.get('RVT_FUSED_MLP', 'auto')
+    if what == 'bwd_fused':
+        return mode != '0' and os.environ.get('RVT_MLP_BWD_FUSED', '1') != '0' and ops.mlp_bwd_fused_supported(dtype, C)
     if mode == '0' or not ops.mlp_fused_supported(dtype, C):
         return False
     if mode == '1':
@@ -144,7 +149,11 @@ def stage_seq_forward(sw: StageWeights, g: StageGeom, inp: Tensor, h0: Optional[
             a = ops.attn_fwd(qkv, F_, H, W, C, g.dim_head, g.ph, g.pw, window)    # maxvit.py:349-352
             xmid = ops.linear_scale_res_fwd(a, bw['proj_w'], bw['proj_b'], bw['g1'], x)        # :353, :268
             v2 = None
-            if use_fused_mlp(dt, C, 'fwd_train' if save else 'fwd_infer'):
+            if save and use_fused_mlp(dt, C, 'bwd_fused'):
+                # the backward recomputes everything from xmid: inference-flavoured forward, nothing else kept
+                xout, hg, hgp = ops.mlp_fwd(xmid, bw['n2_w'], bw['n2_b'], bw['fc1_w'], bw['fc1_b'], bw['fc2_w'], bw['fc2_b'],
+                                            bw['g2'], g.eps, want_grad=False)
+            elif use_fused_mlp(dt, C, 'fwd_train' if save else 'fwd_infer'):
                 r = ops.mlp_fwd(xmid, bw['n2_w'], bw['n2_b'], bw['fc1_w'], bw['fc1_b'], bw['fc2_w'], bw['fc2_b'], bw['g2'],
                                 g.eps, want_grad=save, want_v2=save)
                 xout, hg, hgp = r[:3]
@@ -286,25 +295,32 @@ def stage_seq_backward(sw: StageWeights, g: StageGeom, sv: StageSaved, dH: Optio
             bp = f'{pre}att_blocks.{pi}.{"att_window" if window else "att_grid"}.'
             # MLP branch: xout = xmid + g2 * (gelu(hd) W2^T + b2).  The weight-gradient GEMM delivers the raw products
             # S2 = dxout^T g and cs2 = colsum(dxout); LayerScale is folded in by the finalize table launch.
-            def fc2_wgrad_fn(dx=dx, s=s, bp=bp):
-                ops.linear_wgrad(dx, s['hg'], G(bp + 'S2'), colsum_out=G(bp + 'cs2'))
-            side.run(fc2_wgrad_fn, dx, s['hg'])
             dn2w, dn2b = G(bp + 'norm2.weight'), G(bp + 'norm2.bias')
-            fused = use_fused_mlp(dt, C, 'bwd')
-            if fused:       # fc2 dgrad * gp, fc1 dgrad and LayerNorm-2 backward (+ residual) in one kernel
-                dhd, dxmid = ops.mlp_bwd_dgrad(dx, s['hgp'], s['xmid'], bw['n2_w'], bw['fc2_wt'], bw['fc1_wt'], dn2w, dn2b,
-                                               g.eps)
+            if s['hg'] is None:
+                # everything on chip: recompute, both input-gradient products, LayerNorm backward and the fc1 / fc2 weight
+                # gradients (accumulated in registers) in one kernel; nothing for the weight-gradient stream to do
+                dxmid = ops.mlp_bwd_fused(dx, s['xmid'], bw['n2_w'], bw['n2_b'], bw['fc1_w'], bw['fc1_b'], bw['fc2_wt'],
+                                          bw['fc1_wt'], dn2w, dn2b, G(bp + 'mlp.net.0.0.weight'), G(bp + 'mlp.net.0.0.bias'),
+                                          G(bp + 'S2'), G(bp + 'cs2'), g.eps)
             else:
-                dhd = ops.linear_dgrad(dx, bw['fc2_wt'], mul=s['hgp'])
-            def fc1_wgrad_fn(dhd=dhd, s=s, bw=bw, bp=bp):
-                v2 = s['v2'] if s['v2'] is not None else ops.layernorm_fwd(s['xmid'], bw['n2_w'], bw['n2_b'], g.eps)
-                ops.linear_wgrad(dhd, v2, G(bp + 'mlp.net.0.0.weight'), colsum_out=G(bp + 'mlp.net.0.0.bias'))
-            side.run(fc1_wgrad_fn, dhd, s['xmid'])
-            if not fused:
-                dv2 = ops.linear_dgrad(dhd, bw['fc1_wt'])
-                dxmid = ops.layernorm_bwd(s['xmid'], bw['n2_w'], dv2, dx, dn2w, dn2b, g.eps)
-                del dv2
-            del dhd
+                def fc2_wgrad_fn(dx=dx, s=s, bp=bp):
+                    ops.linear_wgrad(dx, s['hg'], G(bp + 'S2'), colsum_out=G(bp + 'cs2'))
+                side.run(fc2_wgrad_fn, dx, s['hg'])
+                fused = use_fused_mlp(dt, C, 'bwd')
+                if fused:       # fc2 dgrad * gp, fc1 dgrad and LayerNorm-2 backward (+ residual) in one kernel
+                    dhd, dxmid = ops.mlp_bwd_dgrad(dx, s['hgp'], s['xmid'], bw['n2_w'], bw['fc2_wt'], bw['fc1_wt'], dn2w,
+                                                   dn2b, g.eps)
+                else:
+                    dhd = ops.linear_dgrad(dx, bw['fc2_wt'], mul=s['hgp'])
+                def fc1_wgrad_fn(dhd=dhd, s=s, bw=bw, bp=bp):
+                    v2 = s['v2'] if s['v2'] is not None else ops.layernorm_fwd(s['xmid'], bw['n2_w'], bw['n2_b'], g.eps)
+                    ops.linear_wgrad(dhd, v2, G(bp + 'mlp.net.0.0.weight'), colsum_out=G(bp + 'mlp.net.0.0.bias'))
+                side.run(fc1_wgrad_fn, dhd, s['xmid'])
+                if not fused:
+                    dv2 = ops.linear_dgrad(dhd, bw['fc1_wt'])
+                    dxmid = ops.layernorm_bwd(s['xmid'], bw['n2_w'], dv2, dx, dn2w, dn2b, g.eps)
+                    del dv2
+                del dhd
             # attention branch: xmid = xin + g1 * (a Wp^T + bp)
             def proj_wgrad_fn(dxmid=dxmid, s=s, bp=bp):
                 ops.linear_wgrad(dxmid, s['a'], G(bp + 'S1'), colsum_out=G(bp + 'cs1'))

@@ -348,3 +348,47 @@ def test_state_reset(backend, dt):
     ref[0] = 0
     ref[2] = 0
     assert torch.equal(st.cpu(), ref.cpu())
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('M', [130, 1000])
+def test_mlp_bwd_fused_everything_on_chip(backend, dt, M):
+    """rvt_mlp_bwd_fused (recompute + in-kernel weight gradients, C = 64) vs fp64 autograd of the MLP half."""
+    C = 64
+    assert ops.mlp_bwd_fused_supported(dt, C)
+    x = rnd((M, C), backend, dt, 1, 1.5)
+    lw, lb = rnd((C,), backend, torch.float32, 2) * 0.3 + 1.0, rnd((C,), backend, torch.float32, 3, 0.2)
+    w1, b1 = rnd((4 * C, C), backend, dt, 4, 0.2), rnd((4 * C,), backend, torch.float32, 5, 0.2)
+    w2, b2 = rnd((C, 4 * C), backend, dt, 6, 0.1), rnd((C,), backend, torch.float32, 7, 0.2)
+    gam = rnd((C,), backend, torch.float32, 8)
+    dy = rnd((M, C), backend, dt, 9)
+
+    xr = f64(x).requires_grad_(True)
+    lwr, lbr = f64(lw).requires_grad_(True), f64(lb).requires_grad_(True)
+    w1r, b1r = f64(w1).requires_grad_(True), f64(b1).requires_grad_(True)
+    v2 = F.layer_norm(xr, (C,), lwr, lbr, 1e-5)
+    g = F.gelu(v2 @ w1r.t() + b1r)
+    g.retain_grad()
+    y2 = g @ f64(w2).t() + f64(b2)                       # the LayerScale branch: xout = x + gamma * y2
+    want = xr + f64(gam) * y2
+    want.backward(f64(dy))
+
+    w2g_t = (f64(w2) * f64(gam)[:, None]).t().to(dt).contiguous().to(backend)
+    w1_t = f64(w1).t().to(dt).contiguous().to(backend)
+    z = lambda *s: torch.zeros(*s, device=backend)
+    dlw, dlb, dw1, db1, s2, cs2 = z(C), z(C), z(4 * C, C), z(4 * C), z(C, 4 * C), z(C)
+    dxm = ops.mlp_bwd_fused(dy, x, lw, lb, w1, b1, w2g_t, w1_t, dlw, dlb, dw1, db1, s2, cs2, 1e-5)
+    mult = 1.0 if dt == torch.float32 else 2.0
+    close(dxm, xr.grad, dt, 'mlp_bwd_fused dxmid', mult=mult)
+    close(dlw, lwr.grad, dt, 'mlp_bwd_fused dln_w', mult=2 * mult)
+    close(dlb, lbr.grad, dt, 'mlp_bwd_fused dln_b', mult=2 * mult)
+    close(dw1, w1r.grad, dt, 'mlp_bwd_fused dW1', mult=2 * mult)
+    close(db1, b1r.grad, dt, 'mlp_bwd_fused db1', mult=2 * mult)
+    # raw fc2 products: S2 = dy^T g, cs2 = colsum(dy)  (gamma is applied by the LayerScale fold)
+    close(s2, f64(dy).t() @ g.detach(), dt, 'mlp_bwd_fused S2', mult=2 * mult)
+    close(cs2, f64(dy).sum(0), dt, 'mlp_bwd_fused cs2', mult=mult)
+    # accumulation semantics (+=) of every parameter-gradient output
+    dxm2 = ops.mlp_bwd_fused(dy, x, lw, lb, w1, b1, w2g_t, w1_t, dlw, dlb, dw1, db1, s2, cs2, 1e-5)
+    assert torch.equal(dxm2.cpu(), dxm.cpu())
+    close(dw1, 2 * w1r.grad, dt, 'mlp_bwd_fused dW1 accumulate', mult=2 * mult)
+    close(cs2, 2 * f64(dy).sum(0), dt, 'mlp_bwd_fused cs2 accumulate', mult=mult)
