@@ -108,6 +108,17 @@ size_t rvt_mlp_bwd_fused_ws_floats(int dtype, int C, int M);
 int rvt_mlp_bwd_fused(const void* dxout, const void* xmid, void* dxmid, const float* ln_w, const float* ln_b, const void* w1,
                       const float* b1, const void* w2g_t, const void* w1_t, float* dln_w, float* dln_b, float* dw1, float* db1,
                       float* s2, float* cs2, float* ws, int dtype, int M, int C, float eps, void* stream);
+/* The same kernel cut in two along the critical path of backward (both recompute LN2 / fc1 / GELU from xmid):
+ *   rvt_mlp_bwd_recompute_dgrad: dxmid and dln_w / dln_b only — no weight-gradient accumulators, several workgroups per CU;
+ *   rvt_mlp_bwd_recompute_wgrad: dw1, db1, s2, cs2 only (two groups of hidden chunks per tile column, 64 accumulator
+ *     registers each) — for the weight-gradient stream; reads (dxout, xmid) once per group instead of the 10 rows of C
+ *     per token the two weight-gradient GEMMs re-read. */
+int rvt_mlp_bwd_recompute_dgrad(const void* dxout, const void* xmid, void* dxmid, const float* ln_w, const float* ln_b,
+                                const void* w1, const float* b1, const void* w2g_t, const void* w1_t, float* dln_w,
+                                float* dln_b, int dtype, int M, int C, float eps, void* stream);
+int rvt_mlp_bwd_recompute_wgrad(const void* dxout, const void* xmid, const float* ln_w, const float* ln_b, const void* w1,
+                                const float* b1, const void* w2g_t, float* dw1, float* db1, float* s2, float* cs2, float* ws,
+                                int dtype, int M, int C, float eps, void* stream);
 
 /* Partitioned multi-head attention core (maxvit.py:252-265,273-304,343-354 minus the two linears):
  * qkv [F*H*W][3C] in image token order, per-head layout [q|k|v]; out [F*H*W][C].  window=1: ph x pw

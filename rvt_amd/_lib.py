@@ -50,6 +50,8 @@ _SIGS = {
     'rvt_token_mask_bwd': [_vp, _vp, _vp, _i, _i, _i, _vp],
     'rvt_state_reset_masked': [_vp, _vp, _i, _i, _sz, _vp],
     'rvt_pack_table': [_vp, _i, _i, _i, _vp],
+    'rvt_mlp_bwd_recompute_dgrad': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
+    'rvt_mlp_bwd_recompute_wgrad': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
     'rvt_mlp_bwd_fused': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
     'rvt_lstm_scan_fwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     'rvt_lstm_scan_bwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],

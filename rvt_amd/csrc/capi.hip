@@ -440,13 +440,29 @@ int rvt_mlp_bwd_fused_supported(int dtype, int C) {
     return (dtype == RVT_BF16 || dtype == RVT_F32) && C == 64;
 }
 }  // extern "C"
-template <class T> static int mlp_bwd_fused_grid(int M) {
-    return mlp_grid(mlp_bwd_fused_kernel<T, 64>, M, 64);
+template <class T, int MODE> static int mlp_bwd_fused_grid(int M) {
+    const int g = mlp_grid(mlp_bwd_fused_kernel<T, 64, MODE>, M, 64);
+    return MODE == 2 ? imax(1, g / 2) : g;            // MODE 2 launches two chunk groups (grid.y) per tile column
+}
+// fold the per-workgroup partial records of a weight-gradient launch (plain stores; device-scope float atomics execute
+// memory-side on this part) into the fp32 outputs
+static void mlp_fold_partials(const float* ws, int grid, int C, float* dw1, float* db1, float* s2, float* cs2, hipStream_t st) {
+    const size_t wc = (size_t)4 * C * C;
+    const float* p = ws;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for(wc, 1024)), dim3(256), 0, st, p, dw1, grid, wc, 0);
+    p += (size_t)grid * wc;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for(wc, 1024)), dim3(256), 0, st, p, s2, grid, wc, 0);
+    p += (size_t)grid * wc;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for((size_t)4 * C, 64)), dim3(256), 0, st, p, db1, 2 * grid, (size_t)4 * C, 0);
+    p += (size_t)2 * grid * 4 * C;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for((size_t)C, 64)), dim3(256), 0, st, p, cs2, grid, (size_t)C, 0);
 }
 extern "C" {
 size_t rvt_mlp_bwd_fused_ws_floats(int dtype, int C, int M) {
     if (!rvt_mlp_bwd_fused_supported(dtype, C)) return 0;
-    const size_t grid = dtype == RVT_BF16 ? mlp_bwd_fused_grid<bf16>(M) : mlp_bwd_fused_grid<float>(M);
+    size_t grid = dtype == RVT_BF16 ? mlp_bwd_fused_grid<bf16, 0>(M) : mlp_bwd_fused_grid<float, 0>(M);
+    const size_t g2 = dtype == RVT_BF16 ? mlp_bwd_fused_grid<bf16, 2>(M) : mlp_bwd_fused_grid<float, 2>(M);
+    if (g2 > grid) grid = g2;
     return grid * ((size_t)2 * 4 * C * C + 2 * 4 * C + C);
 }
 
@@ -458,21 +474,42 @@ int rvt_mlp_bwd_fused(const void* dxout, const void* xmid, void* dxmid, const fl
     hipStream_t st = (hipStream_t)stream;
     int grid = 0;
     DISPATCH_DTYPE(dtype, {
-        grid = mlp_bwd_fused_grid<T>(M);
-        hipLaunchKernelGGL((mlp_bwd_fused_kernel<T, 64>), dim3(grid), dim3(256), 0, st, (const T*)dxout, (const T*)xmid, (T*)dxmid,
+        grid = mlp_bwd_fused_grid<T, 0>(M);
+        hipLaunchKernelGGL((mlp_bwd_fused_kernel<T, 64, 0>), dim3(grid), dim3(256), 0, st, (const T*)dxout, (const T*)xmid, (T*)dxmid,
                            ln_w, ln_b, (const T*)w1, b1, (const T*)w2g_t, (const T*)w1_t, dln_w, dln_b, ws, M, eps);
     });
-    // fold the per-workgroup partials (plain stores above; device-scope float atomics are memory-side on this part)
-    const size_t wc = (size_t)4 * C * C;
-    const float* p = ws;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for(wc, 1024)), dim3(256), 0, st, p, dw1, grid, wc, 0);
-    p += (size_t)grid * wc;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for(wc, 1024)), dim3(256), 0, st, p, s2, grid, wc, 0);
-    p += (size_t)grid * wc;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for((size_t)4 * C, 64)), dim3(256), 0, st, p, db1, 2 * grid, (size_t)4 * C, 0);
-    p += (size_t)2 * grid * 4 * C;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for((size_t)C, 64)), dim3(256), 0, st, p, cs2, grid, (size_t)C, 0);
+    mlp_fold_partials(ws, grid, C, dw1, db1, s2, cs2, st);
     return check_launch("mlp_bwd_fused");
+}
+
+int rvt_mlp_bwd_recompute_dgrad(const void* dxout, const void* xmid, void* dxmid, const float* ln_w, const float* ln_b,
+                                const void* w1, const float* b1, const void* w2g_t, const void* w1_t, float* dln_w,
+                                float* dln_b, int dtype, int M, int C, float eps, void* stream) {
+    RVT_CHECK(rvt_mlp_bwd_fused_supported(dtype, C), "mlp_bwd_recompute_dgrad: not built for dtype=%d C=%d", dtype, C);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_DTYPE(dtype, {
+        const int grid = mlp_bwd_fused_grid<T, 1>(M);
+        hipLaunchKernelGGL((mlp_bwd_fused_kernel<T, 64, 1>), dim3(grid), dim3(256), 0, st, (const T*)dxout, (const T*)xmid, (T*)dxmid,
+                           ln_w, ln_b, (const T*)w1, b1, (const T*)w2g_t, (const T*)w1_t, dln_w, dln_b, (float*)nullptr, M, eps);
+    });
+    return check_launch("mlp_bwd_recompute_dgrad");
+}
+
+int rvt_mlp_bwd_recompute_wgrad(const void* dxout, const void* xmid, const float* ln_w, const float* ln_b, const void* w1,
+                                const float* b1, const void* w2g_t, float* dw1, float* db1, float* s2, float* cs2, float* ws,
+                                int dtype, int M, int C, float eps, void* stream) {
+    RVT_CHECK(rvt_mlp_bwd_fused_supported(dtype, C), "mlp_bwd_recompute_wgrad: not built for dtype=%d C=%d", dtype, C);
+    RVT_CHECK(ws != nullptr && M >= 1, "mlp_bwd_recompute_wgrad: workspace required");
+    hipStream_t st = (hipStream_t)stream;
+    int grid = 0;
+    DISPATCH_DTYPE(dtype, {
+        grid = mlp_bwd_fused_grid<T, 2>(M);
+        hipLaunchKernelGGL((mlp_bwd_fused_kernel<T, 64, 2>), dim3(grid, 2), dim3(256), 0, st, (const T*)dxout, (const T*)xmid,
+                           (T*)nullptr, ln_w, ln_b, (const T*)w1, b1, (const T*)w2g_t, (const T*)nullptr, (float*)nullptr,
+                           (float*)nullptr, ws, M, eps);
+    });
+    mlp_fold_partials(ws, grid, C, dw1, db1, s2, cs2, st);
+    return check_launch("mlp_bwd_recompute_wgrad");
 }
 
 // ----------------------------------------------------------------------------------------- attention

@@ -608,14 +608,23 @@ template <class T, int C> struct MlpFusedSmem {
     static_assert(BYTES <= 160 * 1024, "LDS");
 };
 
-template <class T, int C>
-__global__ void __launch_bounds__(256, 1)      // 128 accumulator registers of weight gradients: one workgroup per CU, no spills
+// MODE 0: everything in one kernel (input gradient + all weight gradients: 128 accumulator registers, one workgroup per CU)
+// MODE 1: input-gradient half only (dxmid, LayerNorm parameter gradients): no accumulators, several workgroups per CU —
+//         the kernel on the critical path of backward
+// MODE 2: weight-gradient half only, blockIdx.y = group of NCH/NG hidden chunks (64 accumulator registers per group with
+//         NG = 2): re-reads (dxout, xmid) once per group, for the weight-gradient stream
+template <class T, int C, int MODE>
+__global__ void __launch_bounds__(256, (MODE == 0 || sizeof(T) == 4) ? 1 : 2)
 mlp_bwd_fused_kernel(const T* __restrict__ dxout, const T* __restrict__ xmid, T* __restrict__ dxmid,
                      const float* __restrict__ ln_w, const float* __restrict__ ln_b, const T* __restrict__ W1,
                      const float* __restrict__ b1, const T* __restrict__ W2gT, const T* __restrict__ W1T,
                      float* __restrict__ dln_w, float* __restrict__ dln_b, float* __restrict__ ws, int M, float eps) {
     typedef MlpFusedSmem<T, C> S;
     constexpr int TM = S::TM, JC = S::JC, HID = 4 * C, NCH = HID / JC;
+    constexpr bool DGRAD = MODE != 2, WGRAD = MODE != 1;
+    constexpr int NG = MODE == 2 ? 2 : 1;                  // chunk groups (blockIdx.y)
+    constexpr int NCG = NCH / NG;                          // hidden chunks this workgroup walks
+    const int ch_base = MODE == 2 ? (int)blockIdx.y * NCG : 0;
     constexpr int G = C / 8, NFX = TM * G / 256;
     constexpr int F1 = C / 8, F2 = JC / 8, N1 = JC * F1 / 256, N2 = C * F2 / 256;
     constexpr int LD2 = C + 4;
@@ -643,10 +652,11 @@ mlp_bwd_fused_kernel(const T* __restrict__ dxout, const T* __restrict__ xmid, T*
 
     // persistent accumulators (whole launch): weight gradients per hidden chunk in the MFMA C/D layout, db1 per lane
     // column, LayerNorm parameter gradients and cs2 per (thread, 8-channel chunk)
-    f32x16 dW2acc[NCH], dW1acc[NCH];
-    float db1acc[NCH];
+    constexpr int NACC = WGRAD ? NCG : 1;
+    f32x16 dW2acc[NACC], dW1acc[NACC];
+    float db1acc[NACC];
 #pragma unroll
-    for (int c = 0; c < NCH; c++) { acc_zero(dW2acc[c]); acc_zero(dW1acc[c]); db1acc[c] = 0.f; }
+    for (int c = 0; c < NACC; c++) { acc_zero(dW2acc[c]); acc_zero(dW1acc[c]); db1acc[c] = 0.f; }
     float aw[8], ab[8], acs[8];
 #pragma unroll
     for (int e = 0; e < 8; e++) { aw[e] = 0.f; ab[e] = 0.f; acs[e] = 0.f; }
@@ -682,7 +692,7 @@ mlp_bwd_fused_kernel(const T* __restrict__ dxout, const T* __restrict__ xmid, T*
             frag_to_float<T>(rdx[q], d);
             float s = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; e++) { s += v[e]; acs[e] += ok ? d[e] : 0.f; }
+            for (int e = 0; e < 8; e++) { s += v[e]; if (WGRAD) acs[e] += ok ? d[e] : 0.f; }
             mean[q] = group_sum(s, G) / (float)C;
             float qq = 0.f;
 #pragma unroll
@@ -705,10 +715,12 @@ mlp_bwd_fused_kernel(const T* __restrict__ dxout, const T* __restrict__ xmid, T*
             p.r0[i] = frag_load<T>(W1 + (size_t)(j0 + f / F1) * C + (f % F1) * 8);
             p.r1[i] = frag_load<T>(W2gT + (size_t)(j0 + f / F1) * C + (f % F1) * 8);
         }
+        if (DGRAD) {
 #pragma unroll
-        for (int i = 0; i < N2; i++) {
-            const int f = tid + i * 256;
-            p.r2[i] = frag_load<T>(W1T + (size_t)(f / F2) * HID + j0 + (f % F2) * 8);
+            for (int i = 0; i < N2; i++) {
+                const int f = tid + i * 256;
+                p.r2[i] = frag_load<T>(W1T + (size_t)(f / F2) * HID + j0 + (f % F2) * 8);
+            }
         }
     };
     auto store_panels = [&](const Panels& p) {
@@ -718,10 +730,12 @@ mlp_bwd_fused_kernel(const T* __restrict__ dxout, const T* __restrict__ xmid, T*
             opm_store_frag<T>(B0, JC, f / F1, f % F1, p.r0[i]);
             opm_store_frag<T>(B1, JC, f / F1, f % F1, p.r1[i]);
         }
+        if (DGRAD) {
 #pragma unroll
-        for (int i = 0; i < N2; i++) {
-            const int f = tid + i * 256;
-            opm_store_frag<T>(B2, C, f / F2, f % F2, p.r2[i]);
+            for (int i = 0; i < N2; i++) {
+                const int f = tid + i * 256;
+                opm_store_frag<T>(B2, C, f / F2, f % F2, p.r2[i]);
+            }
         }
     };
 
@@ -730,7 +744,7 @@ mlp_bwd_fused_kernel(const T* __restrict__ dxout, const T* __restrict__ xmid, T*
         frag_t<T> rawdx[NFX], rawx[NFX], ndx[NFX], nx[NFX];
         Panels wp;
         load_rows(tile, rawdx, rawx);
-        load_panels(wp, 0);
+        load_panels(wp, ch_base * JC);
         stage_tile(tile, rawdx, rawx);
         store_panels(wp);
 
@@ -744,12 +758,12 @@ mlp_bwd_fused_kernel(const T* __restrict__ dxout, const T* __restrict__ xmid, T*
             f32x16 acc2[1][1];
             acc_zero(acc2[0][0]);
 #pragma unroll
-            for (int ch = 0; ch < NCH; ch++) {
-                const int j0 = ch * JC;
-                const bool last = ch == NCH - 1;
+            for (int ch = 0; ch < NCG; ch++) {
+                const int j0 = (ch_base + ch) * JC;
+                const bool last = ch == NCG - 1;
                 lds_barrier();                                         // this chunk's panels and the tiles are in LDS
                 if (!last) load_panels(wp, j0 + JC);
-                else if (have2) load_panels(wp, 0);
+                else if (have2) load_panels(wp, ch_base * JC);
                 const float b1c = k_b1[j0 + wn * 32 + li];
                 sched_fence();
                 // h = v2 W1_j^T (recomputed) and dg = dxout (W2 gamma)_j: same tiling -> same lane, same register
@@ -770,52 +784,56 @@ mlp_bwd_fused_kernel(const T* __restrict__ dxout, const T* __restrict__ xmid, T*
                         const float dh = acc1[0][0][r] * gpv[e];
                         colsum += dh;
                         const int o = acc_elem_off(off0, r);
-                        *reinterpret_cast<T*>(Ag + o) = (T)gv[e];
+                        if (WGRAD) *reinterpret_cast<T*>(Ag + o) = (T)gv[e];
                         *reinterpret_cast<T*>(Ah + o) = (T)dh;
                     }
                 }
-                db1acc[ch] += colsum;
+                if (WGRAD) db1acc[ch] += colsum;
                 lds_barrier();                                         // g / dh chunk complete; B0 / B1 consumed
-                opm_mma<T, 1, 1>(acc2, Ah, TM, wm * 32, B2, C, wn * 32, JC, lane);
+                if (DGRAD) opm_mma<T, 1, 1>(acc2, Ah, TM, wm * 32, B2, C, wn * 32, JC, lane);
                 // weight gradients: contraction over the TM tokens of the tile, operands transposed on the way out of LDS
+                if (WGRAD) {
 #pragma unroll
-                for (int k0 = 0; k0 < TM; k0 += 16) {
-                    mma32(dW2acc[ch], trm.load(Ax, k0, lane), trn.load(Ag, k0, lane));       // rows c, columns j
-                    mma32(dW1acc[ch], trm.load(Ah, k0, lane), trn.load(Av, k0, lane));       // rows j, columns c
+                    for (int k0 = 0; k0 < TM; k0 += 16) {
+                        mma32(dW2acc[ch], trm.load(Ax, k0, lane), trn.load(Ag, k0, lane));       // rows c, columns j
+                        mma32(dW1acc[ch], trm.load(Ah, k0, lane), trn.load(Av, k0, lane));       // rows j, columns c
+                    }
                 }
                 lds_barrier();                                         // Ag / Ah / B2 free for the next chunk
                 if (!last) store_panels(wp);
                 sched_fence();            // keep the unrolled chunks apart: interleaving them only multiplies live registers
             }
 
-            // ---- LayerNorm backward + residual, in the load layout (all lanes of a row group take part in the shuffles) ----
-            stage_pass<1, 1>(stage, LD2, acc2, 0, wm, wn, lane);
-            lds_barrier();
-#pragma unroll
-            for (int q = 0; q < NFX; q++) {
-                const int row = (tid + q * 256) / G;
-                const bool ok = m0 + row < M;
-                float d[8], xv[8], dxv[8], xh[8], lnw[8];
-                load_cols<8>(k_lnw, cl * 8, lnw);
-                stage_read8(stage, LD2, row, cl * 8, d);
-                frag_to_float<T>(rawx[q], xv);
-                frag_to_float<T>(rawdx[q], dxv);
-                float gsum = 0.f, gxsum = 0.f;
-#pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    d[e] = ok ? d[e] : 0.f;
-                    xh[e] = ok ? (xv[e] - mean[q]) * rstd[q] : 0.f;
-                    const float g_ = d[e] * lnw[e];
-                    gsum += g_; gxsum += g_ * xh[e];
-                    aw[e] += d[e] * xh[e]; ab[e] += d[e];
-                }
-                const float m1 = group_sum(gsum, G) / (float)C;
-                const float m2 = group_sum(gxsum, G) / (float)C;
-                if (ok) {
-                    float o[8];
-#pragma unroll
-                    for (int e = 0; e < 8; e++) o[e] = dxv[e] + rstd[q] * (d[e] * lnw[e] - m1 - xh[e] * m2);
-                    frag_store<T>(dxmid + (size_t)(m0 + row) * C + cl * 8, frag_from_float<T>(o));
+            if (DGRAD) {
+                // ---- LayerNorm backward + residual, in the load layout (all lanes of a row group take part in the shuffles) ----
+                stage_pass<1, 1>(stage, LD2, acc2, 0, wm, wn, lane);
+                lds_barrier();
+    #pragma unroll
+                for (int q = 0; q < NFX; q++) {
+                    const int row = (tid + q * 256) / G;
+                    const bool ok = m0 + row < M;
+                    float d[8], xv[8], dxv[8], xh[8], lnw[8];
+                    load_cols<8>(k_lnw, cl * 8, lnw);
+                    stage_read8(stage, LD2, row, cl * 8, d);
+                    frag_to_float<T>(rawx[q], xv);
+                    frag_to_float<T>(rawdx[q], dxv);
+                    float gsum = 0.f, gxsum = 0.f;
+    #pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        d[e] = ok ? d[e] : 0.f;
+                        xh[e] = ok ? (xv[e] - mean[q]) * rstd[q] : 0.f;
+                        const float g_ = d[e] * lnw[e];
+                        gsum += g_; gxsum += g_ * xh[e];
+                        aw[e] += d[e] * xh[e]; ab[e] += d[e];
+                    }
+                    const float m1 = group_sum(gsum, G) / (float)C;
+                    const float m2 = group_sum(gxsum, G) / (float)C;
+                    if (ok) {
+                        float o[8];
+    #pragma unroll
+                        for (int e = 0; e < 8; e++) o[e] = dxv[e] + rstd[q] * (d[e] * lnw[e] - m1 - xh[e] * m2);
+                        frag_store<T>(dxmid + (size_t)(m0 + row) * C + cl * 8, frag_from_float<T>(o));
+                    }
                 }
             }
             lds_barrier();
@@ -833,21 +851,23 @@ mlp_bwd_fused_kernel(const T* __restrict__ dxout, const T* __restrict__ xmid, T*
     }
 
     // ---- partial results of this workgroup: ws = [dW1: grid x 4C x C][S2: grid x C x 4C][db1: 2 grid x 4C][cs2: grid x C] ----
-    {
+    // (MODE 2: every chunk group of a column of workgroups writes its own rows of the same per-workgroup record)
+    if (WGRAD) {
         const size_t nwg = gridDim.x, wg = blockIdx.x;
         float* const p_dw1 = ws + wg * (size_t)(HID * C);
         float* const p_s2 = ws + nwg * (size_t)(HID * C) + wg * (size_t)(C * HID);
         float* const p_db1 = ws + 2 * nwg * (size_t)(HID * C) + (wg * 2 + wm) * (size_t)HID;
 #pragma unroll
-        for (int ch = 0; ch < NCH; ch++) {
+        for (int ch = 0; ch < NACC; ch++) {
+            const int jb = (ch_base + ch) * JC;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int rr = wm * 32 + acc_row(r, lane), cc = wn * 32 + li;
-                p_dw1[(size_t)(ch * JC + rr) * C + cc] = dW1acc[ch][r];            // rows j, columns c
-                p_s2[(size_t)rr * HID + ch * JC + cc] = dW2acc[ch][r];            // rows c, columns j
+                p_dw1[(size_t)(jb + rr) * C + cc] = dW1acc[ch][r];            // rows j, columns c
+                p_s2[(size_t)rr * HID + jb + cc] = dW2acc[ch][r];            // rows c, columns j
             }
             const float v = db1acc[ch] + __shfl_xor(db1acc[ch], 32);
-            if (half == 0) p_db1[ch * JC + wn * 32 + li] = v;
+            if (half == 0) p_db1[jb + wn * 32 + li] = v;
         }
     }
     // LayerNorm parameter gradients and cs2: fold the 256/G threads that own the same channel chunk
@@ -862,9 +882,11 @@ mlp_bwd_fused_kernel(const T* __restrict__ dxout, const T* __restrict__ xmid, T*
         for (int e = 0; e < 8; e++) {
             float sw = 0.f, sb = 0.f, sc = 0.f;
             for (int t = tid; t < 256; t += G) { sw += red[t * 24 + e]; sb += red[t * 24 + 8 + e]; sc += red[t * 24 + 16 + e]; }
-            atomicAdd(dln_w + cl * 8 + e, sw);
-            atomicAdd(dln_b + cl * 8 + e, sb);
-            p_cs2[cl * 8 + e] = sc;
+            if (DGRAD) {
+                atomicAdd(dln_w + cl * 8 + e, sw);
+                atomicAdd(dln_b + cl * 8 + e, sb);
+            }
+            if (WGRAD && ch_base == 0) p_cs2[cl * 8 + e] = sc;
         }
     }
 }

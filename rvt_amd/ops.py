@@ -177,13 +177,8 @@ def mlp_bwd_fused(dxout: Tensor, xmid: Tensor, ln_w: Tensor, ln_b: Tensor, w1: T
     C = xmid.shape[-1]
     M = xmid.numel() // C
     dt = L.dtype_code(xmid.dtype)
-    n = L.get_lib().rvt_mlp_bwd_fused_ws_floats(dt, C, M)
     st = L.stream_of(xmid)
-    key = ('mlpbwd', xmid.device.type, xmid.device.index, 0 if st is None else int(st))
-    ws = _WS.get(key)
-    if ws is None or ws.numel() < n:
-        ws = torch.empty(n, dtype=torch.float32, device=xmid.device)
-        _WS[key] = ws
+    ws = _mlp_ws(xmid)
     dxmid = torch.empty_like(xmid)
     for t in (dw1, db1, s2, cs2, dln_w, dln_b):
         assert t.dtype == torch.float32
@@ -191,6 +186,42 @@ def mlp_bwd_fused(dxout: Tensor, xmid: Tensor, ln_w: Tensor, ln_b: Tensor, w1: T
            L.ptr(w2g_t), L.ptr(w1_t), L.ptr(dln_w), L.ptr(dln_b), L.ptr(dw1), L.ptr(db1), L.ptr(s2), L.ptr(cs2), L.ptr(ws), dt,
            M, C, float(eps), st)
     return dxmid
+
+
+def _mlp_ws(xmid: Tensor) -> Tensor:
+    C = xmid.shape[-1]
+    M = xmid.numel() // C
+    n = L.get_lib().rvt_mlp_bwd_fused_ws_floats(L.dtype_code(xmid.dtype), C, M)
+    st = L.stream_of(xmid)
+    key = ('mlpbwd', xmid.device.type, xmid.device.index, 0 if st is None else int(st))
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < n:
+        ws = torch.empty(n, dtype=torch.float32, device=xmid.device)
+        _WS[key] = ws
+    return ws
+
+
+def mlp_bwd_recompute_dgrad(dxout: Tensor, xmid: Tensor, ln_w: Tensor, ln_b: Tensor, w1: Tensor, b1: Tensor, w2g_t: Tensor,
+                            w1_t: Tensor, dln_w: Tensor, dln_b: Tensor, eps: float) -> Tensor:
+    """Input-gradient half of the recompute backward: dxmid = dxout + LN2'(...); dln_w / dln_b += ."""
+    C = xmid.shape[-1]
+    M = xmid.numel() // C
+    dxmid = torch.empty_like(xmid)
+    L.call('rvt_mlp_bwd_recompute_dgrad', L.ptr(dxout), L.ptr(xmid), L.ptr(dxmid), L.ptr(ln_w), L.ptr(ln_b), L.ptr(w1),
+           L.ptr(b1), L.ptr(w2g_t), L.ptr(w1_t), L.ptr(dln_w), L.ptr(dln_b), L.dtype_code(xmid.dtype), M, C, float(eps),
+           L.stream_of(xmid))
+    return dxmid
+
+
+def mlp_bwd_recompute_wgrad(dxout: Tensor, xmid: Tensor, ln_w: Tensor, ln_b: Tensor, w1: Tensor, b1: Tensor, w2g_t: Tensor,
+                            dw1: Tensor, db1: Tensor, s2: Tensor, cs2: Tensor, eps: float) -> None:
+    """Weight-gradient half of the recompute backward: dw1, db1, s2 (raw), cs2 (raw) += ."""
+    C = xmid.shape[-1]
+    M = xmid.numel() // C
+    ws = _mlp_ws(xmid)
+    L.call('rvt_mlp_bwd_recompute_wgrad', L.ptr(dxout), L.ptr(xmid), L.ptr(ln_w), L.ptr(ln_b), L.ptr(w1), L.ptr(b1),
+           L.ptr(w2g_t), L.ptr(dw1), L.ptr(db1), L.ptr(s2), L.ptr(cs2), L.ptr(ws), L.dtype_code(xmid.dtype), M, C, float(eps),
+           L.stream_of(xmid))
 
 
 def linear_dgrad(dy: Tensor, wt: Tensor, gelu_pre: Optional[Tensor] = None, add: Optional[Tensor] = None,

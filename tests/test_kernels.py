@@ -392,3 +392,24 @@ def test_mlp_bwd_fused_everything_on_chip(backend, dt, M):
     assert torch.equal(dxm2.cpu(), dxm.cpu())
     close(dw1, 2 * w1r.grad, dt, 'mlp_bwd_fused dW1 accumulate', mult=2 * mult)
     close(cs2, 2 * f64(dy).sum(0), dt, 'mlp_bwd_fused cs2 accumulate', mult=mult)
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+def test_mlp_bwd_recompute_split_matches_fused(backend, dt):
+    """The two halves of the recompute backward (input-gradient kernel + weight-gradient kernel with chunk groups) give what
+    the all-in-one kernel gives."""
+    C, M = 64, 700
+    x = rnd((M, C), backend, dt, 1, 1.5)
+    lw, lb = rnd((C,), backend, torch.float32, 2) * 0.3 + 1.0, rnd((C,), backend, torch.float32, 3, 0.2)
+    w1, b1 = rnd((4 * C, C), backend, dt, 4, 0.2), rnd((4 * C,), backend, torch.float32, 5, 0.2)
+    w2g_t, w1_t = rnd((4 * C, C), backend, dt, 6, 0.1), w1.t().contiguous()
+    dy = rnd((M, C), backend, dt, 9)
+    z = lambda *s: torch.zeros(*s, device=backend)
+    a = [z(C), z(C), z(4 * C, C), z(4 * C), z(C, 4 * C), z(C)]
+    b = [z(C), z(C), z(4 * C, C), z(4 * C), z(C, 4 * C), z(C)]
+    dxa = ops.mlp_bwd_fused(dy, x, lw, lb, w1, b1, w2g_t, w1_t, *a, 1e-5)
+    dxb = ops.mlp_bwd_recompute_dgrad(dy, x, lw, lb, w1, b1, w2g_t, w1_t, b[0], b[1], 1e-5)
+    ops.mlp_bwd_recompute_wgrad(dy, x, lw, lb, w1, b1, w2g_t, b[2], b[3], b[4], b[5], 1e-5)
+    assert torch.equal(dxa.cpu(), dxb.cpu())
+    for i, (u, v) in enumerate(zip(a, b)):
+        close(v, u.double(), dt, f'split vs fused output {i}', mult=0.1 if dt == torch.float32 else 1e-3)
