@@ -128,6 +128,24 @@ int rvt_attn_fwd(const void* qkv, void* out, int dtype, int F, int H, int W, int
 int rvt_attn_bwd(const void* qkv, const void* dout, void* dqkv, int dtype, int F, int H, int W, int C, int dim_head,
                  int ph, int pw, int window, void* stream);
 
+/* Fused attention half of a PartitionAttentionCl block (replaces maxvit.py:268 = norm1 :229, SelfAttentionCl :343-354 on
+ * the partitions of :273-304, LayerScale :51-53 and the residual): one wave per partition, everything between the x rows
+ * and the xmid rows on chip (csrc/attn_block.hpp).  rvt_attn_block_supported: C == 64, dim_head == 32, 32 < ph*pw <= 96.
+ *   fwd: xmid = x + gamma * (attention(LN1(x) wqkv^T + bqkv) wp^T + bp); ln_w / ln_b NULL = no norm1 (first window block of a
+ *        stage, maxvit_rnn.py:153); a_out (nullable) receives the attention output rows [F*H*W][C] (operand of the proj
+ *        weight gradient).  wqkv [3C][C] (rows [head][q|k|v][dh]), wp [C][C].
+ *   bwd: dx = dxmid + LN1'(dqkv wqkv), dqkv = attention backward of dxmid (gamma wp) with q / k / v / P recomputed from x;
+ *        writes dqkv [F*H*W][3C] and (u_out nullable, LN only) LN1(x) for the qkv weight-gradient GEMM; dln_w / dln_b +=
+ *        LayerNorm parameter gradients.  wpg_t = (wp * gamma[:,None])^T [C][C]. */
+int rvt_attn_block_supported(int dtype, int C, int dim_head, int L);
+int rvt_attn_block_fwd(const void* x, void* xmid, void* a_out, const float* ln_w, const float* ln_b, const void* wqkv,
+                       const float* bqkv, const void* wp, const float* bp, const float* gamma, int dtype, int F, int H, int W,
+                       int C, int dim_head, int ph, int pw, int window, float eps, void* stream);
+int rvt_attn_block_bwd(const void* x, const void* dxmid, void* dx, void* dqkv, void* u_out, const float* ln_w,
+                       const float* ln_b, const void* wqkv, const float* bqkv, const void* wpg_t, float* dln_w, float* dln_b,
+                       int dtype, int F, int H, int W, int C, int dim_head, int ph, int pw, int window, float eps,
+                       void* stream);
+
 /* ConvLSTM cell with 1x1 conv (rnn.py:52-67): mix = [x|h_prev] Wp^T + bp with gate-interleaved rows
  * (row n' = (c/8)*32 + gate*8 + c%8, gates f,i,o,g); writes h_out [M][C], c_out [M][C] (float32) and,
  * if gates != NULL, the activated gates [M][4C] in natural order [f|i|o|g]. */

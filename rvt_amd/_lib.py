@@ -40,6 +40,8 @@ _SIGS = {
     'rvt_mlp_bwd_dgrad': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
     'rvt_attn_fwd': [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     'rvt_attn_bwd': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    'rvt_attn_block_fwd': [_vp] * 10 + [_i] * 9 + [_f, _vp],
+    'rvt_attn_block_bwd': [_vp] * 12 + [_i] * 9 + [_f, _vp],
     'rvt_lstm_fwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     'rvt_lstm_gates_bwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     'rvt_lstm_dgrad': [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
@@ -59,7 +61,7 @@ _SIGS = {
 }
 EXPORTS = sorted(list(_SIGS) + ['rvt_last_error', 'rvt_is_emulator', 'rvt_wgrad_workspace_floats',
                                'rvt_mlp_fused_supported', 'rvt_lstm_scan_supported', 'rvt_mlp_bwd_fused_supported',
-                               'rvt_mlp_bwd_fused_ws_floats'])
+                               'rvt_mlp_bwd_fused_ws_floats', 'rvt_attn_block_supported'])
 
 
 def _bind(lib: ctypes.CDLL) -> ctypes.CDLL:
@@ -77,6 +79,8 @@ def _bind(lib: ctypes.CDLL) -> ctypes.CDLL:
     lib.rvt_mlp_bwd_fused_supported.argtypes = [_i, _i]
     lib.rvt_mlp_bwd_fused_ws_floats.restype = ctypes.c_size_t
     lib.rvt_mlp_bwd_fused_ws_floats.argtypes = [_i, _i, _i]
+    lib.rvt_attn_block_supported.restype = ctypes.c_int
+    lib.rvt_attn_block_supported.argtypes = [_i, _i, _i, _i]
     lib.rvt_lstm_scan_supported.restype = ctypes.c_int
     lib.rvt_lstm_scan_supported.argtypes = [_i, _i]
     lib.rvt_wgrad_workspace_floats.restype = ctypes.c_size_t

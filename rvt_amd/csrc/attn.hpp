@@ -29,7 +29,7 @@ namespace rvt {
 // lgkmcnt (plus a compiler barrier) is all the synchronisation there is to do — no s_barrier across the workgroup.
 __device__ __forceinline__ void wave_lds_sync() {
 #ifdef RVT_EMU
-    __syncthreads();              // emulator: waves are fibers; every wave of the block reaches each sync point (uniform code)
+    emu::wave_barrier();          // emulator: lanes are fibers; the LDS hand-off is between the lanes of this wave only
 #else
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif

@@ -9,6 +9,7 @@
 #include "gemm.hpp"
 #include "rowops.hpp"
 #include "attn.hpp"
+#include "attn_block.hpp"
 #include "mlp.hpp"
 #include "events.hpp"
 #include "pack.hpp"
@@ -575,6 +576,79 @@ int rvt_attn_bwd(const void* qkv, const void* dout, void* dqkv, int dtype, int F
     if (make_attn_geom(g, F, H, W, C, dim_head, ph, pw, window)) return 1;
     DISPATCH_DTYPE(dtype, (launch_attn_any<T>(true, qkv, dout, dqkv, g, (hipStream_t)stream)));
     return check_launch("attn_bwd");
+}
+
+// ------------------------------------------------------------------------- fused attention half (csrc/attn_block.hpp)
+int rvt_attn_block_supported(int dtype, int C, int dim_head, int L) {
+    if (dim_head != 32 || C != 64 || L <= 32 || L > 96) return 0;
+    return dtype == RVT_BF16 || dtype == RVT_F32;
+}
+}  // extern "C"
+// waves per workgroup: what the LDS holds (weights + per-wave backward scratch)
+template <class T, int NB> struct AbWaves { static constexpr int V = sizeof(T) == 2 ? (NB == 2 ? 4 : 3) : 2; };
+template <class K> static int ab_grid(K kernel, int threads, int n_part, int wpb) {
+    static const int resident_override = getenv("RVT_AB_RESIDENT") ? atoi(getenv("RVT_AB_RESIDENT")) : 0;
+    const int per_cu = resident_per_cu(kernel, threads, 1);
+    const int want = (n_part + wpb - 1) / wpb;
+    return imax(1, imin(want, resident_override > 0 ? resident_override : 256 * per_cu));
+}
+template <class T, int NB, bool LN>
+static void launch_ab_fwd(const void* x, void* xmid, void* a_out, const float* ln_w, const float* ln_b, const void* wqkv,
+                          const float* bqkv, const void* wp, const float* bp, const float* gamma, const AttnGeom& g, float eps,
+                          hipStream_t st) {
+    constexpr int WPB = AbWaves<T, NB>::V;
+    auto k = attn_block_fwd_kernel<T, 64, NB, LN, WPB>;
+    hipLaunchKernelGGL(k, dim3(ab_grid(k, 64 * WPB, g.F * g.P, WPB)), dim3(64 * WPB), 0, st, (const T*)x, (T*)xmid, (T*)a_out, ln_w,
+                       ln_b, (const T*)wqkv, bqkv, (const T*)wp, bp, gamma, g, eps);
+}
+template <class T, int NB, bool LN>
+static void launch_ab_bwd(const void* x, const void* dxmid, void* dx, void* dqkv, void* u_out, const float* ln_w,
+                          const float* ln_b, const void* wqkv, const float* bqkv, const void* wpg_t, float* dln_w, float* dln_b,
+                          const AttnGeom& g, float eps, hipStream_t st) {
+    constexpr int WPB = AbWaves<T, NB>::V;
+    auto k = attn_block_bwd_kernel<T, 64, NB, LN, WPB>;
+    hipLaunchKernelGGL(k, dim3(ab_grid(k, 64 * WPB, g.F * g.P, WPB)), dim3(64 * WPB), 0, st, (const T*)x, (const T*)dxmid, (T*)dx,
+                       (T*)dqkv, (T*)u_out, ln_w, ln_b, (const T*)wqkv, bqkv, (const T*)wpg_t, dln_w, dln_b, g, eps);
+}
+extern "C" {
+int rvt_attn_block_fwd(const void* x, void* xmid, void* a_out, const float* ln_w, const float* ln_b, const void* wqkv,
+                       const float* bqkv, const void* wp, const float* bp, const float* gamma, int dtype, int F, int H, int W,
+                       int C, int dim_head, int ph, int pw, int window, float eps, void* stream) {
+    RVT_CHECK(rvt_attn_block_supported(dtype, C, dim_head, ph * pw), "attn_block_fwd: not built for dtype=%d C=%d dim_head=%d L=%d",
+              dtype, C, dim_head, ph * pw);
+    RVT_CHECK((ln_w == nullptr) == (ln_b == nullptr), "attn_block_fwd: ln_w and ln_b go together");
+    AttnGeom g;
+    if (make_attn_geom(g, F, H, W, C, dim_head, ph, pw, window)) return 1;
+    const int NB = (g.L + 31) / 32;
+    hipStream_t st = (hipStream_t)stream;
+#define RVT_AB_FWD(NBB, LNN) launch_ab_fwd<T, NBB, LNN>(x, xmid, a_out, ln_w, ln_b, wqkv, bqkv, wp, bp, gamma, g, eps, st)
+    DISPATCH_DTYPE(dtype, {
+        if (NB == 2) { if (ln_w) RVT_AB_FWD(2, true); else RVT_AB_FWD(2, false); }
+        else { if (ln_w) RVT_AB_FWD(3, true); else RVT_AB_FWD(3, false); }
+    });
+#undef RVT_AB_FWD
+    return check_launch("attn_block_fwd");
+}
+
+int rvt_attn_block_bwd(const void* x, const void* dxmid, void* dx, void* dqkv, void* u_out, const float* ln_w,
+                       const float* ln_b, const void* wqkv, const float* bqkv, const void* wpg_t, float* dln_w, float* dln_b,
+                       int dtype, int F, int H, int W, int C, int dim_head, int ph, int pw, int window, float eps,
+                       void* stream) {
+    RVT_CHECK(rvt_attn_block_supported(dtype, C, dim_head, ph * pw), "attn_block_bwd: not built for dtype=%d C=%d dim_head=%d L=%d",
+              dtype, C, dim_head, ph * pw);
+    RVT_CHECK((ln_w == nullptr) == (ln_b == nullptr), "attn_block_bwd: ln_w and ln_b go together");
+    RVT_CHECK(ln_w == nullptr || (dln_w != nullptr && dln_b != nullptr), "attn_block_bwd: LayerNorm gradients need dln_w / dln_b");
+    AttnGeom g;
+    if (make_attn_geom(g, F, H, W, C, dim_head, ph, pw, window)) return 1;
+    const int NB = (g.L + 31) / 32;
+    hipStream_t st = (hipStream_t)stream;
+#define RVT_AB_BWD(NBB, LNN) launch_ab_bwd<T, NBB, LNN>(x, dxmid, dx, dqkv, u_out, ln_w, ln_b, wqkv, bqkv, wpg_t, dln_w, dln_b, g, eps, st)
+    DISPATCH_DTYPE(dtype, {
+        if (NB == 2) { if (ln_w) RVT_AB_BWD(2, true); else RVT_AB_BWD(2, false); }
+        else { if (ln_w) RVT_AB_BWD(3, true); else RVT_AB_BWD(3, false); }
+    });
+#undef RVT_AB_BWD
+    return check_launch("attn_block_bwd");
 }
 
 // ---------------------------------------------------------------------------------------------- lstm

@@ -272,6 +272,36 @@ def attn_bwd(qkv: Tensor, dout: Tensor, F_: int, H: int, W: int, C: int, dh: int
     return d
 
 
+def attn_block_supported(dtype: torch.dtype, C: int, dh: int, n_tok: int) -> bool:
+    return dtype in L._DT and bool(L.get_lib().rvt_attn_block_supported(L.dtype_code(dtype), C, dh, n_tok))
+
+
+def attn_block_fwd(x: Tensor, ln_w: Optional[Tensor], ln_b: Optional[Tensor], wqkv: Tensor, bqkv: Tensor, wp: Tensor, bp: Tensor,
+                   gamma: Tensor, F_: int, H: int, W: int, C: int, dh: int, ph: int, pw: int, window: bool, eps: float,
+                   want_a: bool):
+    """Fused attention half (csrc/attn_block.hpp): xmid = x + gamma * (attention(LN1(x) wqkv^T + bqkv) wp^T + bp).
+    Returns (xmid, a) with a = the attention output rows (kept for the proj weight gradient) or None."""
+    xmid = torch.empty_like(x)
+    a = torch.empty_like(x) if want_a else None
+    L.call('rvt_attn_block_fwd', L.ptr(x), L.ptr(xmid), L.ptr(a), L.ptr(ln_w), L.ptr(ln_b), L.ptr(wqkv), L.ptr(bqkv), L.ptr(wp),
+           L.ptr(bp), L.ptr(gamma), L.dtype_code(x.dtype), F_, H, W, C, dh, ph, pw, int(window), float(eps), L.stream_of(x))
+    return xmid, a
+
+
+def attn_block_bwd(x: Tensor, dxmid: Tensor, ln_w: Optional[Tensor], ln_b: Optional[Tensor], wqkv: Tensor, bqkv: Tensor,
+                   wpg_t: Tensor, dln_w: Optional[Tensor], dln_b: Optional[Tensor], F_: int, H: int, W: int, C: int, dh: int,
+                   ph: int, pw: int, window: bool, eps: float):
+    """Backward of the fused attention half from (x, dxmid): returns (dx, dqkv, u) with u = LN1(x) (None without norm1:
+    then x itself is the operand of the qkv weight gradient); dln_w / dln_b are accumulated."""
+    dx = torch.empty_like(x)
+    dqkv = torch.empty((*x.shape[:-1], 3 * C), dtype=x.dtype, device=x.device)
+    u = torch.empty_like(x) if ln_w is not None else None
+    L.call('rvt_attn_block_bwd', L.ptr(x), L.ptr(dxmid), L.ptr(dx), L.ptr(dqkv), L.ptr(u), L.ptr(ln_w), L.ptr(ln_b), L.ptr(wqkv),
+           L.ptr(bqkv), L.ptr(wpg_t), L.ptr(dln_w), L.ptr(dln_b), L.dtype_code(x.dtype), F_, H, W, C, dh, ph, pw, int(window),
+           float(eps), L.stream_of(x))
+    return dx, dqkv, u
+
+
 def lstm_fwd(x: Tensor, h_prev: Tensor, c_prev: Tensor, w_perm: Tensor, b_perm: Tensor, h_out: Tensor, c_out: Tensor,
              gates: Optional[Tensor]) -> None:
     C = x.shape[-1]

@@ -46,6 +46,13 @@ def use_fused_mlp(dtype, C: int, what: str) -> bool:
     return C == 64 or (C == 128 and what.startswith('fwd'))
 
 
+def use_attn_block(dtype, C: int, dh: int, n_tok: int) -> bool:
+    """Attention half of a block (norm1, qkv, partition attention, proj, LayerScale + residual) as ONE kernel per direction
+    (csrc/attn_block.hpp, one wave per partition) instead of LayerNorm + linear + attention core + linear (+ their
+    backward chain): where it is built (C = 64, dim_head 32, partitions of 33..96 tokens).  RVT_ATTN_BLOCK=0 disables."""
+    return os.environ.get('RVT_ATTN_BLOCK', '1') != '0' and ops.attn_block_supported(dtype, C, dh, n_tok)
+
+
 def use_lstm_scan(dtype, C: int, dws) -> bool:
     """ConvLSTM with the time loop inside the kernel (csrc/lstm_scan.hpp) instead of one launch per step: only the 1x1-conv
     cell (dws_conv False — every shipped config); by default where the weights stay resident in LDS (C <= 64), C = 128
@@ -144,10 +151,17 @@ def stage_seq_forward(sw: StageWeights, g: StageGeom, inp: Tensor, h0: Optional[
 
     for pair in sw.blocks:
         for bw, window in ((pair[0], True), (pair[1], False)):
-            u = x if bw['n1_w'] is None else ops.layernorm_fwd(x, bw['n1_w'], bw['n1_b'], g.eps)
-            qkv = ops.linear_fwd(u, bw['qkv_w'], bw['qkv_b'])                     # maxvit.py:347
-            a = ops.attn_fwd(qkv, F_, H, W, C, g.dim_head, g.ph, g.pw, window)    # maxvit.py:349-352
-            xmid = ops.linear_scale_res_fwd(a, bw['proj_w'], bw['proj_b'], bw['g1'], x)        # :353, :268
+            if use_attn_block(dt, C, g.dim_head, g.ph * g.pw):
+                # maxvit.py:268 in one launch; backward recomputes q / k / v / P from the block input (nothing but `a`,
+                # the operand of the proj weight gradient, is kept)
+                xmid, a = ops.attn_block_fwd(x, bw['n1_w'], bw['n1_b'], bw['qkv_w'], bw['qkv_b'], bw['proj_w'], bw['proj_b'],
+                                             bw['g1'], F_, H, W, C, g.dim_head, g.ph, g.pw, window, g.eps, want_a=save)
+                u = qkv = None
+            else:
+                u = x if bw['n1_w'] is None else ops.layernorm_fwd(x, bw['n1_w'], bw['n1_b'], g.eps)
+                qkv = ops.linear_fwd(u, bw['qkv_w'], bw['qkv_b'])                     # maxvit.py:347
+                a = ops.attn_fwd(qkv, F_, H, W, C, g.dim_head, g.ph, g.pw, window)    # maxvit.py:349-352
+                xmid = ops.linear_scale_res_fwd(a, bw['proj_w'], bw['proj_b'], bw['g1'], x)        # :353, :268
             v2 = None
             if save and use_fused_mlp(dt, C, 'bwd_fused'):
                 # the backward recomputes everything from xmid: inference-flavoured forward, nothing else kept
@@ -336,6 +350,19 @@ def stage_seq_backward(sw: StageWeights, g: StageGeom, sv: StageSaved, dH: Optio
             def proj_wgrad_fn(dxmid=dxmid, s=s, bp=bp):
                 ops.linear_wgrad(dxmid, s['a'], G(bp + 'S1'), colsum_out=G(bp + 'cs1'))
             side.run(proj_wgrad_fn, dxmid, s['a'])
+            if s['qkv'] is None:
+                # fused: proj / attention / qkv input gradients and the norm1 backward in one launch (from the block input)
+                has_n1 = bw['n1_w'] is not None
+                dx, dqkv, u = ops.attn_block_bwd(s['xin'], dxmid, bw['n1_w'], bw['n1_b'], bw['qkv_w'], bw['qkv_b'], bw['proj_wt'],
+                                                 G(bp + 'norm1.weight') if has_n1 else None,
+                                                 G(bp + 'norm1.bias') if has_n1 else None, F_, H, W, C, g.dim_head, g.ph, g.pw,
+                                                 window, g.eps)
+                u = s['xin'] if u is None else u
+                def qkv_wgrad_fused_fn(dqkv=dqkv, u=u, bp=bp):
+                    ops.linear_wgrad(dqkv, u, G(bp + 'self_attn.qkv.weight'), colsum_out=G(bp + 'self_attn.qkv.bias'))
+                side.run(qkv_wgrad_fused_fn, dqkv, u)
+                del dqkv, dxmid, u
+                continue
             da = ops.linear_dgrad(dxmid, bw['proj_wt'])
             dqkv = ops.attn_bwd(s['qkv'], da, F_, H, W, C, g.dim_head, g.ph, g.pw, window)
             del da

@@ -37,6 +37,10 @@ CASES: Dict[str, dict] = {
                       T=5, B=2, gamma='default'),
     'tiny_gen1_gamma': dict(embed_dim=32, dim_head=32, partition_size=(8, 10), hw=(240, 304), in_res=(256, 320),
                             T=5, B=2, gamma='rand'),
+    # RVT-Base widths (stage 1: C = 64, two heads, 6x10 partitions = the fused attention-half kernels) at a resolution the
+    # CPU emulator of the kernel sources gets through: 48x80 tokens at stage 1, one partition per frame at stage 4
+    'base_qvga': dict(embed_dim=64, dim_head=32, partition_size=(6, 10), hw=(180, 300), in_res=(192, 320),
+                      T=2, B=1, gamma='rand'),
     # RVT-Base on the 1Mpx shape, reduced B*T so that the CPU oracle finishes in seconds
     'base_1mpx': dict(embed_dim=64, dim_head=32, partition_size=(6, 10), hw=(360, 640), in_res=(384, 640),
                       T=2, B=1, gamma='rand'),

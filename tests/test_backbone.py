@@ -12,7 +12,7 @@ from tests.harness import compare, load_golden, summarize
 
 UNSUPPORTED = set()
 EMU_CASES = ['micro', 'micro_default_gamma', 'micro_dh24', 'micro_mask', 'micro_nooverlap', 'micro_dws_hidden',
-             'micro_dws_xh']
+             'micro_dws_xh', 'base_qvga']
 ALL_CASES = [c for c in casegen.CASES if c not in UNSUPPORTED]
 
 

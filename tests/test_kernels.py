@@ -242,6 +242,64 @@ def test_attention(backend, dt, window, case):
     close(dq, qr.grad, dt, 'attn_bwd', mult=2.0)
 
 
+AB_CASES = [  # F, H, W, ph, pw   (C = 64, dim_head 32: two heads)
+    (2, 12, 20, 6, 10),            # L=60 (two 32-token blocks), 1 Mpx partition, 4 partitions per frame
+    (1, 8, 20, 8, 10),             # L=80 (three blocks), Gen1 partition
+    (3, 6, 10, 6, 10),             # one partition per frame; more partitions than one workgroup's waves
+]
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+@pytest.mark.parametrize('window,ln', [(True, False), (False, True), (True, True)])
+@pytest.mark.parametrize('case', AB_CASES)
+def test_attn_block_fused(backend, dt, window, ln, case):
+    """Fused attention half (csrc/attn_block.hpp) against an fp64 autograd restatement of maxvit.py:229,268,343-354."""
+    Fr, H, W, ph, pw = case
+    C, dh, eps = 64, 32, 1e-5
+    assert ops.attn_block_supported(dt, C, dh, ph * pw)
+    x = rnd((Fr, H, W, C), backend, dt, 1)
+    dxm = rnd((Fr, H, W, C), backend, dt, 2)
+    ln_w = (1.0 + 0.3 * rnd((C,), backend, torch.float32, 3)) if ln else None
+    ln_b = 0.2 * rnd((C,), backend, torch.float32, 4) if ln else None
+    wqkv32 = rnd((3 * C, C), backend, torch.float32, 5, C ** -0.5)
+    bqkv = 0.3 * rnd((3 * C,), backend, torch.float32, 6)
+    wp32 = rnd((C, C), backend, torch.float32, 7, C ** -0.5)
+    bp = 0.3 * rnd((C,), backend, torch.float32, 8)
+    gamma = 0.5 + rnd((C,), backend, torch.float32, 9).abs()
+    wqkv, wp = wqkv32.to(dt), wp32.to(dt)
+    wpg_t = (wp32 * gamma[:, None]).t().contiguous().to(dt)
+
+    xmid, a = ops.attn_block_fwd(x, ln_w, ln_b, wqkv, bqkv, wp, bp, gamma, Fr, H, W, C, dh, ph, pw, window, eps, want_a=True)
+    xmid2, a2 = ops.attn_block_fwd(x, ln_w, ln_b, wqkv, bqkv, wp, bp, gamma, Fr, H, W, C, dh, ph, pw, window, eps, want_a=False)
+    assert a2 is None and torch.equal(xmid, xmid2)
+
+    xr = f64(x).requires_grad_(True)
+    lw = f64(ln_w).requires_grad_(True) if ln else None
+    lb = f64(ln_b).requires_grad_(True) if ln else None
+    u_r = F.layer_norm(xr, (C,), lw, lb, eps) if ln else xr
+    u_r.retain_grad()
+    qkv_r = u_r @ f64(wqkv).t() + f64(bqkv)
+    qkv_r.retain_grad()
+    a_r = ref_attention(qkv_r, Fr, H, W, C, dh, ph, pw, window)
+    wpg = (f64(wpg_t).t() / f64(gamma)[:, None])          # = the (rounded) proj weight the backward kernel sees
+    xmid_r = xr + f64(gamma) * (a_r @ f64(wp).t() + f64(bp))
+    close(a, a_r, dt, 'attn_block a')
+    close(xmid, xmid_r, dt, 'attn_block xmid')
+    xmid_r.backward(f64(dxm))
+
+    dln_w = torch.zeros(C, dtype=torch.float32, device=backend) if ln else None
+    dln_b = torch.zeros(C, dtype=torch.float32, device=backend) if ln else None
+    dx, dqkv, u = ops.attn_block_bwd(x, dxm, ln_w, ln_b, wqkv, bqkv, wpg_t, dln_w, dln_b, Fr, H, W, C, dh, ph, pw, window, eps)
+    close(dqkv, qkv_r.grad, dt, 'attn_block dqkv', mult=2.0)
+    close(dx, xr.grad, dt, 'attn_block dx', mult=2.0)
+    if ln:
+        close(u, u_r, dt, 'attn_block u')
+        close(dln_w, lw.grad, dt, 'attn_block dln_w', mult=4.0)
+        close(dln_b, lb.grad, dt, 'attn_block dln_b', mult=4.0)
+    else:
+        assert u is None
+
+
 @pytest.mark.parametrize('dt', DTYPES)
 @pytest.mark.parametrize('M,C', [(150, 16), (70, 72)])
 def test_lstm_cell(backend, dt, M, C):
