@@ -1,0 +1,9 @@
+#!/bin/bash
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/${1:-r2f}
+mkdir -p $OUT
+cd $ROOT
+timeout 1500 python -m pytest tests -m gpu -q -x --durations=5 2>&1 | tail -12 > $OUT/pytest.log
+cat $OUT/pytest.log
+timeout 400 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --op-breakdown $OUT/op_breakdown.txt > $OUT/bench_base.json 2> $OUT/bench_base.err
+tail -2 $OUT/bench_base.err; cat $OUT/bench_base.json; head -36 $OUT/op_breakdown.txt

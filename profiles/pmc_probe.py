@@ -47,6 +47,35 @@ elif op in ('mlp_fwd', 'mlp_bwd'):
         dy, dlw, dlb = rnd(M, C), torch.zeros(C, device=dev), torch.zeros(C, device=dev)
         w2gt, w1t = w2.t().contiguous(), w1.t().contiguous()
         fn = lambda: ops.mlp_bwd_dgrad(dy, dy4, x, lw, w2gt, w1t, dlw, dlb, 1e-5)
+elif op in ('mlpc_fwd', 'mlpc_dgrad', 'mlpc_wgrad'):      # recompute MLP route (csrc/mlp_chain.hpp unless RVT_MLP_CHAIN=0)
+    lw, lb = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    w1, w2 = rnd(4 * C, C) * 0.1, rnd(C, 4 * C) * 0.1
+    b1, b2, gam = torch.zeros(4 * C, device=dev), torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    dy = rnd(M, C)
+    w2gt, w1t = w2.t().contiguous(), w1.t().contiguous()
+    z = lambda *s: torch.zeros(*s, device=dev)
+    dlw, dlb, dw1, db1, s2, cs2 = z(C), z(C), z(4 * C, C), z(4 * C), z(C, 4 * C), z(C)
+    del dy4
+    if op == 'mlpc_fwd':
+        fn = lambda: ops.mlp_fwd(x, lw, lb, w1, b1, w2, b2, gam, 1e-5, want_grad=False)
+    elif op == 'mlpc_dgrad':
+        fn = lambda: ops.mlp_bwd_recompute_dgrad(dy, x, lw, lb, w1, b1, w2gt, w1t, dlw, dlb, 1e-5)
+    else:
+        fn = lambda: ops.mlp_bwd_recompute_wgrad(dy, x, lw, lb, w1, b1, w2gt, dw1, db1, s2, cs2, 1e-5)
+elif op in ('ab_fwd', 'ab_bwd', 'ab_fwd_ln', 'ab_bwd_ln'):      # fused attention half (csrc/attn_block.hpp), stage-1 window block
+    F_, H, W = 504, 96, 160
+    del dy4
+    ln = op.endswith('_ln')
+    lw, lb = (torch.ones(C, device=dev), torch.zeros(C, device=dev)) if ln else (None, None)
+    wqkv, wp = rnd(3 * C, C) * 0.125, rnd(C, C) * 0.125
+    bqkv, bp, gam = torch.zeros(3 * C, device=dev), torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    x4 = x.view(F_, H, W, C)
+    if op.startswith('ab_fwd'):
+        fn = lambda: ops.attn_block_fwd(x4, lw, lb, wqkv, bqkv, wp, bp, gam, F_, H, W, C, 32, 6, 10, True, 1e-5, True)
+    else:
+        dxm = rnd(F_, H, W, C)
+        dlw, dlb = (torch.zeros(C, device=dev), torch.zeros(C, device=dev)) if ln else (None, None)
+        fn = lambda: ops.attn_block_bwd(x4, dxm, lw, lb, wqkv, bqkv, wp.t().contiguous(), dlw, dlb, F_, H, W, C, 32, 6, 10, True, 1e-5)
 for _ in range(3):
     fn()
 torch.cuda.synchronize()

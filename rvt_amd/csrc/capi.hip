@@ -11,6 +11,7 @@
 #include "attn.hpp"
 #include "attn_block.hpp"
 #include "mlp.hpp"
+#include "mlp_chain.hpp"
 #include "events.hpp"
 #include "pack.hpp"
 #include "lstm_scan.hpp"
@@ -251,6 +252,9 @@ int rvt_layernorm_bwd(const void* x, const float* w, const void* dy, const void*
     int G = pow2_ge(C / 8);
     int rows_per_block = 4 * (64 / G);
     int grid = imin(2048, imax(1, (rows + rows_per_block - 1) / rows_per_block));     // 8 workgroups (32 waves) per CU
+    // (parameter gradients: one device atomic per column per workgroup.  Measured on MI355X against per-workgroup partial rows +
+    // a column-sum fold: 0.90 / 0.42 / 0.21 / 0.12 ms vs 0.99 / 0.43 / 0.22 / 0.14 ms at the four RVT-Base stage shapes,
+    // profiles/r2/microbench_ln.txt — the kernel is HBM-bound at 4-4.6 TB/s either way)
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ln_bwd_kernel<T>), dim3(grid), dim3(256), 0, st, (const T*)x, w,
                                              (const T*)dy, (const T*)dres, (T*)dx, dw, db, rows, C, G, eps));
     return check_launch("layernorm_bwd");
@@ -394,6 +398,23 @@ template <class K> static int mlp_grid(K kernel, int M, int tm) {
     const int per_cu = resident_per_cu(kernel, 256, 2);
     return imax(1, imin(n_tiles, resident_override > 0 ? resident_override : 256 * per_cu));
 }
+// register-chained MLP kernels (csrc/mlp_chain.hpp): C == 64; RVT_MLP_CHAIN=0 falls back to the LDS-staged kernels of mlp.hpp
+static bool mlp_chain_on(int dtype, int C) {
+    static const int off = getenv("RVT_MLP_CHAIN") ? atoi(getenv("RVT_MLP_CHAIN")) == 0 : 0;
+    return !off && C == 64 && (dtype == RVT_BF16 || dtype == RVT_F32);
+}
+template <class T> struct McWaves { static constexpr int V = sizeof(T) == 2 ? 8 : 4; };
+template <class K> static int mc_grid(K kernel, int threads, int M, int wpb) {
+    static const int resident_override = getenv("RVT_MC_RESIDENT") ? atoi(getenv("RVT_MC_RESIDENT")) : 0;
+    const int per_cu = resident_per_cu(kernel, threads, 1);
+    const int want = ((M + 31) / 32 + wpb - 1) / wpb;
+    return imax(1, imin(want, resident_override > 0 ? resident_override : 256 * per_cu));
+}
+template <class T> static int mc_wgrad_grid(int M) {
+    auto k = mlpc_bwd_wgrad_kernel<T, 64>;
+    const int per_cu = resident_per_cu(k, 512, 1);
+    return imax(1, imin((M + 31) / 32, 256 * per_cu));
+}
 extern "C" {
 
 int rvt_mlp_fwd(const void* xmid, void* xout, void* g_out, void* gp_out, void* v2_out, const float* ln_w, const float* ln_b,
@@ -402,6 +423,16 @@ int rvt_mlp_fwd(const void* xmid, void* xout, void* g_out, void* gp_out, void* v
     RVT_CHECK(rvt_mlp_fused_supported(dtype, C), "mlp_fwd: fused MLP not built for dtype=%d C=%d", dtype, C);
     RVT_CHECK((g_out == nullptr) == (gp_out == nullptr), "mlp_fwd: g_out and gp_out go together");
     hipStream_t st = (hipStream_t)stream;
+    if (g_out == nullptr && v2_out == nullptr && mlp_chain_on(dtype, C)) {
+        // nothing to save: the register-chained kernel (csrc/mlp_chain.hpp)
+        DISPATCH_DTYPE(dtype, {
+            constexpr int WPB = McWaves<T>::V;
+            auto k = mlpc_fwd_kernel<T, 64, WPB>;
+            hipLaunchKernelGGL(k, dim3(mc_grid(k, 64 * WPB, M, WPB)), dim3(64 * WPB), 0, st, (const T*)xmid, (T*)xout, ln_w, ln_b,
+                               (const T*)w1, b1, (const T*)w2, b2, gamma, M, eps);
+        });
+        return check_launch("mlp_fwd(chain)");
+    }
     const int tm = mlp_tm(dtype, C);
 #define RVT_MLP_FWD(TT, CC, TMM)                                                                                           \
     hipLaunchKernelGGL((mlp_fwd_kernel<TT, CC, TMM>), dim3(mlp_grid(mlp_fwd_kernel<TT, CC, TMM>, M, tm)), dim3(256), 0, st, \
@@ -464,6 +495,8 @@ size_t rvt_mlp_bwd_fused_ws_floats(int dtype, int C, int M) {
     size_t grid = dtype == RVT_BF16 ? mlp_bwd_fused_grid<bf16, 0>(M) : mlp_bwd_fused_grid<float, 0>(M);
     const size_t g2 = dtype == RVT_BF16 ? mlp_bwd_fused_grid<bf16, 2>(M) : mlp_bwd_fused_grid<float, 2>(M);
     if (g2 > grid) grid = g2;
+    const size_t g3 = dtype == RVT_BF16 ? mc_wgrad_grid<bf16>(M) : mc_wgrad_grid<float>(M);
+    if (g3 > grid) grid = g3;
     return grid * ((size_t)2 * 4 * C * C + 2 * 4 * C + C);
 }
 
@@ -488,6 +521,15 @@ int rvt_mlp_bwd_recompute_dgrad(const void* dxout, const void* xmid, void* dxmid
                                 float* dln_b, int dtype, int M, int C, float eps, void* stream) {
     RVT_CHECK(rvt_mlp_bwd_fused_supported(dtype, C), "mlp_bwd_recompute_dgrad: not built for dtype=%d C=%d", dtype, C);
     hipStream_t st = (hipStream_t)stream;
+    if (mlp_chain_on(dtype, C)) {
+        DISPATCH_DTYPE(dtype, {
+            constexpr int WPB = McWaves<T>::V;
+            auto k = mlpc_bwd_dgrad_kernel<T, 64, WPB>;
+            hipLaunchKernelGGL(k, dim3(mc_grid(k, 64 * WPB, M, WPB)), dim3(64 * WPB), 0, st, (const T*)dxout, (const T*)xmid,
+                               (T*)dxmid, ln_w, ln_b, (const T*)w1, b1, (const T*)w2g_t, dln_w, dln_b, M, eps);
+        });
+        return check_launch("mlp_bwd_recompute_dgrad(chain)");
+    }
     DISPATCH_DTYPE(dtype, {
         const int grid = mlp_bwd_fused_grid<T, 1>(M);
         hipLaunchKernelGGL((mlp_bwd_fused_kernel<T, 64, 1>), dim3(grid), dim3(256), 0, st, (const T*)dxout, (const T*)xmid, (T*)dxmid,
@@ -503,6 +545,18 @@ int rvt_mlp_bwd_recompute_wgrad(const void* dxout, const void* xmid, const float
     RVT_CHECK(ws != nullptr && M >= 1, "mlp_bwd_recompute_wgrad: workspace required");
     hipStream_t st = (hipStream_t)stream;
     int grid = 0;
+    // (measured on MI355X, 7.74 M tokens: the chunk-per-wave weight-gradient kernel re-reads its rows once per wave —
+    // 7 GB fetched for 2 GB of input, 4.85 ms against 2.85 ms for the LDS-tile kernel; opt-in until its loads are shared)
+    static const int chain_wgrad = getenv("RVT_MLP_CHAIN_WGRAD") ? atoi(getenv("RVT_MLP_CHAIN_WGRAD")) : 0;
+    if (chain_wgrad && mlp_chain_on(dtype, C)) {
+        DISPATCH_DTYPE(dtype, {
+            grid = mc_wgrad_grid<T>(M);
+            hipLaunchKernelGGL((mlpc_bwd_wgrad_kernel<T, 64>), dim3(grid), dim3(512), 0, st, (const T*)dxout, (const T*)xmid, ln_w,
+                               ln_b, (const T*)w1, b1, (const T*)w2g_t, ws, M, eps);
+        });
+        mlp_fold_partials(ws, grid, C, dw1, db1, s2, cs2, st);
+        return check_launch("mlp_bwd_recompute_wgrad(chain)");
+    }
     DISPATCH_DTYPE(dtype, {
         grid = mlp_bwd_fused_grid<T, 2>(M);
         hipLaunchKernelGGL((mlp_bwd_fused_kernel<T, 64, 2>), dim3(grid, 2), dim3(256), 0, st, (const T*)dxout, (const T*)xmid,

@@ -1,0 +1,498 @@
+// MLP half of a block (reference maxvit.py:269 with the MLP of :100-118) with the data flow kept in REGISTERS:
+//
+//     xout = xmid + gamma2 * ( GELU( LN2(xmid) W1^T + b1 ) W2^T + b2 )
+//
+// Same accumulator-to-operand chaining as the attention half (attn_block.hpp): ONE WAVE owns 32 token rows, read from HBM
+// directly in MFMA-operand form (lane = row, 16 bytes per k-step; LayerNorm statistics = in-lane sums + one lane^32
+// exchange).  Per 32-column hidden chunk
+//     h^T = W1_j v2^T                     (A = weight rows, B = token rows)  -> accumulator: col = token, registers = hidden j
+//     GELU / GELU' in the accumulator registers
+//     out^T += W2[:, j] g^T               (B = g straight from the registers; W2 columns staged in accumulator order)
+// so nothing but the weight panels ever touches LDS and the waves of a workgroup never synchronise.  The fused kernels of
+// mlp.hpp move every hidden chunk through LDS twice (fp32 staging + operand tile) behind three workgroup barriers.
+//
+//   mlpc_fwd_kernel        reads xmid, writes xout                                       (nothing saved: backward recomputes)
+//   mlpc_bwd_dgrad_kernel  reads dxout, xmid; writes dxmid = dxout + LN2'(dh W1), dh = (dxout (W2 gamma)) * GELU'(h)
+//   mlpc_bwd_wgrad_kernel  reads dxout, xmid; accumulates dW1, db1, S2 = dxout^T g, cs2 in registers across its persistent
+//                          tile walk: wave w of a workgroup owns hidden chunk w, the
+//                          products are computed N-form (A = token rows) so that the hidden index sits in the lanes and the
+//                          tokens in the registers = the contraction index of the weight gradients, and the token-major
+//                          operands v2 / dxout are transposed by an MFMA with an identity operand (exact; the matrix pipe is idle).
+#pragma once
+#include "common.hpp"
+#include "attn_block.hpp"
+
+namespace rvt {
+
+// stage a row-major [rows][K] weight matrix into an LDS operand matrix; PERM: 32-column blocks in accumulator order
+template <class T, int K, bool PERM>
+__device__ __forceinline__ void chain_stage_weights(char* dst, const T* __restrict__ src, int rows, int tid, int nthreads) {
+    constexpr int FPR = K / 8;
+    for (int f = tid; f < rows * FPR; f += nthreads) {
+        const int row = f / FPR, fcg = f % FPR;
+        frag_t<T> v;
+        if (!PERM) {
+            v = frag_load<T>(src + (size_t)row * K + fcg * 8);
+        } else {
+            const int blk = fcg >> 2, q = (fcg >> 1) & 1, half = fcg & 1;
+            const T* p = src + (size_t)row * K + blk * 32 + 16 * q + 4 * half;
+#pragma unroll
+            for (int e = 0; e < 4; e++) { v[e] = p[e]; v[4 + e] = p[8 + e]; }
+        }
+        opm_store_frag<T>(dst, rows, row, fcg, v);
+    }
+}
+
+// exact-erf GELU / GELU' (common.hpp) on the 16 accumulator registers of a block, two values per packed instruction
+__device__ __forceinline__ void gelu_acc(const f32x16& h, float (&g)[16]) {
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+        const f32x2 v = {h[i], h[i + 1]};
+        const f32x2 av = {fabsf(v[0]), fabsf(v[1])};
+        const f32x2 d = fma2(av, f32x2{0.23164189f, 0.23164189f}, f32x2{1.0f, 1.0f});
+        const f32x2 t = {fast_rcp(d[0]), fast_rcp(d[1])};
+        const f32x2 a = v * v * -0.72134752044448170f;
+        const f32x2 e = {fast_exp2(a[0]), fast_exp2(a[1])};
+        f32x2 poly = fma2(t, f32x2{0.5307027145f, 0.5307027145f}, f32x2{-0.7265760135f, -0.7265760135f});
+        poly = fma2(t, poly, f32x2{0.7107068705f, 0.7107068705f});
+        poly = fma2(t, poly, f32x2{-0.142248368f, -0.142248368f});
+        poly = fma2(t, poly, f32x2{0.127414796f, 0.127414796f});
+        const f32x2 q = (t * poly) * e;
+        const f32x2 omq = 1.0f - q;
+        const f32x2 c = {v[0] < 0.0f ? q[0] : omq[0], v[1] < 0.0f ? q[1] : omq[1]};
+        const f32x2 gg = v * c;
+        g[i] = gg[0]; g[i + 1] = gg[1];
+    }
+}
+__device__ __forceinline__ void gelu_both_acc(const f32x16& h, float (&g)[16], float (&gp)[16]) {
+#pragma unroll
+    for (int i = 0; i < 16; i += 8) {
+        float x8[8], g8[8], p8[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) x8[e] = h[i + e];
+        gelu_both_8(x8, g8, p8);
+#pragma unroll
+        for (int e = 0; e < 8; e++) { g[i + e] = g8[e]; gp[i + e] = p8[e]; }
+    }
+}
+
+// ---- GELU through an LDS table --------------------------------------------------------------------------------------
+// The exact-erf GELU costs ~24 VALU-issue slots per element (two quarter-rate transcendentals) and these kernels are
+// VALU-bound on it (SQ counters: VALU 72 % of SIMD time, MFMA 15 %), while the LDS pipe is almost idle.  Phi(x) and
+// GELU'(x) = Phi(x) + x phi(x) are smooth and bounded, so each is tabulated at GELU_LUT_N points of [-X, X] as
+// (value, forward difference) pairs and evaluated by ONE 8-byte LDS gather plus a linear interpolation: 7 VALU slots.
+// Interpolation error <= h^2/8 max|f"| = 4e-6 (h = 2X / N = 0.0117; max|Phi"| = 0.24, max of the second derivative of
+// GELU' ~ 0.5) - three orders below the 1e-3 parity bar; beyond |x| = X both functions are at their limits to 1e-9.
+// The table is filled per workgroup from the A&S 7.1.26 evaluation of common.hpp (|err| <= 1.5e-7).
+constexpr int GELU_LUT_N = 1024;
+constexpr float GELU_LUT_X = 6.0f;
+constexpr int GELU_LUT_BYTES = GELU_LUT_N * 8;
+template <bool GRAD> __device__ __forceinline__ void gelu_lut_fill(float* lut, int tid, int nthreads) {
+    const float h = 2.0f * GELU_LUT_X / (float)GELU_LUT_N;
+    for (int i = tid; i < GELU_LUT_N; i += nthreads) {
+        const float x0 = -GELU_LUT_X + h * (float)i, x1 = x0 + h;
+        float e0, e1;
+        float f0 = gelu_phi(x0, e0), f1 = gelu_phi(x1, e1);
+        if (GRAD) { f0 = fmaf(x0 * 0.3989422804014327f, e0, f0); f1 = fmaf(x1 * 0.3989422804014327f, e1, f1); }
+        lut[2 * i] = f0;
+        lut[2 * i + 1] = f1 - f0;
+    }
+}
+// table values at the 16 accumulator registers of a block: Phi (GRAD = false table) or GELU' (GRAD = true table).  Three
+// phases — all indices, all gathers, all interpolations — so that the sixteen LDS round trips overlap instead of each
+// being waited for in turn (two waves per SIMD do not hide a dependent gather chain).
+__device__ __forceinline__ void gelu_lut_eval16(const float* lut, const f32x16& x, float (&out)[16]) {
+    const float s = (float)GELU_LUT_N / (2.0f * GELU_LUT_X);
+    float fr[16];
+    const f32x2* p[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        float t = fmaf(x[r], s, GELU_LUT_X * s);
+        t = fminf(fmaxf(t, 0.0f), (float)GELU_LUT_N - 0.001f);
+        const float fl = floorf(t);
+        fr[r] = t - fl;
+        p[r] = reinterpret_cast<const f32x2*>(lut) + (int)fl;
+    }
+    sched_fence();
+    f32x2 ab[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) ab[r] = *p[r];
+    sched_fence();
+#pragma unroll
+    for (int r = 0; r < 16; r++) out[r] = fmaf(fr[r], ab[r][1], ab[r][0]);
+}
+
+template <class T, int C> struct McSmem {
+    static constexpr int KT = C / TileGeom<T>::BK, HID = 4 * C;
+    static constexpr int W_1 = KT * HID * 128;                     // [4C rows][C]
+    static constexpr int W_2 = (HID / TileGeom<T>::BK) * C * 128;  // [C rows][4C]   (forward: W2, columns in accumulator order)
+    static constexpr int K_LNW = 0, K_LNB = C, K_B2 = 2 * C, K_GAM = 3 * C, K_B1 = 4 * C, NCONST = 8 * C;
+};
+
+// one token row per lane (row = tile * 32 + lane & 31) in operand form; LayerNorm in place
+template <class T, int C>
+__device__ __forceinline__ void mc_load_row(frag_t<T> (&f)[C / 16], const T* __restrict__ src, int row, bool valid, int half) {
+#pragma unroll
+    for (int ks = 0; ks < C / 16; ks++) {
+        const frag_t<T> v = frag_load<T>(src + (size_t)(valid ? row : 0) * C + (2 * ks + half) * 8);
+        const frag_t<T> z = frag_zero<T>();
+        f[ks] = valid ? v : z;
+    }
+}
+template <class T, int C>
+__device__ __forceinline__ void mc_layernorm(const frag_t<T> (&xf)[C / 16], frag_t<T> (&uf)[C / 16], const float* k_lnw,
+                                              const float* k_lnb, bool valid, int half, float eps, float& mean, float& rstd) {
+    constexpr int KS = C / 16;
+    float s = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) s += (float)xf[ks][e];
+    s += __shfl_xor(s, 32);
+    mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) { const float d = (float)xf[ks][e] - mean; q += d * d; }
+    q += __shfl_xor(q, 32);
+    rstd = 1.0f / sqrtf(q / (float)C + eps);
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) {
+        float w[8], bb[8];
+        load_cols<8>(k_lnw, 16 * ks + 8 * half, w);
+        load_cols<8>(k_lnb, 16 * ks + 8 * half, bb);
+        frag_t<T> o;
+#pragma unroll
+        for (int e = 0; e < 8; e++) o[e] = (T)(valid ? ((float)xf[ks][e] - mean) * rstd * w[e] + bb[e] : 0.f);
+        uf[ks] = o;
+    }
+}
+
+// ===================================================================================================== forward
+template <class T, int C, int WPB>
+__global__ void __launch_bounds__(64 * WPB)
+mlpc_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                const T* __restrict__ W1, const float* __restrict__ b1, const T* __restrict__ W2, const float* __restrict__ b2,
+                const float* __restrict__ gamma, int M, float eps) {
+    typedef McSmem<T, C> S;
+    constexpr int KS = C / 16, NCB = C / 32, HID = 4 * C, NJC = HID / 32;
+    __shared__ __attribute__((aligned(16))) char smem[S::W_1 + S::W_2 + S::NCONST * 4 + GELU_LUT_BYTES];
+    char* const W1_l = smem;
+    char* const W2_l = smem + S::W_1;
+    float* const kst = reinterpret_cast<float*>(smem + S::W_1 + S::W_2);
+    float* const lut = kst + S::NCONST;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, half = lane >> 5, wave = tid >> 6;
+    gelu_lut_fill<false>(lut, tid, 64 * WPB);
+    chain_stage_weights<T, C, false>(W1_l, W1, HID, tid, 64 * WPB);
+    chain_stage_weights<T, HID, true>(W2_l, W2, C, tid, 64 * WPB);
+    for (int i = tid; i < C; i += 64 * WPB) {
+        kst[S::K_LNW + i] = ln_w[i]; kst[S::K_LNB + i] = ln_b[i]; kst[S::K_B2 + i] = b2[i]; kst[S::K_GAM + i] = gamma[i];
+    }
+    for (int i = tid; i < HID; i += 64 * WPB) kst[S::K_B1 + i] = b1[i];
+    __syncthreads();
+
+    const int n_tiles = (M + 31) / 32;
+    for (int tile = blockIdx.x * WPB + wave; tile < n_tiles; tile += gridDim.x * WPB) {
+        const int row = tile * 32 + li;
+        const bool valid = row < M;
+        frag_t<T> xf[KS], uf[KS];
+        mc_load_row<T, C>(xf, xmid, row, valid, half);
+        float mean, rstd;
+        mc_layernorm<T, C>(xf, uf, kst + S::K_LNW, kst + S::K_LNB, valid, half, eps, mean, rstd);
+        f32x16 oacc[NCB];
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) acc_zero(oacc[cb]);
+#pragma unroll 2
+        for (int jc = 0; jc < NJC; jc++) {
+            f32x16 h;
+            acc_zero(h);
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) mma32(h, opm_load_frag<T>(W1_l, HID, 32 * jc + li, 2 * ks + half), uf[ks]);
+            acc_add_rows(h, kst + S::K_B1 + 32 * jc, half);
+            float g[16];
+            gelu_lut_eval16(lut, h, g);
+#pragma unroll
+            for (int r = 0; r < 16; r++) g[r] *= h[r];
+            frag_t<T> gf[2];
+            gf[0] = arr_slot_frag<T>(g, 0);
+            gf[1] = arr_slot_frag<T>(g, 1);
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb++)
+#pragma unroll
+                for (int q = 0; q < 2; q++)
+                    mma32(oacc[cb], opm_load_frag<T>(W2_l, C, cb * 32 + li, 4 * jc + 2 * q + half), gf[q]);
+        }
+        // LayerScale + residual (maxvit.py:51-53,269); the raw row pieces are still in registers
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) {
+            float r8[2][8];
+            acc_to_rows(oacc[cb], r8);
+#pragma unroll
+            for (int m = 0; m < 2; m++) {
+                const int ks = 2 * cb + m;
+                float res[8], gam[8], b2v[8], o[8];
+                frag_to_float<T>(xf[ks], res);
+                load_cols<8>(kst + S::K_GAM, 16 * ks + 8 * half, gam);
+                load_cols<8>(kst + S::K_B2, 16 * ks + 8 * half, b2v);
+#pragma unroll
+                for (int e = 0; e < 8; e++) o[e] = res[e] + gam[e] * (r8[m][e] + b2v[e]);
+                if (valid) frag_store<T>(xout + (size_t)row * C + (2 * ks + half) * 8, frag_from_float<T>(o));
+            }
+        }
+    }
+}
+
+// ============================================================================ backward: input-gradient chain
+// dh[m][j] = (dxout (W2 gamma))[m][j] * GELU'(h[m][j]);  dv2 = dh W1;  dxmid = dxout + LN2'(dv2; xmid);  dln_w / dln_b += .
+// W2gT = (W2 * gamma[:, None])^T stored [4C][C].  dv2^T's A operand (rows c, contraction over j) comes out of the ONE LDS
+// image of W1 through the transposing LDS read, in accumulator order.
+template <class T, int C, int WPB>
+__global__ void __launch_bounds__(64 * WPB)
+mlpc_bwd_dgrad_kernel(const T* __restrict__ dxout, const T* __restrict__ xmid, T* __restrict__ dxmid,
+                      const float* __restrict__ ln_w, const float* __restrict__ ln_b, const T* __restrict__ W1,
+                      const float* __restrict__ b1, const T* __restrict__ W2gT, float* __restrict__ dln_w,
+                      float* __restrict__ dln_b, int M, float eps) {
+    typedef McSmem<T, C> S;
+    constexpr int KS = C / 16, NCB = C / 32, HID = 4 * C, NJC = HID / 32;
+    __shared__ __attribute__((aligned(16))) char smem[2 * S::W_1 + S::NCONST * 4 + GELU_LUT_BYTES];
+    char* const W1_l = smem;
+    char* const W2_l = smem + S::W_1;                                // (W2 gamma)^T: [4C rows][C]
+    float* const kst = reinterpret_cast<float*>(smem + 2 * S::W_1);
+    float* const lut = kst + S::NCONST;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, half = lane >> 5, wave = tid >> 6;
+    gelu_lut_fill<true>(lut, tid, 64 * WPB);
+    chain_stage_weights<T, C, false>(W1_l, W1, HID, tid, 64 * WPB);
+    chain_stage_weights<T, C, false>(W2_l, W2gT, HID, tid, 64 * WPB);
+    for (int i = tid; i < C; i += 64 * WPB) { kst[S::K_LNW + i] = ln_w[i]; kst[S::K_LNB + i] = ln_b[i]; }
+    for (int i = tid; i < HID; i += 64 * WPB) kst[S::K_B1 + i] = b1[i];
+    __syncthreads();
+
+    // LayerNorm parameter gradients = column sums over tokens of dv2 * xhat and dv2.  The row pieces hold tokens in the LANES;
+    // an MFMA against an identity operand turns a piece block into "col = channel, registers = tokens" (exact), where the
+    // column sum is an in-lane sum: one accumulator per 32-channel block instead of 2 x 32 per-lane partial sums.
+    frag_t<T> idf[2];
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) idf[m][e] = (T)((16 * m + 8 * half + e == li) ? 1.0f : 0.0f);
+    float aw[NCB], ab[NCB];                                          // dln_w / dln_b of channel 32 cb + (lane & 31), this half's tokens
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) { aw[cb] = 0.f; ab[cb] = 0.f; }
+
+    const int n_tiles = (M + 31) / 32;
+    for (int tile = blockIdx.x * WPB + wave; tile < n_tiles; tile += gridDim.x * WPB) {
+        const int row = tile * 32 + li;
+        const bool valid = row < M;
+        frag_t<T> xf[KS], uf[KS], df[KS];
+        mc_load_row<T, C>(xf, xmid, row, valid, half);
+        mc_load_row<T, C>(df, dxout, row, valid, half);
+        float mean, rstd;
+        mc_layernorm<T, C>(xf, uf, kst + S::K_LNW, kst + S::K_LNB, valid, half, eps, mean, rstd);
+        f32x16 dacc[NCB];
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) acc_zero(dacc[cb]);
+#pragma unroll 2
+        for (int jc = 0; jc < NJC; jc++) {
+            f32x16 h, dg;
+            acc_zero(h);
+            acc_zero(dg);
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) {
+                mma32(h, opm_load_frag<T>(W1_l, HID, 32 * jc + li, 2 * ks + half), uf[ks]);
+                mma32(dg, opm_load_frag<T>(W2_l, HID, 32 * jc + li, 2 * ks + half), df[ks]);
+            }
+            acc_add_rows(h, kst + S::K_B1 + 32 * jc, half);
+            float dh[16];
+            gelu_lut_eval16(lut, h, dh);
+#pragma unroll
+            for (int r = 0; r < 16; r++) dh[r] *= dg[r];
+            frag_t<T> dhf[2];
+            dhf[0] = arr_slot_frag<T>(dh, 0);
+            dhf[1] = arr_slot_frag<T>(dh, 1);
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb++)
+#pragma unroll
+                for (int q = 0; q < 2; q++) mma32(dacc[cb], ab_tr_frag<T>(W1_l, HID, 32 * jc + 16 * q, cb * 32, lane), dhf[q]);
+        }
+        // LayerNorm backward + residual in operand-piece form
+        float d8[KS][8], xh[KS][8];
+        float gsum = 0.f, gxsum = 0.f;
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) {
+            float r8[2][8];
+            acc_to_rows(dacc[cb], r8);
+#pragma unroll
+            for (int m = 0; m < 2; m++) {
+                const int ks = 2 * cb + m;
+                float w[8];
+                load_cols<8>(kst + S::K_LNW, 16 * ks + 8 * half, w);
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    d8[ks][e] = valid ? r8[m][e] : 0.f;
+                    xh[ks][e] = valid ? ((float)xf[ks][e] - mean) * rstd : 0.f;
+                    const float gw = d8[ks][e] * w[e];
+                    gsum += gw;
+                    gxsum += gw * xh[ks][e];
+                }
+            }
+            f32x16 tw, tb;
+            acc_zero(tw);
+            acc_zero(tb);
+#pragma unroll
+            for (int m = 0; m < 2; m++) {
+                float pw[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) pw[e] = d8[2 * cb + m][e] * xh[2 * cb + m][e];
+                mma32(tw, frag_from_float<T>(pw), idf[m]);
+                mma32(tb, frag_from_float<T>(d8[2 * cb + m]), idf[m]);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) { aw[cb] += tw[r]; ab[cb] += tb[r]; }
+        }
+        gsum += __shfl_xor(gsum, 32);
+        gxsum += __shfl_xor(gxsum, 32);
+        const float m1 = gsum / (float)C, m2 = gxsum / (float)C;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            float w[8], o[8];
+            load_cols<8>(kst + S::K_LNW, 16 * ks + 8 * half, w);
+#pragma unroll
+            for (int e = 0; e < 8; e++) o[e] = (float)df[ks][e] + rstd * (d8[ks][e] * w[e] - m1 - xh[ks][e] * m2);
+            if (valid) frag_store<T>(dxmid + (size_t)row * C + (2 * ks + half) * 8, frag_from_float<T>(o));
+        }
+    }
+    // fold the two halves and the waves: one atomic per channel per workgroup
+    __syncthreads();                                                 // weights are dead: the LDS becomes reduction scratch
+    float* const red = reinterpret_cast<float*>(smem);               // [WPB][dln_w C | dln_b C]
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) {
+        const float a = aw[cb] + __shfl_xor(aw[cb], 32), b = ab[cb] + __shfl_xor(ab[cb], 32);
+        if (half == 0) {
+            red[wave * 2 * C + 32 * cb + li] = a;
+            red[wave * 2 * C + C + 32 * cb + li] = b;
+        }
+    }
+    __syncthreads();
+    for (int v = tid; v < 2 * C; v += 64 * WPB) {
+        float sum = 0.f;
+        for (int w = 0; w < WPB; w++) sum += red[w * 2 * C + v];
+        atomicAdd((v < C ? dln_w : dln_b) + (v % C), sum);
+    }
+}
+
+// =========================================================================== backward: weight gradients
+// Workgroup of 4C/32 waves; all of them walk the same 32-token tiles (tile = blockIdx.x, += gridDim.x), wave w owns the
+// hidden columns j = 32 w .. 32 w + 31.  Partial results per workgroup in `ws`, laid out as mlp_fold_partials expects:
+// [dW1: grid x 4C x C][S2: grid x C x 4C][db1: 2 grid x 4C][cs2: grid x C].
+template <class T, int C>
+__global__ void __launch_bounds__(64 * (4 * C / 32))
+mlpc_bwd_wgrad_kernel(const T* __restrict__ dxout, const T* __restrict__ xmid, const float* __restrict__ ln_w,
+                      const float* __restrict__ ln_b, const T* __restrict__ W1, const float* __restrict__ b1,
+                      const T* __restrict__ W2gT, float* __restrict__ ws, int M, float eps) {
+    constexpr int KS = C / 16, NCB = C / 32, HID = 4 * C, NW = HID / 32;
+    typedef McSmem<T, C> S;
+    __shared__ __attribute__((aligned(16))) char smem[2 * S::W_1 + 2 * C * 4];
+    char* const W1_l = smem;
+    char* const W2_l = smem + S::W_1;
+    float* const kst = reinterpret_cast<float*>(smem + 2 * S::W_1);
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, half = lane >> 5, wave = tid >> 6;
+    chain_stage_weights<T, C, false>(W1_l, W1, HID, tid, 64 * NW);
+    chain_stage_weights<T, C, false>(W2_l, W2gT, HID, tid, 64 * NW);
+    for (int i = tid; i < C; i += 64 * NW) { kst[i] = ln_w[i]; kst[C + i] = ln_b[i]; }
+    __syncthreads();
+    const float b1v = b1[32 * wave + li];
+    // identity operand pieces: row n = lane & 31 of a 32-column block, k-step m of the block's two: 1 at k = n
+    frag_t<T> idf[2];
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) idf[m][e] = (T)((16 * m + 8 * half + e == li) ? 1.0f : 0.0f);
+
+    f32x16 dw1[NCB], s2[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) { acc_zero(dw1[cb]); acc_zero(s2[cb]); }
+    float db1 = 0.f, cs2[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) cs2[cb] = 0.f;
+
+    const int n_tiles = (M + 31) / 32;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int row = tile * 32 + li;
+        const bool valid = row < M;
+        frag_t<T> uf[KS], df[KS];
+        // all waves read the SAME rows: keep them in step (the barrier is uniform: the tile walk does not depend on the wave), so
+        // that seven of the eight reads of a line hit the L1 / L2 while it is still there
+        __syncthreads();
+        mc_load_row<T, C>(uf, xmid, row, valid, half);
+        mc_load_row<T, C>(df, dxout, row, valid, half);
+        float mean, rstd;
+        mc_layernorm<T, C>(uf, uf, kst, kst + C, valid, half, eps, mean, rstd);
+        // N-form products: accumulator col = hidden j (this lane), registers = the tile's tokens
+        f32x16 h, dg;
+        acc_zero(h);
+        acc_zero(dg);
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            mma32(h, uf[ks], opm_load_frag<T>(W1_l, HID, 32 * wave + li, 2 * ks + half));     // this wave's weight rows
+            mma32(dg, df[ks], opm_load_frag<T>(W2_l, HID, 32 * wave + li, 2 * ks + half));
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) h[r] += b1v;
+        float g[16], gp[16];
+        gelu_both_acc(h, g, gp);
+        float dh[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) { dh[r] = dg[r] * gp[r]; db1 += dh[r]; }
+        frag_t<T> gf[2], dhf[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) { gf[q] = arr_slot_frag<T>(g, q); dhf[q] = arr_slot_frag<T>(dh, q); }
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) {
+            // transposes by identity: (v2, dxout)[token][32 cb + .] -> accumulators col = channel, registers = tokens
+            f32x16 vt, dt;
+            acc_zero(vt);
+            acc_zero(dt);
+#pragma unroll
+            for (int m = 0; m < 2; m++) {
+                mma32(vt, uf[2 * cb + m], idf[m]);
+                mma32(dt, df[2 * cb + m], idf[m]);
+            }
+            if (wave == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) cs2[cb] += dt[r];
+            }
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                mma32(dw1[cb], dhf[q], acc_slot_frag<T>(vt, q));        // rows j, columns c
+                mma32(s2[cb], acc_slot_frag<T>(dt, q), gf[q]);          // rows c, columns j
+            }
+        }
+    }
+    const size_t nwg = gridDim.x, wg = blockIdx.x;
+    float* const p_dw1 = ws + wg * (size_t)(HID * C);
+    float* const p_s2 = ws + nwg * (size_t)(HID * C) + wg * (size_t)(C * HID);
+    float* const p_db1 = ws + 2 * nwg * (size_t)(HID * C) + (wg * 2) * (size_t)HID;
+    float* const p_cs2 = ws + 2 * nwg * (size_t)(HID * C) + 2 * nwg * (size_t)HID + wg * (size_t)C;
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            p_dw1[(size_t)(32 * wave + acc_row(r, lane)) * C + 32 * cb + li] = dw1[cb][r];
+            p_s2[(size_t)(32 * cb + acc_row(r, lane)) * HID + 32 * wave + li] = s2[cb][r];
+        }
+    db1 += __shfl_xor(db1, 32);
+    if (half == 0) {
+        p_db1[32 * wave + li] = db1;
+        p_db1[HID + 32 * wave + li] = 0.f;
+    }
+    if (wave == 0) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) {
+            const float v = cs2[cb] + __shfl_xor(cs2[cb], 32);
+            if (half == 0) p_cs2[32 * cb + li] = v;
+        }
+    }
+}
+
+}  // namespace rvt

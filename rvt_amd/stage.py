@@ -74,7 +74,10 @@ class SideStream:
     _streams = {}
 
     def __init__(self, like: Tensor):
-        self.enabled = like.is_cuda and os.environ.get('RVT_WGRAD_STREAM', '1') == '1'
+        # off by default since round 2: with the fused stage-1 kernels the step on ONE stream costs exactly the sum of its
+        # kernels' isolated times (98.6 ms, profiles/r2/op_breakdown_serial_r2i.txt) and the second stream only adds
+        # contention (100.7 ms); RVT_WGRAD_STREAM=1 re-enables it
+        self.enabled = like.is_cuda and os.environ.get('RVT_WGRAD_STREAM', '0') == '1'
         self._keep = []
         if self.enabled:
             key = like.device.index
