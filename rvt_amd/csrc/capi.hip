@@ -775,17 +775,42 @@ static void launch_lstm_scan_fwd(const void* x_all, void* Hall, const float* c0,
     hipLaunchKernelGGL(k, dim3(scan_grid(k, 64 * NW, M, TM)), dim3(64 * NW), 0, st, (const T*)x_all, (T*)Hall, c0, c_last,
                        (T*)Csave, (const T*)W, bias, M, Tn);
 }
-template <class T, int C, int NW, bool W_LDS>
+// in-kernel weight gradients of the reverse scan: where the weights are LDS-resident (bf16, C <= 64)
+static bool scan_wgrad_built(int dtype, int C) { return dtype == RVT_BF16 && (C == 32 || C == 64); }
+template <class T, int C, int NW, bool W_LDS, bool WGRAD>
+static int lstm_scan_bwd_grid(int M) {
+    constexpr int TM = (NW / (C / 32)) * 32;
+    auto k = lstm_scan_bwd_kernel<T, C, NW, W_LDS, WGRAD>;
+    return scan_grid(k, 64 * NW, M, TM);
+}
+template <class T, int C, int NW, bool W_LDS, bool WGRAD>
 static void launch_lstm_scan_bwd(const void* x_all, const void* Hall, const void* Csave, const float* c0, const void* dH,
                                  const float* dc_last, const void* W, const void* Wt, const float* bias, void* dx_all,
-                                 void* dz_all, void* dh0, float* dc0, int M, int Tn, hipStream_t st) {
-    constexpr int TM = (NW / (C / 32)) * 32;
-    auto k = lstm_scan_bwd_kernel<T, C, NW, W_LDS>;
-    hipLaunchKernelGGL(k, dim3(scan_grid(k, 64 * NW, M, TM)), dim3(64 * NW), 0, st, (const T*)x_all, (const T*)Hall,
+                                 void* dz_all, void* dh0, float* dc0, float* dw, float* db, float* ws, int M, int Tn,
+                                 hipStream_t st) {
+    auto k = lstm_scan_bwd_kernel<T, C, NW, W_LDS, WGRAD>;
+    const int grid = lstm_scan_bwd_grid<T, C, NW, W_LDS, WGRAD>(M);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * NW), 0, st, (const T*)x_all, (const T*)Hall,
                        (const T*)Csave, c0, (const T*)dH, dc_last, (const T*)W, (const T*)Wt, bias, (T*)dx_all, (T*)dz_all,
-                       (T*)dh0, dc0, M, Tn);
+                       (T*)dh0, dc0, ws, M, Tn);
+    if (WGRAD) {
+        // fold the per-workgroup partial records: the [4C][2C] weight block and the NWM bias rows are column sums over records
+        constexpr int NWM = NW / (C / 32);
+        const size_t rec = (size_t)4 * C * 2 * C + (size_t)NWM * 4 * C;
+        hipLaunchKernelGGL(strided_reduce_kernel, dim3(grid_for((size_t)4 * C * 2 * C, 1024)), dim3(256), 0, st, (const float*)ws, dw,
+                           grid, rec, (size_t)4 * C * 2 * C);
+        for (int m = 0; m < NWM; m++)
+            hipLaunchKernelGGL(strided_reduce_kernel, dim3(grid_for((size_t)4 * C, 64)), dim3(256), 0, st,
+                               (const float*)(ws + (size_t)4 * C * 2 * C + (size_t)m * 4 * C), db, grid, rec, (size_t)4 * C);
+    }
 }
 extern "C" {
+size_t rvt_lstm_scan_bwd_ws_floats(int dtype, int C, int M) {
+    if (!scan_wgrad_built(dtype, C)) return 0;
+    const int grid = C == 32 ? lstm_scan_bwd_grid<bf16, 32, 4, true, true>(M) : lstm_scan_bwd_grid<bf16, 64, 4, true, true>(M);
+    const int NWM = 4 / (C / 32);
+    return (size_t)grid * ((size_t)4 * C * 2 * C + (size_t)NWM * 4 * C);
+}
 
 int rvt_lstm_scan_fwd(const void* x_all, void* Hall, const float* c0, float* c_last, void* Csave, const void* w,
                       const float* bias, int dtype, int M, int C, int T_steps, void* stream) {
@@ -808,19 +833,24 @@ int rvt_lstm_scan_fwd(const void* x_all, void* Hall, const float* c0, float* c_l
 
 int rvt_lstm_scan_bwd(const void* x_all, const void* Hall, const void* Csave, const float* c0, const void* dH,
                       const float* dc_last, const void* w, const void* wt, const float* bias, void* dx_all, void* dz_all,
-                      void* dh0, float* dc0, int dtype, int M, int C, int T_steps, void* stream) {
+                      void* dh0, float* dc0, float* dw, float* db, float* ws, int dtype, int M, int C, int T_steps,
+                      void* stream) {
     RVT_CHECK(rvt_lstm_scan_supported(dtype, C), "lstm_scan_bwd: not built for dtype=%d C=%d", dtype, C);
     RVT_CHECK(M >= 1 && T_steps >= 1 && Csave != nullptr, "lstm_scan_bwd: empty problem / missing saved cell states");
     hipStream_t st = (hipStream_t)stream;
-#define RVT_SCAN_BWD(TT, CC, NWW, LDS) launch_lstm_scan_bwd<TT, CC, NWW, LDS>(x_all, Hall, Csave, c0, dH, dc_last, w, wt, bias, dx_all, dz_all, dh0, dc0, M, T_steps, st)
+    const bool wgrad = dw != nullptr;
+    RVT_CHECK(!wgrad || (scan_wgrad_built(dtype, C) && db != nullptr && ws != nullptr),
+              "lstm_scan_bwd: in-kernel weight gradients need dtype bf16, C in {32, 64}, db and a workspace");
+    RVT_CHECK(wgrad || dz_all != nullptr, "lstm_scan_bwd: dz_all required without in-kernel weight gradients");
+#define RVT_SCAN_BWD(TT, CC, NWW, LDS, WG) launch_lstm_scan_bwd<TT, CC, NWW, LDS, WG>(x_all, Hall, Csave, c0, dH, dc_last, w, wt, bias, dx_all, dz_all, dh0, dc0, dw, db, ws, M, T_steps, st)
     if (dtype == RVT_BF16) {
-        if (C == 32) RVT_SCAN_BWD(bf16, 32, 4, true);
-        else if (C == 64) RVT_SCAN_BWD(bf16, 64, 4, true);
-        else RVT_SCAN_BWD(bf16, 128, 4, false);
+        if (C == 32) { if (wgrad) RVT_SCAN_BWD(bf16, 32, 4, true, true); else RVT_SCAN_BWD(bf16, 32, 4, true, false); }
+        else if (C == 64) { if (wgrad) RVT_SCAN_BWD(bf16, 64, 4, true, true); else RVT_SCAN_BWD(bf16, 64, 4, true, false); }
+        else RVT_SCAN_BWD(bf16, 128, 4, false, false);
     } else {
-        if (C == 32) RVT_SCAN_BWD(float, 32, 4, false);
-        else if (C == 64) RVT_SCAN_BWD(float, 64, 4, false);
-        else RVT_SCAN_BWD(float, 128, 4, false);
+        if (C == 32) RVT_SCAN_BWD(float, 32, 4, false, false);
+        else if (C == 64) RVT_SCAN_BWD(float, 64, 4, false, false);
+        else RVT_SCAN_BWD(float, 128, 4, false, false);
     }
 #undef RVT_SCAN_BWD
     return check_launch("lstm_scan_bwd");

@@ -558,6 +558,21 @@ splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int 
     }
 }
 
+// out[i] += sum_s ws[s * stride + i], i < count  (per-workgroup partial RECORDS of `stride` floats each)
+__global__ void __launch_bounds__(256)
+strided_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int nrec, size_t stride, size_t count) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int s = 0;
+        for (; s + 8 <= nrec; s += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) a[u] += ws[(size_t)(s + u) * stride + i];
+        }
+        for (; s < nrec; s++) a[0] += ws[(size_t)s * stride + i];
+        out[i] += ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    }
+}
+
 // conv input-gradient of one parity class: row m = (frame, yy, xx) -> pixel (s*yy+py, s*xx+px); out = v + add
 template <class T> struct EpDgradScatter {
     __device__ __forceinline__ void begin_block(int) {}

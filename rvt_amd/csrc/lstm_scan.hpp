@@ -210,12 +210,17 @@ lstm_scan_fwd_kernel(const T* __restrict__ x_all, T* __restrict__ Hall, const fl
 // Reverse scan.  Inputs as the forward's plus dH [Tn][M][C] (cotangent of Hall[1..], null = zeros) and dc_last fp32 [M][C]
 // (null = zeros); Wt = W^T [2C][4C] (only read when !W_LDS).  Outputs: dx_all [Tn][M][C], dz_all [Tn][M][4C] (natural gate
 // order, for the weight-gradient GEMM), dh0 [M][C] (T), dc0 fp32 [M][C].
-template <class T, int C, int NW, bool W_LDS>
+// WGRAD: the weight gradients dW[4C][2C] += dz^T [x | h_prev] and db[4C] += colsum(dz) are accumulated IN REGISTERS across
+// the whole launch (the dz tile and the [x | h] tiles are in LDS anyway; their token-contraction operands come out through the
+// transposing LDS read) and leave as one partial per workgroup in `ws` ([grid][4C x 2C | 4C] floats): dz never goes to HBM
+// (4 rows of C per token-step written + re-read by the weight-gradient GEMM otherwise).  Wave w owns dW rows 64 w .. 64 w + 63.
+template <class T, int C, int NW, bool W_LDS, bool WGRAD>
 __global__ void __launch_bounds__(64 * NW)
 lstm_scan_bwd_kernel(const T* __restrict__ x_all, const T* __restrict__ Hall, const T* __restrict__ Csave,
                      const float* __restrict__ c0, const T* __restrict__ dH, const float* __restrict__ dc_last,
                      const T* __restrict__ W, const T* __restrict__ Wt, const float* __restrict__ bias,
-                     T* __restrict__ dx_all, T* __restrict__ dz_all, T* __restrict__ dh0, float* __restrict__ dc0, int M, int Tn) {
+                     T* __restrict__ dx_all, T* __restrict__ dz_all, T* __restrict__ dh0, float* __restrict__ dc0,
+                     float* __restrict__ ws, int M, int Tn) {
     typedef LstmScanGeom<T, C, NW> Gm;
     constexpr int NT = Gm::NT, NWC = Gm::NWC, NWM = Gm::NWM, KTC = Gm::KTC, BK = Gm::BK;
     constexpr int TM = NWM * 32;
@@ -282,6 +287,23 @@ lstm_scan_bwd_kernel(const T* __restrict__ x_all, const T* __restrict__ Hall, co
         }
     };
 
+    // weight-gradient accumulators: dW row blocks (4C / 32) / NW per wave x all 2C / 32 column blocks
+    constexpr int WG_RB = WGRAD ? (4 * C / 32) / NW : 1, WG_CB = WGRAD ? 2 * C / 32 : 1;
+    static_assert(!WGRAD || ((4 * C / 32) % NW == 0 && TM % 16 == 0), "weight-gradient tiling");
+    f32x16 dwacc[WG_RB][WG_CB];
+    float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
+    TrFeat<T> tr_dz[WG_RB], tr_xh[WG_CB];
+    if (WGRAD) {
+#pragma unroll
+        for (int i = 0; i < WG_RB; i++) {
+            tr_dz[i].init((wave * WG_RB + i) * 32, TM, lane);
+#pragma unroll
+            for (int j = 0; j < WG_CB; j++) acc_zero(dwacc[i][j]);
+        }
+#pragma unroll
+        for (int j = 0; j < WG_CB; j++) tr_xh[j].init((j * 32) % C, TM, lane);
+    }
+
     const int n_tiles = (M + TM - 1) / TM;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int m0 = tile * TM;
@@ -347,10 +369,13 @@ lstm_scan_bwd_kernel(const T* __restrict__ x_all, const T* __restrict__ Hall, co
                 const float dh = (float)*reinterpret_cast<const T*>(Sd + acc_elem_off(off0, r)) + dh_rec[r];
                 const float tc = tanh_f(f * cp + ig * g);
                 const float dc = dc_rec[r] + dh * o * (1.f - tc * tc);
-                *reinterpret_cast<T*>(Adz + dz_off(0, r)) = (T)(dc * cp * f * (1.f - f));
-                *reinterpret_cast<T*>(Adz + dz_off(1, r)) = (T)(dc * g * ig * (1.f - ig));
-                *reinterpret_cast<T*>(Adz + dz_off(2, r)) = (T)(dh * tc * o * (1.f - o));
-                *reinterpret_cast<T*>(Adz + dz_off(3, r)) = (T)(dc * ig * (1.f - g * g));
+                const float zf = dc * cp * f * (1.f - f), zi = dc * g * ig * (1.f - ig);
+                const float zo = dh * tc * o * (1.f - o), zg = dc * ig * (1.f - g * g);
+                *reinterpret_cast<T*>(Adz + dz_off(0, r)) = (T)zf;
+                *reinterpret_cast<T*>(Adz + dz_off(1, r)) = (T)zi;
+                *reinterpret_cast<T*>(Adz + dz_off(2, r)) = (T)zo;
+                *reinterpret_cast<T*>(Adz + dz_off(3, r)) = (T)zg;
+                if (WGRAD) { dbacc[0] += zf; dbacc[1] += zi; dbacc[2] += zo; dbacc[3] += zg; }   // (rows beyond M: dh = dc = 0)
                 dc_rec[r] = dc * f;
             }
             lds_barrier();                                 // dz tile complete; Ax/Ah/Sc/Sd of step t consumed
@@ -380,6 +405,21 @@ lstm_scan_bwd_kernel(const T* __restrict__ x_all, const T* __restrict__ Hall, co
                     mma32(acc2[part], a, b);
                 }
             }
+            if (WGRAD) {
+                // dW[n][k] += sum_tok dz[tok][n] [x | h][tok][k]: both operands transposed on the way out of LDS
+#pragma unroll
+                for (int k0 = 0; k0 < TM; k0 += 16) {
+                    frag_t<T> a[WG_RB], b[WG_CB];
+#pragma unroll
+                    for (int i = 0; i < WG_RB; i++) a[i] = tr_dz[i].load(Adz, k0, lane);
+#pragma unroll
+                    for (int j = 0; j < WG_CB; j++) b[j] = tr_xh[j].load(j * 32 < C ? Ax : Ah, k0, lane);
+#pragma unroll
+                    for (int i = 0; i < WG_RB; i++)
+#pragma unroll
+                        for (int j = 0; j < WG_CB; j++) mma32(dwacc[i][j], a[i], b[j]);
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 *reinterpret_cast<T*>(Sx + acc_elem_off(off0, r)) = (T)acc2[0][r];
@@ -392,10 +432,12 @@ lstm_scan_bwd_kernel(const T* __restrict__ x_all, const T* __restrict__ Hall, co
                     const int row = f / G, cg = f % G;
                     if (m0 + row < M) frag_store<T>(xdst + (size_t)(m0 + row) * C + cg * 8, opm_load_frag<T>(Sx, TM, row, cg));
                 }
-                T* const zdst = dz_all + (size_t)t * MC * 4;
-                for (int f = tid; f < TM * 4 * G; f += NT) {
-                    const int row = f / (4 * G), cg = f % (4 * G);
-                    if (m0 + row < M) frag_store<T>(zdst + (size_t)(m0 + row) * 4 * C + cg * 8, opm_load_frag<T>(Adz, TM, row, cg));
+                if (!WGRAD) {
+                    T* const zdst = dz_all + (size_t)t * MC * 4;
+                    for (int f = tid; f < TM * 4 * G; f += NT) {
+                        const int row = f / (4 * G), cg = f % (4 * G);
+                        if (m0 + row < M) frag_store<T>(zdst + (size_t)(m0 + row) * 4 * C + cg * 8, opm_load_frag<T>(Adz, TM, row, cg));
+                    }
                 }
             }
             if (t > 0) {
@@ -412,6 +454,23 @@ lstm_scan_bwd_kernel(const T* __restrict__ x_all, const T* __restrict__ Hall, co
                 dh0[(size_t)row * C + ch] = (T)dh_rec[r];
                 dc0[(size_t)row * C + ch] = dc_rec[r];
             }
+        }
+    }
+    if (WGRAD) {
+        // per-workgroup partials: [4C][2C] weight gradient, then [NWM][4C] bias-gradient rows (one per token half of the tile)
+        float* const p_dw = ws + (size_t)blockIdx.x * (4 * C * 2 * C + NWM * 4 * C);
+        float* const p_db = p_dw + 4 * C * 2 * C + wm * 4 * C;
+#pragma unroll
+        for (int i = 0; i < WG_RB; i++)
+#pragma unroll
+            for (int j = 0; j < WG_CB; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    p_dw[(size_t)((wave * WG_RB + i) * 32 + acc_row(r, lane)) * (2 * C) + j * 32 + li] = dwacc[i][j][r];
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const float v = dbacc[g] + __shfl_xor(dbacc[g], 32);
+            if (half == 0) p_db[g * C + ch] = v;
         }
     }
 }

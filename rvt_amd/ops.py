@@ -351,15 +351,32 @@ def lstm_scan_fwd(x_all: Tensor, Hall: Tensor, c0: Optional[Tensor], c_last: Ten
            L.dtype_code(x_all.dtype), M, C, T_, L.stream_of(x_all))
 
 
+def lstm_scan_wgrad_supported(dtype: torch.dtype, C: int, M: int) -> bool:
+    """In-kernel weight gradients of the reverse scan (bf16, LDS-resident weights: C <= 64)."""
+    return dtype in L._DT and L.get_lib().rvt_lstm_scan_bwd_ws_floats(L.dtype_code(dtype), C, M) > 0
+
+
 def lstm_scan_bwd(x_all: Tensor, Hall: Tensor, Csave: Tensor, c0: Optional[Tensor], dH: Optional[Tensor],
-                  dc_last: Optional[Tensor], w: Tensor, wt: Tensor, bias: Tensor, dx_all: Tensor, dz_all: Tensor,
-                  dh0: Tensor, dc0: Tensor) -> None:
+                  dc_last: Optional[Tensor], w: Tensor, wt: Tensor, bias: Tensor, dx_all: Tensor, dz_all: Optional[Tensor],
+                  dh0: Tensor, dc0: Tensor, dw: Optional[Tensor] = None, db: Optional[Tensor] = None) -> None:
+    """Reverse scan.  With dw / db (fp32 [4C][2C] / [4C], +=) the weight gradients are accumulated inside the kernel and
+    dz_all is not produced (pass None)."""
     T_, C = x_all.shape[0], x_all.shape[-1]
     M = x_all[0].numel() // C
     assert dc0.dtype == torch.float32 and (dc_last is None or dc_last.dtype == torch.float32)
+    ws = None
+    st = L.stream_of(x_all)
+    if dw is not None:
+        assert dw.dtype == torch.float32 and db is not None and db.dtype == torch.float32 and tuple(dw.shape) == (4 * C, 2 * C)
+        n = L.get_lib().rvt_lstm_scan_bwd_ws_floats(L.dtype_code(x_all.dtype), C, M)
+        key = ('scanbwd', x_all.device.type, x_all.device.index, 0 if st is None else int(st))
+        ws = _WS.get(key)
+        if ws is None or ws.numel() < n:
+            ws = torch.empty(n, dtype=torch.float32, device=x_all.device)
+            _WS[key] = ws
     L.call('rvt_lstm_scan_bwd', L.ptr(x_all), L.ptr(Hall), L.ptr(Csave), L.ptr(c0), L.ptr(dH), L.ptr(dc_last), L.ptr(w),
-           L.ptr(wt), L.ptr(bias), L.ptr(dx_all), L.ptr(dz_all), L.ptr(dh0), L.ptr(dc0), L.dtype_code(x_all.dtype), M, C, T_,
-           L.stream_of(x_all))
+           L.ptr(wt), L.ptr(bias), L.ptr(dx_all), L.ptr(dz_all), L.ptr(dh0), L.ptr(dc0), L.ptr(dw), L.ptr(db), L.ptr(ws),
+           L.dtype_code(x_all.dtype), M, C, T_, st)
 
 
 def dwconv(x: Tensor, w: Tensor, b: Optional[Tensor], k: int, transpose: bool = False, out: Optional[Tensor] = None) -> Tensor:

@@ -250,17 +250,25 @@ def stage_seq_backward(sw: StageWeights, g: StageGeom, sv: StageSaved, dH: Optio
     G = sg.g
 
     # ---- ConvLSTM BPTT ------------------------------------------------------------------------------
-    dz = torch.empty((T, B, H, W, 4 * C), dtype=dt, device=dev)
     dx = torch.empty((T, B, H, W, C), dtype=dt, device=dev)
     dws = sw.dws
+    lstm_wgrad_done = False
+    dz = None
     if sv.Csave is not None:
-        # reverse scan in ONE launch: gates recomputed from (x_t, h_{t-1}), dc / dh_rec in registers across t
+        # reverse scan in ONE launch: gates recomputed from (x_t, h_{t-1}), dc / dh_rec in registers across t; where built
+        # (bf16, C <= 64) the weight gradients are accumulated in the same kernel and dz never exists in HBM
         dh_rec = torch.empty((B, H, W, C), dtype=dt, device=dev)
         dc_rec = torch.empty((B, H, W, C), dtype=f32, device=dev)
+        lstm_wgrad_done = os.environ.get('RVT_LSTM_SCAN_WGRAD', '1') != '0' and ops.lstm_scan_wgrad_supported(dt, C, B * H * W)
+        if not lstm_wgrad_done:
+            dz = torch.empty((T, B, H, W, 4 * C), dtype=dt, device=dev)
         ops.lstm_scan_bwd(sv.xin_lstm.view(T, B, H, W, C), sv.Hall, sv.Csave, sv.c0, dH,
                           None if dc_last is None else dc_last.to(f32).contiguous(), sw.lstm_wn, sw.lstm_wt, sw.lstm_bn,
-                          dx, dz, dh_rec, dc_rec)
+                          dx, dz, dh_rec, dc_rec,
+                          dw=G(pre + 'lstm.conv1x1.weight').view(4 * C, 2 * C) if lstm_wgrad_done else None,
+                          db=G(pre + 'lstm.conv1x1.bias') if lstm_wgrad_done else None)
     else:
+        dz = torch.empty((T, B, H, W, 4 * C), dtype=dt, device=dev)
         if dH is None:
             dH = torch.zeros((T, B, H, W, C), dtype=dt, device=dev)
         dc_rec = torch.zeros((B, H, W, C), dtype=f32, device=dev) if dc_last is None else dc_last.to(f32).contiguous().clone()
@@ -279,13 +287,14 @@ def stage_seq_backward(sw: StageWeights, g: StageGeom, sv: StageSaved, dH: Optio
                 ops.dwconv(dhc[t], wh, None, dws['k'], transpose=True, out=nxt)
             dh_rec = nxt
     if side is None:
-        side = SideStream(dz)
+        side = SideStream(dx)
     h_seg = sv.Hall[:T].reshape(F_, H, W, C) if dws is None else sv.hconv.view(F_, H, W, C)
 
     def lstm_wgrad_fn():
         ops.lstm_wgrad(dz.view(F_, H, W, 4 * C), sv.xin_lstm, h_seg, G(pre + 'lstm.conv1x1.weight').view(4 * C, 2 * C),
                        G(pre + 'lstm.conv1x1.bias'))
-    side.run(lstm_wgrad_fn, dz, sv.xin_lstm, h_seg)
+    if not lstm_wgrad_done:
+        side.run(lstm_wgrad_fn, dz, sv.xin_lstm, h_seg)
     dh0, dc0 = dh_rec, dc_rec
     dx = dx.view(F_, H, W, C)
     if dws is not None:

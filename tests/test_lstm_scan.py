@@ -99,6 +99,18 @@ def test_lstm_scan_fwd_bwd(backend, dt, C, M, T, zero_state):
     assert rel(dzc.t() @ xh, wr.grad) <= tol * 2, ('dW', rel(dzc.t() @ xh, wr.grad))
     assert rel(dzc.sum(0), br.grad) <= tol * 2, ('db', rel(dzc.sum(0), br.grad))
 
+    # in-kernel weight gradients (bf16, LDS-resident weights): same dx / dh0 / dc0, dW and db accumulated (+=) without a dz tensor
+    if ops.lstm_scan_wgrad_supported(dt, C, M):
+        dw = torch.ones(4 * C, 2 * C, dtype=torch.float32, device=dev)
+        db = torch.ones(4 * C, dtype=torch.float32, device=dev)
+        dx2, dh02, dc02 = torch.empty_like(dx), torch.empty_like(dh0), torch.empty_like(dc0)
+        ops.lstm_scan_bwd(x, Hall, Csave, c0, dH, dc_last, w, w.t().contiguous(), b, dx2, None, dh02, dc02, dw=dw, db=db)
+        assert torch.equal(dx2.cpu(), dx.cpu()) and torch.equal(dh02.cpu(), dh0.cpu()) and torch.equal(dc02.cpu(), dc0.cpu())
+        assert rel(dw - 1.0, wr.grad) <= tol * 2, ('in-kernel dW', rel(dw - 1.0, wr.grad))
+        assert rel(db - 1.0, br.grad) <= tol * 2, ('in-kernel db', rel(db - 1.0, br.grad))
+    else:
+        assert dt == torch.float32 or C > 64
+
     # no upstream cotangents at all -> every gradient is zero / finite
     ops.lstm_scan_bwd(x, Hall, Csave, c0, None, None, w, w.t().contiguous(), b, dx, dz, dh0, dc0)
     assert float(dx.float().abs().max()) == 0.0 and float(dz.float().abs().max()) == 0.0
