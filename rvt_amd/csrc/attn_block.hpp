@@ -79,8 +79,10 @@ __device__ __forceinline__ void acc_add_rows(f32x16& c, const float* p, int half
 }
 
 
-// softmax_cols of attn.hpp without the 16-register key-mask array: the padded keys of the LAST key block are selected away
-// by comparing the (compile-time) accumulator row of register r with one per-lane limit
+// S^T column softmax for one query block.  In: raw scores s[bj][r] (keys down the registers, this lane's query).  Out:
+// p[bj][r] = exp(scale (s - max)) (UN-normalised) and the column's 1/sum.  Padded keys (j >= L) only exist in the LAST
+// 32-key block: they are selected away by comparing the (compile-time) accumulator row of register r with one per-lane
+// limit; exp2 with scale * log2(e) folded into one multiply.
 template <int NB>
 __device__ __forceinline__ float ab_softmax_cols(const f32x16 (&s)[NB], float (&p)[NB][16], int klim, float scale_log2e) {
     float mx = -3.0e38f;

@@ -1,0 +1,219 @@
+// Partitioned multi-head self-attention core (reference maxvit.py:343-354 minus the two linears, on the partitions of
+// :273-304) for the stages whose attention half is not fused (attn_block.hpp): same contract as the kernels of attn.hpp
+// (qkv [F*H*W][3C] in image token order, per-head [q|k|v]; one wave per (frame, partition, head)), rebuilt on the
+// accumulator-to-operand chaining of attn_block.hpp:
+//   * Q, K, V, dO rows come from HBM in operand form = the "row token, contract d" operands of S^T = K Q^T and dP^T = V dO^T;
+//   * the "row d, contract token" operands (V for O^T = V^T P^T; K, Q, dO for dQ^T, dK^T, dV^T) are transposes of those rows:
+//     an MFMA against an identity operand (exact) instead of a transposed LDS copy built with 2-byte stores and read back with
+//     2-byte loads — the forward touches no LDS at all;
+//   * P and dS (contraction over queries for dV, dK) take one trip through a wave-private LDS tile as 8-byte row pieces and
+//     come back through the transposing LDS read;
+//   * dQ^T, dK^T, dV^T leave as 16-byte row pieces (v_permlane32_swap) instead of being staged through LDS.
+#pragma once
+#include "attn_block.hpp"
+
+namespace rvt {
+
+// identity operand pieces of a 32-column block: row n = lane & 31, k-step cc: 1 at slot k = 16 cc + 8 half + e == n
+template <class T> __device__ __forceinline__ void make_identity_frags(frag_t<T> (&idf)[2], int li, int half) {
+#pragma unroll
+    for (int cc = 0; cc < 2; cc++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) idf[cc][e] = (T)((16 * cc + 8 * half + e == li) ? 1.0f : 0.0f);
+}
+// rows held in operand form (lane = row, pieces cc = 0, 1) -> the transposed operand "row = column, contract over the 32 rows"
+template <class T> __device__ __forceinline__ void transpose_rows(const frag_t<T> (&rows)[2], const frag_t<T> (&idf)[2], frag_t<T> (&out)[2]) {
+    f32x16 acc;
+    acc_zero(acc);
+#pragma unroll
+    for (int cc = 0; cc < 2; cc++) mma32(acc, rows[cc], idf[cc]);
+    out[0] = acc_slot_frag<T>(acc, 0);
+    out[1] = acc_slot_frag<T>(acc, 1);
+}
+
+struct AcPart {
+    int f, p, head, qoff;
+};
+__device__ __forceinline__ AcPart ac_partition(const AttnGeom& g, int HG, int wv) {
+    uint32_t fp, grp, f, p;
+    g.dGroups.divmod(blockIdx.x, fp, grp);
+    g.dP.divmod(fp, f, p);
+    AcPart a;
+    a.f = (int)f; a.p = (int)p; a.head = (int)grp * HG + wv; a.qoff = a.head * 3 * g.dh;
+    return a;
+}
+
+template <class T, int NB, int HG>
+__global__ void __launch_bounds__(64 * HG)
+attn_core_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, AttnGeom g) {
+    const int lane = threadIdx.x & 63, li = lane & 31, half = lane >> 5, wv = threadIdx.x >> 6;
+    const AcPart a = ac_partition(g, HG, wv);
+    const int C3 = 3 * g.C, dh = g.dh;
+    int tok[NB]; bool valid[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        const int l = 32 * b + li;
+        valid[b] = l < g.L;
+        tok[b] = attn_token(g, a.f, a.p, valid[b] ? l : 0);
+    }
+    const int klim = g.L - 32 * (NB - 1) - 4 * half;
+    const float scale_log2e = g.scale * 1.4426950408889634f;
+    frag_t<T> qf[NB][2], kf[NB][2], vr[NB][2];
+#pragma unroll
+    for (int b = 0; b < NB; b++)
+#pragma unroll
+        for (int cc = 0; cc < 2; cc++) {
+            const int chunk = half + 2 * cc;
+            const T* row = qkv + (size_t)tok[b] * C3 + a.qoff;
+            qf[b][cc] = load_chunk<T>(row, chunk, dh, valid[b]);
+            kf[b][cc] = load_chunk<T>(row + dh, chunk, dh, valid[b]);
+            vr[b][cc] = load_chunk<T>(row + 2 * dh, chunk, dh, valid[b]);
+        }
+    frag_t<T> idf[2], vf[NB][2];
+    make_identity_frags<T>(idf, li, half);
+#pragma unroll
+    for (int b = 0; b < NB; b++) transpose_rows<T>(vr[b], idf, vf[b]);      // V^T: "row d, contract keys"
+
+#pragma unroll
+    for (int bi = 0; bi < NB; bi++) {
+        f32x16 s[NB];
+#pragma unroll
+        for (int bj = 0; bj < NB; bj++) {
+            acc_zero(s[bj]);
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++)
+                if (ks * 16 < dh) mma32(s[bj], kf[bj][ks], qf[bi][ks]);
+        }
+        float pr[NB][16];
+        const float inv = ab_softmax_cols<NB>(s, pr, klim, scale_log2e);
+        f32x16 o;
+        acc_zero(o);
+#pragma unroll
+        for (int bj = 0; bj < NB; bj++)
+#pragma unroll
+            for (int q = 0; q < 2; q++) mma32(o, vf[bj][q], arr_slot_frag<T>(pr[bj], q));
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[r] *= inv;
+        float r8[2][8];
+        acc_to_rows(o, r8);
+        if (valid[bi]) {
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+                if (16 * m + 8 * half < dh)
+                    frag_store<T>(out + (size_t)tok[bi] * g.C + a.head * dh + 16 * m + 8 * half, frag_from_float<T>(r8[m]));
+        }
+    }
+}
+
+// Backward: recomputes S / P from the saved qkv.  dP^T = V dO^T; delta_i = sum_j P dP; dS^T = P^T (dP^T - delta) scale;
+// dQ^T = K^T dS^T; dV^T = dO^T P; dK^T = Q^T dS (the last two contract over the queries: P, dS through the LDS tile).
+template <class T, int NB, int HG>
+__global__ void __launch_bounds__(64 * HG, NB == 3 ? 1 : 2)
+attn_core_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ dout, T* __restrict__ dqkv, AttnGeom g) {
+    typedef AbBwdScratch<T, NB> SC;
+    __shared__ __attribute__((aligned(16))) char smem[HG * SC::BYTES];
+    const int lane = threadIdx.x & 63, li = lane & 31, half = lane >> 5, wv = threadIdx.x >> 6;
+    char* const Pl = smem + wv * SC::BYTES;
+    char* const dSl = Pl + SC::ONE;
+    const AcPart a = ac_partition(g, HG, wv);
+    const int C3 = 3 * g.C, dh = g.dh;
+    int tok[NB]; bool valid[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        const int l = 32 * b + li;
+        valid[b] = l < g.L;
+        tok[b] = attn_token(g, a.f, a.p, valid[b] ? l : 0);
+    }
+    const int klim = g.L - 32 * (NB - 1) - 4 * half;
+    const float scale_log2e = g.scale * 1.4426950408889634f;
+    // every global read of the kernel in one batch: rows in operand form = the T-form operands
+    frag_t<T> qf[NB][2], kf[NB][2], vf[NB][2], df[NB][2];
+#pragma unroll
+    for (int b = 0; b < NB; b++)
+#pragma unroll
+        for (int cc = 0; cc < 2; cc++) {
+            const int chunk = half + 2 * cc;
+            const T* row = qkv + (size_t)tok[b] * C3 + a.qoff;
+            qf[b][cc] = load_chunk<T>(row, chunk, dh, valid[b]);
+            kf[b][cc] = load_chunk<T>(row + dh, chunk, dh, valid[b]);
+            vf[b][cc] = load_chunk<T>(row + 2 * dh, chunk, dh, valid[b]);
+            df[b][cc] = load_chunk<T>(dout + (size_t)tok[b] * g.C + a.head * dh, chunk, dh, valid[b]);
+        }
+    frag_t<T> idf[2], kn[NB][2];
+    make_identity_frags<T>(idf, li, half);
+#pragma unroll
+    for (int b = 0; b < NB; b++) transpose_rows<T>(kf[b], idf, kn[b]);
+    auto store_rows = [&](const f32x16& z, int b, int off) {       // T-form block (lane = token) -> 16-byte row pieces
+        float r8[2][8];
+        acc_to_rows(z, r8);
+        if (valid[b]) {
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+                if (16 * m + 8 * half < dh)
+                    frag_store<T>(dqkv + (size_t)tok[b] * C3 + a.qoff + off + 16 * m + 8 * half, frag_from_float<T>(r8[m]));
+        }
+    };
+    f32x16 dk[NB], dv[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++) { acc_zero(dk[b]); acc_zero(dv[b]); }
+
+#pragma unroll
+    for (int bi = 0; bi < NB; bi++) {
+        f32x16 s[NB], dp[NB];
+#pragma unroll
+        for (int bj = 0; bj < NB; bj++) {
+            acc_zero(s[bj]);
+            acc_zero(dp[bj]);
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++)
+                if (ks * 16 < dh) {
+                    mma32(s[bj], kf[bj][ks], qf[bi][ks]);
+                    mma32(dp[bj], vf[bj][ks], df[bi][ks]);
+                }
+        }
+        float pr[NB][16];
+        const float inv = ab_softmax_cols<NB>(s, pr, klim, scale_log2e);
+        float delta = 0.f;
+#pragma unroll
+        for (int bj = 0; bj < NB; bj++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) { pr[bj][r] *= inv; delta += pr[bj][r] * dp[bj][r]; }
+        delta += __shfl_xor(delta, 32);
+        float ds[NB][16];
+#pragma unroll
+        for (int bj = 0; bj < NB; bj++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) ds[bj][r] = pr[bj][r] * (dp[bj][r] - delta) * g.scale;
+#pragma unroll
+        for (int bj = 0; bj < NB; bj++) {
+            ab_acc_to_lds<T>(Pl, 32, li, 32 * bj, pr[bj], half);
+            ab_acc_to_lds<T>(dSl, 32, li, 32 * bj, ds[bj], half);
+        }
+        f32x16 dq;
+        acc_zero(dq);
+#pragma unroll
+        for (int bj = 0; bj < NB; bj++)
+#pragma unroll
+            for (int q = 0; q < 2; q++) mma32(dq, kn[bj][q], arr_slot_frag<T>(ds[bj], q));
+        store_rows(dq, bi, 0);
+        frag_t<T> qn[2], don[2];                         // this query block's Q and dO as "row d, contract queries" operands
+        transpose_rows<T>(qf[bi], idf, qn);
+        transpose_rows<T>(df[bi], idf, don);
+        wave_lds_sync();
+#pragma unroll
+        for (int bj = 0; bj < NB; bj++)
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                mma32(dv[bj], don[q], ab_tr_frag<T>(Pl, 32, 16 * q, 32 * bj, lane));
+                mma32(dk[bj], qn[q], ab_tr_frag<T>(dSl, 32, 16 * q, 32 * bj, lane));
+            }
+        wave_lds_sync();
+    }
+#pragma unroll
+    for (int bj = 0; bj < NB; bj++) {
+        store_rows(dk[bj], bj, dh);
+        store_rows(dv[bj], bj, 2 * dh);
+    }
+}
+
+}  // namespace rvt

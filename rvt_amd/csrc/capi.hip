@@ -10,6 +10,7 @@
 #include "rowops.hpp"
 #include "attn.hpp"
 #include "attn_block.hpp"
+#include "attn_core2.hpp"
 #include "mlp.hpp"
 #include "mlp_chain.hpp"
 #include "events.hpp"
@@ -585,18 +586,18 @@ static int make_attn_geom(AttnGeom& g, int F, int H, int W, int C, int dh, int p
 constexpr int ATTN_LDS_BUDGET = 80 * 1024;
 template <class T, int NB> static int attn_head_group(int heads) {
     for (int hg = 4; hg > 1; hg >>= 1)
-        if (heads % hg == 0 && hg * AttnBwdLds<T, NB>::BYTES <= ATTN_LDS_BUDGET) return hg;
+        if (heads % hg == 0 && hg * AbBwdScratch<T, NB>::BYTES <= ATTN_LDS_BUDGET) return hg;
     return 1;
 }
 template <class T, int NB, int HG>
 static void launch_attn(bool bwd, const void* qkv, const void* dout, void* out, AttnGeom g, hipStream_t st) {
-    if constexpr (HG == 1 || HG * AttnBwdLds<T, NB>::BYTES <= ATTN_LDS_BUDGET) {
-        g.dGroups = FastDiv(g.heads / HG);
-        dim3 grid((unsigned)(g.F * g.P * (g.heads / HG)));
+    g.dGroups = FastDiv(g.heads / HG);
+    dim3 grid((unsigned)(g.F * g.P * (g.heads / HG)));
+    if constexpr (HG == 1 || HG * AbBwdScratch<T, NB>::BYTES <= ATTN_LDS_BUDGET) {
         if (bwd)
-            hipLaunchKernelGGL((attn_bwd_kernel<T, NB, HG>), grid, dim3(64 * HG), 0, st, (const T*)qkv, (const T*)dout, (T*)out, g);
+            hipLaunchKernelGGL((attn_core_bwd_kernel<T, NB, HG>), grid, dim3(64 * HG), 0, st, (const T*)qkv, (const T*)dout, (T*)out, g);
         else
-            hipLaunchKernelGGL((attn_fwd_kernel<T, NB, HG>), grid, dim3(64 * HG), 0, st, (const T*)qkv, (T*)out, g);
+            hipLaunchKernelGGL((attn_core_fwd_kernel<T, NB, HG>), grid, dim3(64 * HG), 0, st, (const T*)qkv, (T*)out, g);
     }
 }
 template <class T, int NB>
