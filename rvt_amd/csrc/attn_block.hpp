@@ -108,6 +108,16 @@ __device__ __forceinline__ float ab_softmax_cols(const f32x16 (&s)[NB], float (&
     return 1.0f / sum;
 }
 
+// ... and the same constants as the INITIAL value of the accumulator (bias folded into the first MFMA: no zero fill, no adds)
+__device__ __forceinline__ void acc_load_rows(f32x16& c, const float* p, int half) {
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(p + 8 * g + 4 * half);
+#pragma unroll
+        for (int w = 0; w < 4; w++) c[4 * g + w] = t[w];
+    }
+}
+
 template <class T, int C> struct AbSmem {
     static constexpr int KT = C / TileGeom<T>::BK;
     static constexpr int W_QKV = KT * 3 * C * 128;        // [3C rows][C]   (Wqkv; rows = [head][q|k|v][dh])
@@ -271,11 +281,12 @@ attn_block_fwd_kernel(const T* __restrict__ x, T* __restrict__ xmid, T* __restri
             for (int h = 0; h < HEADS; h++) {
                 const int r0 = h * 96;
                 frag_t<T> qf[2], kf[NB][2], vf[NB][2];
+                // biases: q's is the initial value of its accumulator; k's is dropped (it shifts every score of a query by the
+                // same amount: softmax is invariant to it); v's is added to the attention output instead (rows of P sum to 1)
                 {
                     f32x16 acc;
-                    acc_zero(acc);
+                    acc_load_rows(acc, kst + S::K_BQKV + r0, half);
                     ab_proj_t<T, C>(acc, Wq_l, 3 * C, r0, uf[bi], li, half);
-                    acc_add_rows(acc, kst + S::K_BQKV + r0, half);
                     acc_to_frags<T>(acc, qf);
                 }
 #pragma unroll
@@ -283,13 +294,9 @@ attn_block_fwd_kernel(const T* __restrict__ x, T* __restrict__ xmid, T* __restri
                     f32x16 acc;
                     acc_zero(acc);
                     ab_proj_t<T, C>(acc, Wq_l, 3 * C, r0 + 32, uf[b], li, half);
-                    acc_add_rows(acc, kst + S::K_BQKV + r0 + 32, half);
                     acc_to_frags<T>(acc, kf[b]);
                     acc_zero(acc);
                     ab_proj_n<T, C>(acc, Wq_l, 3 * C, r0 + 64, uf[b], li, half);
-                    const float bv = kst[S::K_BQKV + r0 + 64 + li];
-#pragma unroll
-                    for (int r = 0; r < 16; r++) acc[r] += bv;
                     acc_to_frags<T>(acc, vf[b]);
                 }
                 f32x16 s[NB];
@@ -307,8 +314,12 @@ attn_block_fwd_kernel(const T* __restrict__ x, T* __restrict__ xmid, T* __restri
                 for (int bj = 0; bj < NB; bj++)
 #pragma unroll
                     for (int q = 0; q < 2; q++) mma32(o, vf[bj][q], arr_slot_frag<T>(pr[bj], q));
+                {
+                    f32x16 bvr;                          // v bias of this lane's 16 accumulator rows (features d)
+                    acc_load_rows(bvr, kst + S::K_BQKV + r0 + 64, half);
 #pragma unroll
-                for (int r = 0; r < 16; r++) o[r] *= inv;
+                    for (int r = 0; r < 16; r++) o[r] = fmaf(o[r], inv, bvr[r]);
+                }
                 frag_t<T> of[2];
                 acc_to_frags<T>(o, of);
                 if (a_out != nullptr) {       // attention output rows (the B operand of the proj weight gradient)
@@ -478,22 +489,16 @@ attn_block_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dxmid, T* _
             frag_t<T> kf[NB][2], vtf[NB][2], kn[NB][2];
 #pragma unroll
             for (int b = 0; b < NB; b++) {
+                // (k bias dropped: S, P, and with them every gradient but its own — which is identically zero — are invariant to it)
                 f32x16 acc;
                 acc_zero(acc);
                 ab_proj_t<T, C>(acc, Wq_l, 3 * C, r0 + 32, uf[b], li, half);
-                acc_add_rows(acc, kst + S::K_BQKV + r0 + 32, half);
                 acc_to_frags<T>(acc, kf[b]);
-                acc_zero(acc);
+                acc_load_rows(acc, kst + S::K_BQKV + r0 + 64, half);
                 ab_proj_t<T, C>(acc, Wq_l, 3 * C, r0 + 64, uf[b], li, half);
-                acc_add_rows(acc, kst + S::K_BQKV + r0 + 64, half);
                 acc_to_frags<T>(acc, vtf[b]);
                 acc_zero(acc);
                 ab_proj_n<T, C>(acc, Wq_l, 3 * C, r0 + 32, uf[b], li, half);
-                {
-                    const float bv = kst[S::K_BQKV + r0 + 32 + li];
-#pragma unroll
-                    for (int r = 0; r < 16; r++) acc[r] += bv;
-                }
                 acc_to_frags<T>(acc, kn[b]);
             }
             f32x16 dk[NB], dv[NB];
@@ -506,18 +511,16 @@ attn_block_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dxmid, T* _
                 frag_t<T> qf[2], dotf[2], qn[2], don[2];
                 {
                     f32x16 acc;
-                    acc_zero(acc);
+                    acc_load_rows(acc, kst + S::K_BQKV + r0, half);
                     ab_proj_t<T, C>(acc, Wq_l, 3 * C, r0, uf[bi], li, half);
-                    acc_add_rows(acc, kst + S::K_BQKV + r0, half);
                     acc_to_frags<T>(acc, qf);
                     acc_zero(acc);
                     ab_proj_t<T, C>(acc, Wp_l, C, h * 32, df[bi], li, half);
                     acc_to_frags<T>(acc, dotf);
-                    acc_zero(acc);
-                    ab_proj_n<T, C>(acc, Wq_l, 3 * C, r0, uf[bi], li, half);
                     const float bv = kst[S::K_BQKV + r0 + li];
 #pragma unroll
-                    for (int r = 0; r < 16; r++) acc[r] += bv;
+                    for (int r = 0; r < 16; r++) acc[r] = bv;
+                    ab_proj_n<T, C>(acc, Wq_l, 3 * C, r0, uf[bi], li, half);
                     acc_to_frags<T>(acc, qn);
                     acc_zero(acc);
                     ab_proj_n<T, C>(acc, Wp_l, C, h * 32, df[bi], li, half);

@@ -161,10 +161,9 @@ mlpc_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, const float* _
 #pragma unroll 2
         for (int jc = 0; jc < NJC; jc++) {
             f32x16 h;
-            acc_zero(h);
+            acc_load_rows(h, kst + S::K_B1 + 32 * jc, half);           // fc1 bias = initial value of the accumulator
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) mma32(h, opm_load_frag<T>(W1_l, HID, 32 * jc + li, 2 * ks + half), uf[ks]);
-            acc_add_rows(h, kst + S::K_B1 + 32 * jc, half);
             float g[16];
             gelu_lut_eval16(lut, h, g);
 #pragma unroll
@@ -250,14 +249,13 @@ mlpc_bwd_dgrad_kernel(const T* __restrict__ dxout, const T* __restrict__ xmid, T
 #pragma unroll 2
         for (int jc = 0; jc < NJC; jc++) {
             f32x16 h, dg;
-            acc_zero(h);
+            acc_load_rows(h, kst + S::K_B1 + 32 * jc, half);
             acc_zero(dg);
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) {
                 mma32(h, opm_load_frag<T>(W1_l, HID, 32 * jc + li, 2 * ks + half), uf[ks]);
                 mma32(dg, opm_load_frag<T>(W2_l, HID, 32 * jc + li, 2 * ks + half), df[ks]);
             }
-            acc_add_rows(h, kst + S::K_B1 + 32 * jc, half);
             float dh[16];
             gelu_lut_eval16(lut, h, dh);
 #pragma unroll
