@@ -404,6 +404,10 @@ static bool mlp_chain_on(int dtype, int C) {
     static const int off = getenv("RVT_MLP_CHAIN") ? atoi(getenv("RVT_MLP_CHAIN")) == 0 : 0;
     return !off && C == 64 && (dtype == RVT_BF16 || dtype == RVT_F32);
 }
+#ifndef MC_FWD_WPB
+#define MC_FWD_WPB 8      // (6 waves x 3 per SIMD at <= 168 registers spills inside the chunk loop: 2.0 ms against 1.42)
+#define MC_FWD_MINW 2
+#endif
 template <class T> struct McWaves { static constexpr int V = sizeof(T) == 2 ? 8 : 4; };
 template <class K> static int mc_grid(K kernel, int threads, int M, int wpb) {
     static const int resident_override = getenv("RVT_MC_RESIDENT") ? atoi(getenv("RVT_MC_RESIDENT")) : 0;
@@ -427,8 +431,8 @@ int rvt_mlp_fwd(const void* xmid, void* xout, void* g_out, void* gp_out, void* v
     if (g_out == nullptr && v2_out == nullptr && mlp_chain_on(dtype, C)) {
         // nothing to save: the register-chained kernel (csrc/mlp_chain.hpp)
         DISPATCH_DTYPE(dtype, {
-            constexpr int WPB = McWaves<T>::V;
-            auto k = mlpc_fwd_kernel<T, 64, WPB>;
+            constexpr int WPB = sizeof(T) == 2 ? MC_FWD_WPB : 4;
+            auto k = mlpc_fwd_kernel<T, 64, WPB, (sizeof(T) == 2 ? MC_FWD_MINW : 1)>;
             hipLaunchKernelGGL(k, dim3(mc_grid(k, 64 * WPB, M, WPB)), dim3(64 * WPB), 0, st, (const T*)xmid, (T*)xout, ln_w, ln_b,
                                (const T*)w1, b1, (const T*)w2, b2, gamma, M, eps);
         });

@@ -29,25 +29,29 @@ template <bool GRAD> __device__ __forceinline__ void gelu_lut_fill(float* lut, i
 // table values at the 16 accumulator registers of a block: Phi (GRAD = false table) or GELU' (GRAD = true table).  Three
 // phases — all indices, all gathers, all interpolations — so that the sixteen LDS round trips overlap instead of each
 // being waited for in turn (two waves per SIMD do not hide a dependent gather chain).
+template <int BATCH = 16>
 __device__ __forceinline__ void gelu_lut_eval16(const float* lut, const f32x16& x, float (&out)[16]) {
     const float s = (float)GELU_LUT_N / (2.0f * GELU_LUT_X);
-    float fr[16];
-    const f32x2* p[16];
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-        float t = fmaf(x[r], s, GELU_LUT_X * s);
-        t = fminf(fmaxf(t, 0.0f), (float)GELU_LUT_N - 0.001f);
-        const float fl = floorf(t);
-        fr[r] = t - fl;
-        p[r] = reinterpret_cast<const f32x2*>(lut) + (int)fl;
+    for (int r0 = 0; r0 < 16; r0 += BATCH) {            // BATCH gathers in flight at a time (registers vs latency hiding)
+        float fr[BATCH];
+        const f32x2* p[BATCH];
+#pragma unroll
+        for (int r = 0; r < BATCH; r++) {
+            float t = fmaf(x[r0 + r], s, GELU_LUT_X * s);
+            t = fminf(fmaxf(t, 0.0f), (float)GELU_LUT_N - 0.001f);
+            const float fl = floorf(t);
+            fr[r] = t - fl;
+            p[r] = reinterpret_cast<const f32x2*>(lut) + (int)fl;
+        }
+        sched_fence();
+        f32x2 ab[BATCH];
+#pragma unroll
+        for (int r = 0; r < BATCH; r++) ab[r] = *p[r];
+        sched_fence();
+#pragma unroll
+        for (int r = 0; r < BATCH; r++) out[r0 + r] = fmaf(fr[r], ab[r][1], ab[r][0]);
     }
-    sched_fence();
-    f32x2 ab[16];
-#pragma unroll
-    for (int r = 0; r < 16; r++) ab[r] = *p[r];
-    sched_fence();
-#pragma unroll
-    for (int r = 0; r < 16; r++) out[r] = fmaf(fr[r], ab[r][1], ab[r][0]);
 }
 
 // (measured: in the LDS-staged kernels of mlp.hpp the table form of gelu_both_8 changes nothing — they are barrier- / LDS-bound)

@@ -125,8 +125,8 @@ __device__ __forceinline__ void mc_layernorm(const frag_t<T> (&xf)[C / 16], frag
 }
 
 // ===================================================================================================== forward
-template <class T, int C, int WPB>
-__global__ void __launch_bounds__(64 * WPB)
+template <class T, int C, int WPB, int MINW>
+__global__ void __launch_bounds__(64 * WPB, MINW)
 mlpc_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, const float* __restrict__ ln_w, const float* __restrict__ ln_b,
                 const T* __restrict__ W1, const float* __restrict__ b1, const T* __restrict__ W2, const float* __restrict__ b2,
                 const float* __restrict__ gamma, int M, float eps) {

@@ -81,7 +81,7 @@ def test_backbone_fp32_vs_reference_golden_emu(name):
     compare(got, load_golden(name), rtol=1e-3, what=f'hip(emu) vs reference [{name}]', grad_rtol=1e-3)
 
 
-@pytest.mark.parametrize('dtype,rtol,grtol', [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 4e-2, 8e-2)])
+@pytest.mark.parametrize('dtype,rtol,grtol', [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 3e-2, 5e-2)])
 def test_backbone_fused_mlp_path_emu(monkeypatch, dtype, rtol, grtol):
     """Opt-in fused-MLP route (RVT_FUSED_MLP=1; stages with C in {64,128}) against the reference golden."""
     from rvt_amd import _lib
@@ -96,7 +96,7 @@ def test_backbone_fused_mlp_path_emu(monkeypatch, dtype, rtol, grtol):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('dtype,rtol,grtol', [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 4e-2, 8e-2)])
+@pytest.mark.parametrize('dtype,rtol,grtol', [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 3e-2, 5e-2)])
 def test_backbone_fused_mlp_path_gpu(monkeypatch, dtype, rtol, grtol):
     monkeypatch.setenv('RVT_FUSED_MLP', '1')
     got = run_hip_case('micro', torch.device('cuda', 0), dtype, with_batch2=False)
@@ -114,10 +114,10 @@ def test_backbone_fp32_vs_reference_golden_gpu(name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('name', ['micro', 'tiny_gen1_gamma', 'base_1mpx'])
+@pytest.mark.parametrize('name', ['micro', 'tiny_gen1_gamma', 'base_qvga', 'base_1mpx'])
 def test_backbone_bf16_vs_reference_golden_gpu(name):
     """bf16 performance mode against the fp32 reference: stated looser bound (bf16 has 8 mantissa bits;
-    errors accumulate through 4 stages x T recurrent steps): 4e-2 of the tensor scale on features,
-    8e-2 on gradients."""
+    errors accumulate through 4 stages x T recurrent steps): 3e-2 of the tensor scale on features, 5e-2 on gradients
+    (round 2, tightened from 4e-2 / 8e-2: the worst measured ratios on MI355X are 0.86 of 2.5e-2 / 4e-2, profiles/r2/bf16_worst.txt)."""
     got = run_hip_case(name, torch.device('cuda', 0), torch.bfloat16, with_batch2=False)
-    compare(got, load_golden(name), rtol=4e-2, what=f'hip bf16 vs reference [{name}]', grad_rtol=8e-2)
+    compare(got, load_golden(name), rtol=3e-2, what=f'hip bf16 vs reference [{name}]', grad_rtol=5e-2)
