@@ -415,11 +415,6 @@ template <class K> static int mc_grid(K kernel, int threads, int M, int wpb) {
     const int want = ((M + 31) / 32 + wpb - 1) / wpb;
     return imax(1, imin(want, resident_override > 0 ? resident_override : 256 * per_cu));
 }
-template <class T> static int mc_wgrad_grid(int M) {
-    auto k = mlpc_bwd_wgrad_kernel<T, 64>;
-    const int per_cu = resident_per_cu(k, 512, 1);
-    return imax(1, imin((M + 31) / 32, 256 * per_cu));
-}
 extern "C" {
 
 int rvt_mlp_fwd(const void* xmid, void* xout, void* g_out, void* gp_out, void* v2_out, const float* ln_w, const float* ln_b,
@@ -500,8 +495,6 @@ size_t rvt_mlp_bwd_fused_ws_floats(int dtype, int C, int M) {
     size_t grid = dtype == RVT_BF16 ? mlp_bwd_fused_grid<bf16, 0>(M) : mlp_bwd_fused_grid<float, 0>(M);
     const size_t g2 = dtype == RVT_BF16 ? mlp_bwd_fused_grid<bf16, 2>(M) : mlp_bwd_fused_grid<float, 2>(M);
     if (g2 > grid) grid = g2;
-    const size_t g3 = dtype == RVT_BF16 ? mc_wgrad_grid<bf16>(M) : mc_wgrad_grid<float>(M);
-    if (g3 > grid) grid = g3;
     return grid * ((size_t)2 * 4 * C * C + 2 * 4 * C + C);
 }
 
@@ -550,18 +543,6 @@ int rvt_mlp_bwd_recompute_wgrad(const void* dxout, const void* xmid, const float
     RVT_CHECK(ws != nullptr && M >= 1, "mlp_bwd_recompute_wgrad: workspace required");
     hipStream_t st = (hipStream_t)stream;
     int grid = 0;
-    // (measured on MI355X, 7.74 M tokens: the chunk-per-wave weight-gradient kernel re-reads its rows once per wave —
-    // 7 GB fetched for 2 GB of input, 4.85 ms against 2.85 ms for the LDS-tile kernel; opt-in until its loads are shared)
-    static const int chain_wgrad = getenv("RVT_MLP_CHAIN_WGRAD") ? atoi(getenv("RVT_MLP_CHAIN_WGRAD")) : 0;
-    if (chain_wgrad && mlp_chain_on(dtype, C)) {
-        DISPATCH_DTYPE(dtype, {
-            grid = mc_wgrad_grid<T>(M);
-            hipLaunchKernelGGL((mlpc_bwd_wgrad_kernel<T, 64>), dim3(grid), dim3(512), 0, st, (const T*)dxout, (const T*)xmid, ln_w,
-                               ln_b, (const T*)w1, b1, (const T*)w2g_t, ws, M, eps);
-        });
-        mlp_fold_partials(ws, grid, C, dw1, db1, s2, cs2, st);
-        return check_launch("mlp_bwd_recompute_wgrad(chain)");
-    }
     DISPATCH_DTYPE(dtype, {
         grid = mlp_bwd_fused_grid<T, 2>(M);
         hipLaunchKernelGGL((mlp_bwd_fused_kernel<T, 64, 2>), dim3(grid, 2), dim3(256), 0, st, (const T*)dxout, (const T*)xmid,

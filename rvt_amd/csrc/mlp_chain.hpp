@@ -13,11 +13,11 @@
 //
 //   mlpc_fwd_kernel        reads xmid, writes xout                                       (nothing saved: backward recomputes)
 //   mlpc_bwd_dgrad_kernel  reads dxout, xmid; writes dxmid = dxout + LN2'(dh W1), dh = (dxout (W2 gamma)) * GELU'(h)
-//   mlpc_bwd_wgrad_kernel  reads dxout, xmid; accumulates dW1, db1, S2 = dxout^T g, cs2 in registers across its persistent
-//                          tile walk: wave w of a workgroup owns hidden chunk w, the
-//                          products are computed N-form (A = token rows) so that the hidden index sits in the lanes and the
-//                          tokens in the registers = the contraction index of the weight gradients, and the token-major
-//                          operands v2 / dxout are transposed by an MFMA with an identity operand (exact; the matrix pipe is idle).
+// (The weight gradients of the MLP half stay with mlp_bwd_fused_kernel<MODE 2> of mlp.hpp.  A chained version — wave w of
+// a workgroup owns hidden chunk w, products in N-form so that the hidden index sits in the lanes and the tokens in the
+// registers, v2 / dxout transposed by identity MFMAs — was built and measured in round 2: 4.85 ms, 4.16 with a lock-step
+// barrier, 3.05 with the weights in LDS, against 3.05 ms for the LDS-tile kernel: its eight waves re-read the same rows
+// (7 GB fetched for 2 GB of input) and two waves per SIMD do not hide the load latency.  Removed)
 #pragma once
 #include "common.hpp"
 #include "attn_block.hpp"
@@ -41,39 +41,6 @@ __device__ __forceinline__ void chain_stage_weights(char* dst, const T* __restri
             for (int e = 0; e < 4; e++) { v[e] = p[e]; v[4 + e] = p[8 + e]; }
         }
         opm_store_frag<T>(dst, rows, row, fcg, v);
-    }
-}
-
-// exact-erf GELU / GELU' (common.hpp) on the 16 accumulator registers of a block, two values per packed instruction
-__device__ __forceinline__ void gelu_acc(const f32x16& h, float (&g)[16]) {
-#pragma unroll
-    for (int i = 0; i < 16; i += 2) {
-        const f32x2 v = {h[i], h[i + 1]};
-        const f32x2 av = {fabsf(v[0]), fabsf(v[1])};
-        const f32x2 d = fma2(av, f32x2{0.23164189f, 0.23164189f}, f32x2{1.0f, 1.0f});
-        const f32x2 t = {fast_rcp(d[0]), fast_rcp(d[1])};
-        const f32x2 a = v * v * -0.72134752044448170f;
-        const f32x2 e = {fast_exp2(a[0]), fast_exp2(a[1])};
-        f32x2 poly = fma2(t, f32x2{0.5307027145f, 0.5307027145f}, f32x2{-0.7265760135f, -0.7265760135f});
-        poly = fma2(t, poly, f32x2{0.7107068705f, 0.7107068705f});
-        poly = fma2(t, poly, f32x2{-0.142248368f, -0.142248368f});
-        poly = fma2(t, poly, f32x2{0.127414796f, 0.127414796f});
-        const f32x2 q = (t * poly) * e;
-        const f32x2 omq = 1.0f - q;
-        const f32x2 c = {v[0] < 0.0f ? q[0] : omq[0], v[1] < 0.0f ? q[1] : omq[1]};
-        const f32x2 gg = v * c;
-        g[i] = gg[0]; g[i + 1] = gg[1];
-    }
-}
-__device__ __forceinline__ void gelu_both_acc(const f32x16& h, float (&g)[16], float (&gp)[16]) {
-#pragma unroll
-    for (int i = 0; i < 16; i += 8) {
-        float x8[8], g8[8], p8[8];
-#pragma unroll
-        for (int e = 0; e < 8; e++) x8[e] = h[i + e];
-        gelu_both_8(x8, g8, p8);
-#pragma unroll
-        for (int e = 0; e < 8; e++) { g[i + e] = g8[e]; gp[i + e] = p8[e]; }
     }
 }
 
@@ -331,120 +298,6 @@ mlpc_bwd_dgrad_kernel(const T* __restrict__ dxout, const T* __restrict__ xmid, T
         float sum = 0.f;
         for (int w = 0; w < WPB; w++) sum += red[w * 2 * C + v];
         atomicAdd((v < C ? dln_w : dln_b) + (v % C), sum);
-    }
-}
-
-// =========================================================================== backward: weight gradients
-// Workgroup of 4C/32 waves; all of them walk the same 32-token tiles (tile = blockIdx.x, += gridDim.x), wave w owns the
-// hidden columns j = 32 w .. 32 w + 31.  Partial results per workgroup in `ws`, laid out as mlp_fold_partials expects:
-// [dW1: grid x 4C x C][S2: grid x C x 4C][db1: 2 grid x 4C][cs2: grid x C].
-template <class T, int C>
-__global__ void __launch_bounds__(64 * (4 * C / 32))
-mlpc_bwd_wgrad_kernel(const T* __restrict__ dxout, const T* __restrict__ xmid, const float* __restrict__ ln_w,
-                      const float* __restrict__ ln_b, const T* __restrict__ W1, const float* __restrict__ b1,
-                      const T* __restrict__ W2gT, float* __restrict__ ws, int M, float eps) {
-    constexpr int KS = C / 16, NCB = C / 32, HID = 4 * C, NW = HID / 32;
-    typedef McSmem<T, C> S;
-    __shared__ __attribute__((aligned(16))) char smem[2 * S::W_1 + 2 * C * 4];
-    char* const W1_l = smem;
-    char* const W2_l = smem + S::W_1;
-    float* const kst = reinterpret_cast<float*>(smem + 2 * S::W_1);
-    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, half = lane >> 5, wave = tid >> 6;
-    chain_stage_weights<T, C, false>(W1_l, W1, HID, tid, 64 * NW);
-    chain_stage_weights<T, C, false>(W2_l, W2gT, HID, tid, 64 * NW);
-    for (int i = tid; i < C; i += 64 * NW) { kst[i] = ln_w[i]; kst[C + i] = ln_b[i]; }
-    __syncthreads();
-    const float b1v = b1[32 * wave + li];
-    // identity operand pieces: row n = lane & 31 of a 32-column block, k-step m of the block's two: 1 at k = n
-    frag_t<T> idf[2];
-#pragma unroll
-    for (int m = 0; m < 2; m++)
-#pragma unroll
-        for (int e = 0; e < 8; e++) idf[m][e] = (T)((16 * m + 8 * half + e == li) ? 1.0f : 0.0f);
-
-    f32x16 dw1[NCB], s2[NCB];
-#pragma unroll
-    for (int cb = 0; cb < NCB; cb++) { acc_zero(dw1[cb]); acc_zero(s2[cb]); }
-    float db1 = 0.f, cs2[NCB];
-#pragma unroll
-    for (int cb = 0; cb < NCB; cb++) cs2[cb] = 0.f;
-
-    const int n_tiles = (M + 31) / 32;
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int row = tile * 32 + li;
-        const bool valid = row < M;
-        frag_t<T> uf[KS], df[KS];
-        // all waves read the SAME rows: keep them in step (the barrier is uniform: the tile walk does not depend on the wave), so
-        // that seven of the eight reads of a line hit the L1 / L2 while it is still there
-        __syncthreads();
-        mc_load_row<T, C>(uf, xmid, row, valid, half);
-        mc_load_row<T, C>(df, dxout, row, valid, half);
-        float mean, rstd;
-        mc_layernorm<T, C>(uf, uf, kst, kst + C, valid, half, eps, mean, rstd);
-        // N-form products: accumulator col = hidden j (this lane), registers = the tile's tokens
-        f32x16 h, dg;
-        acc_zero(h);
-        acc_zero(dg);
-#pragma unroll
-        for (int ks = 0; ks < KS; ks++) {
-            mma32(h, uf[ks], opm_load_frag<T>(W1_l, HID, 32 * wave + li, 2 * ks + half));     // this wave's weight rows
-            mma32(dg, df[ks], opm_load_frag<T>(W2_l, HID, 32 * wave + li, 2 * ks + half));
-        }
-#pragma unroll
-        for (int r = 0; r < 16; r++) h[r] += b1v;
-        float g[16], gp[16];
-        gelu_both_acc(h, g, gp);
-        float dh[16];
-#pragma unroll
-        for (int r = 0; r < 16; r++) { dh[r] = dg[r] * gp[r]; db1 += dh[r]; }
-        frag_t<T> gf[2], dhf[2];
-#pragma unroll
-        for (int q = 0; q < 2; q++) { gf[q] = arr_slot_frag<T>(g, q); dhf[q] = arr_slot_frag<T>(dh, q); }
-#pragma unroll
-        for (int cb = 0; cb < NCB; cb++) {
-            // transposes by identity: (v2, dxout)[token][32 cb + .] -> accumulators col = channel, registers = tokens
-            f32x16 vt, dt;
-            acc_zero(vt);
-            acc_zero(dt);
-#pragma unroll
-            for (int m = 0; m < 2; m++) {
-                mma32(vt, uf[2 * cb + m], idf[m]);
-                mma32(dt, df[2 * cb + m], idf[m]);
-            }
-            if (wave == 0) {
-#pragma unroll
-                for (int r = 0; r < 16; r++) cs2[cb] += dt[r];
-            }
-#pragma unroll
-            for (int q = 0; q < 2; q++) {
-                mma32(dw1[cb], dhf[q], acc_slot_frag<T>(vt, q));        // rows j, columns c
-                mma32(s2[cb], acc_slot_frag<T>(dt, q), gf[q]);          // rows c, columns j
-            }
-        }
-    }
-    const size_t nwg = gridDim.x, wg = blockIdx.x;
-    float* const p_dw1 = ws + wg * (size_t)(HID * C);
-    float* const p_s2 = ws + nwg * (size_t)(HID * C) + wg * (size_t)(C * HID);
-    float* const p_db1 = ws + 2 * nwg * (size_t)(HID * C) + (wg * 2) * (size_t)HID;
-    float* const p_cs2 = ws + 2 * nwg * (size_t)(HID * C) + 2 * nwg * (size_t)HID + wg * (size_t)C;
-#pragma unroll
-    for (int cb = 0; cb < NCB; cb++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            p_dw1[(size_t)(32 * wave + acc_row(r, lane)) * C + 32 * cb + li] = dw1[cb][r];
-            p_s2[(size_t)(32 * cb + acc_row(r, lane)) * HID + 32 * wave + li] = s2[cb][r];
-        }
-    db1 += __shfl_xor(db1, 32);
-    if (half == 0) {
-        p_db1[32 * wave + li] = db1;
-        p_db1[HID + 32 * wave + li] = 0.f;
-    }
-    if (wave == 0) {
-#pragma unroll
-        for (int cb = 0; cb < NCB; cb++) {
-            const float v = cs2[cb] + __shfl_xor(cs2[cb], 32);
-            if (half == 0) p_cs2[32 * cb + li] = v;
-        }
     }
 }
 
