@@ -402,8 +402,11 @@ template <class T, int NB> struct AbBwdScratch {          // per wave: P and dS 
 };
 
 // dx = dxmid + LN1'( dqkv Wqkv ; x ),  dqkv = attention backward of da = dxmid (gamma Wp)   — dqkv (and u = LN1(x)) go to
-// HBM for the qkv weight-gradient GEMM; LayerNorm parameter gradients are accumulated per workgroup (LDS) and leave as
-// one atomic per channel per workgroup.
+// HBM for the qkv weight-gradient GEMM; LayerNorm parameter gradients leave as one atomic per channel per workgroup.
+// (Measured and dropped in round 2: the qkv weight gradient accumulated inside this kernel — dqkv blocks transposed by
+// identity MFMAs, multiplied with u in the same form, 32x32 results added into an LDS-resident fp32 image of dW with
+// ds_add_f32: correct, but an LDS float atomic costs ~180 cycles per wave instruction on gfx950 — 16.7 ms against 2.7 ms for
+// this kernel plus the weight-gradient GEMM.)
 template <class T, int C, int NB, bool LN, int WPB>
 __global__ void __launch_bounds__(64 * WPB, 1)
 attn_block_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dxmid, T* __restrict__ dx, T* __restrict__ dqkv,
@@ -413,16 +416,26 @@ attn_block_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dxmid, T* _
     typedef AbSmem<T, C> S;
     typedef AbBwdScratch<T, NB> SC;
     constexpr int KS = C / 16, HEADS = C / 32, NCB = C / 32, LP = 32 * NB;
-    // per wave: P / dS scratch, then (LN) lane-private LayerNorm parameter-gradient sums [C values][64 lanes] fp32
-    constexpr int DLN = LN ? C * 64 * 4 : 0;
-    __shared__ __attribute__((aligned(16))) char smem[S::OFF_S + WPB * (SC::BYTES + DLN)];
+    // per wave: P / dS scratch
+    constexpr int DLN = 0;
+    __shared__ __attribute__((aligned(16))) char smem[S::OFF_S + WPB * (SC::BYTES + DLN) + (LN ? WPB * 2 * C * 4 : 0)];
     char* const Wq_l = smem;
     char* const Wp_l = smem + S::OFF_P;
     float* const kst = reinterpret_cast<float*>(smem + S::OFF_K);
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, half = lane >> 5, wave = tid >> 6;
     char* const Pl = smem + S::OFF_S + wave * (SC::BYTES + DLN);
     char* const dSl = Pl + SC::ONE;
-    float* const dln_l = reinterpret_cast<float*>(Pl + SC::BYTES) + lane;                 // value v of this lane at dln_l[64 v]
+    // LayerNorm parameter gradients = column sums over tokens of du * xhat and du: the row pieces hold tokens in the LANES; an
+    // MFMA against an identity operand turns a piece block into "col = channel, registers = tokens" (exact), where the column
+    // sum is an in-lane sum — one running value per 32-channel block instead of per-lane partial sums for every channel
+    frag_t<T> idf[2];
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) idf[m][e] = (T)((16 * m + 8 * half + e == li) ? 1.0f : 0.0f);
+    float aw[NCB], ab[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) { aw[cb] = 0.f; ab[cb] = 0.f; }
 
     ab_stage_weights<T, C, false>(Wq_l, Wqkv, 3 * C, tid, 64 * WPB);
     ab_stage_weights<T, C, false>(Wp_l, WpgT, C, tid, 64 * WPB);
@@ -431,10 +444,6 @@ attn_block_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dxmid, T* _
         kst[S::K_LNB + i] = LN ? ln_b[i] : 0.f;
     }
     for (int i = tid; i < 3 * C; i += 64 * WPB) kst[S::K_BQKV + i] = bqkv[i];
-    if (LN) {
-#pragma unroll
-        for (int v = 0; v < C; v++) dln_l[64 * v] = 0.f;
-    }
     __syncthreads();
 
     const int klim = g.L - 32 * (NB - 1) - 4 * half;        // accumulator rows (r & 3) + 8 (r >> 2) >= klim of the last key block are padding
@@ -583,11 +592,6 @@ attn_block_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dxmid, T* _
         }
 
         // ---- dx = dxmid + LN1'(du)  (maxvit.py:229,268) in operand-piece form ----
-        float tw[KS][8], tb[KS][8];           // this partition's LayerNorm parameter-gradient terms of this lane's channels
-#pragma unroll
-        for (int ks = 0; ks < KS; ks++)
-#pragma unroll
-            for (int e = 0; e < 8; e++) { tw[ks][e] = 0.f; tb[ks][e] = 0.f; }
 #pragma unroll
         for (int b = 0; b < NB; b++) {
             float d8[KS][8];
@@ -614,9 +618,23 @@ attn_block_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dxmid, T* _
                         const float gw = d8[ks][e] * w[e];
                         gsum += gw;
                         gxsum += gw * xh[ks][e];
-                        tw[ks][e] += d8[ks][e] * xh[ks][e];
-                        tb[ks][e] += d8[ks][e];
                     }
+                }
+#pragma unroll
+                for (int cb = 0; cb < NCB; cb++) {
+                    f32x16 tw, tb;
+                    acc_zero(tw);
+                    acc_zero(tb);
+#pragma unroll
+                    for (int m = 0; m < 2; m++) {
+                        float pw[8];
+#pragma unroll
+                        for (int e = 0; e < 8; e++) pw[e] = d8[2 * cb + m][e] * xh[2 * cb + m][e];
+                        mma32(tw, frag_from_float<T>(pw), idf[m]);
+                        mma32(tb, frag_from_float<T>(d8[2 * cb + m]), idf[m]);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; r++) { aw[cb] += tw[r]; ab[cb] += tb[r]; }
                 }
                 gsum += __shfl_xor(gsum, 32);
                 gxsum += __shfl_xor(gxsum, 32);
@@ -640,28 +658,23 @@ attn_block_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dxmid, T* _
                 }
             }
         }
-        if (LN) {       // lane-private LDS sums (no conflicts, no atomics): value (ks, e) of dln_w at 8 ks + e, of dln_b at C/2 + 8 ks + e
-#pragma unroll
-            for (int ks = 0; ks < KS; ks++)
-#pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    dln_l[64 * (8 * ks + e)] += tw[ks][e];
-                    dln_l[64 * (C / 2 + 8 * ks + e)] += tb[ks][e];
-                }
-        }
     }
     if (LN) {
-        // fold lanes and waves: thread (which, half, ks, e) sums the 32 lanes of that half over all waves; one atomic per channel
+        // fold the two halves and the waves: one atomic per channel per workgroup
+        float* const red = reinterpret_cast<float*>(smem + S::OFF_S + WPB * (SC::BYTES + DLN));      // [WPB][dln_w C | dln_b C]
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) {
+            const float a = aw[cb] + __shfl_xor(aw[cb], 32), b = ab[cb] + __shfl_xor(ab[cb], 32);
+            if (half == 0) {
+                red[wave * 2 * C + 32 * cb + li] = a;
+                red[wave * 2 * C + C + 32 * cb + li] = b;
+            }
+        }
         __syncthreads();
         for (int v = tid; v < 2 * C; v += 64 * WPB) {
-            const int which = v / C, hh = (v / (C / 2)) & 1, j = v % (C / 2);
             float sum = 0.f;
-            for (int w = 0; w < WPB; w++) {
-                const float* base = reinterpret_cast<const float*>(smem + S::OFF_S + w * (SC::BYTES + DLN) + SC::BYTES);
-                for (int l = 0; l < 32; l++) sum += base[64 * (which * (C / 2) + j) + 32 * hh + l];
-            }
-            const int ch = 16 * (j >> 3) + 8 * hh + (j & 7);
-            atomicAdd((which == 0 ? dln_w : dln_b) + ch, sum);
+            for (int w = 0; w < WPB; w++) sum += red[w * 2 * C + v];
+            atomicAdd((v < C ? dln_w : dln_b) + (v % C), sum);
         }
     }
 }
