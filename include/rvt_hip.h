@@ -196,6 +196,11 @@ int rvt_dwconv_wgrad(const void* x, int ldx, const void* dy, int ldy, float* dw,
 int rvt_token_mask_fwd(void* x, const unsigned char* mask, const float* token, int dtype, int M, int C, void* stream);
 int rvt_token_mask_bwd(void* dx, const unsigned char* mask, float* dtoken, int dtype, int M, int C, void* stream);
 
+/* Labelled-frame gather of the training step (modules/utils/detection.py:32-46, BackboneFeatureSelector): dst[n] = src[idx[n]]
+ * over whole frames of frame_bytes (a multiple of 16) for n < n_sel; idx: int32 frame indices (t*B + b), on the device.
+ * scatter = 1 is the backward: dst[idx[n]] = src[n] (dst zero-filled by the caller; indices distinct). */
+int rvt_gather_frames(const void* src, const int* idx, void* dst, int n_sel, size_t frame_bytes, int scatter, void* stream);
+
 /* Zero state rows of samples with mask[b] != 0 (modules/utils/detection.py:96-113).
  * st is [B][per_sample] of float32 (is_f32) or `dtype`. */
 int rvt_state_reset_masked(void* st, const unsigned char* mask, int dtype, int B, size_t per_sample, void* stream);

@@ -51,6 +51,7 @@ _SIGS = {
     'rvt_token_mask_fwd': [_vp, _vp, _vp, _i, _i, _i, _vp],
     'rvt_token_mask_bwd': [_vp, _vp, _vp, _i, _i, _i, _vp],
     'rvt_state_reset_masked': [_vp, _vp, _i, _i, _sz, _vp],
+    'rvt_gather_frames': [_vp, _vp, _vp, _i, _sz, _i, _vp],
     'rvt_pack_table': [_vp, _i, _i, _i, _vp],
     'rvt_mlp_bwd_recompute_dgrad': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
     'rvt_mlp_bwd_recompute_wgrad': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],

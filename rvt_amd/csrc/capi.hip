@@ -928,6 +928,19 @@ int rvt_layerscale_grad_table(const void* descs, int n_desc, int total_blocks, v
     return check_launch("layerscale_grad_table");
 }
 
+int rvt_gather_frames(const void* src, const int* idx, void* dst, int n_sel, size_t frame_bytes, int scatter, void* stream) {
+    RVT_CHECK(frame_bytes % 16 == 0, "gather_frames: frames of %zu bytes are not a whole number of 16-byte vectors", frame_bytes);
+    if (n_sel <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t fv = frame_bytes / 16;
+    const int grid = grid_for((size_t)n_sel * fv, 8192);
+    if (scatter)
+        hipLaunchKernelGGL((gather_frames_kernel<true>), dim3(grid), dim3(256), 0, st, (const u32x4*)src, idx, (u32x4*)dst, n_sel, fv);
+    else
+        hipLaunchKernelGGL((gather_frames_kernel<false>), dim3(grid), dim3(256), 0, st, (const u32x4*)src, idx, (u32x4*)dst, n_sel, fv);
+    return check_launch("gather_frames");
+}
+
 int rvt_state_reset_masked(void* st_, const unsigned char* mask, int dtype, int B, size_t per_sample, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     int grid = grid_for((size_t)B * per_sample, 4096);

@@ -276,6 +276,21 @@ state_reset_kernel(S* __restrict__ st, const unsigned char* __restrict__ mask, i
         if (mask[i / per_sample]) st[i] = (S)0.0f;
 }
 
+// ---- labelled-frame gather (reference modules/utils/detection.py:32-46, BackboneFeatureSelector): the feature maps of the
+// (t, b) frames that carry labels, concatenated — dst[n] = src[idx[n]] over whole frames of `frame_vec` 16-byte vectors;
+// SCATTER: the backward, dst[idx[n]] = src[n] into a zero-filled gradient (indices are distinct by construction).
+template <bool SCATTER>
+__global__ void __launch_bounds__(256)
+gather_frames_kernel(const u32x4* __restrict__ src, const int* __restrict__ idx, u32x4* __restrict__ dst, int n_sel, size_t frame_vec) {
+    const size_t total = (size_t)n_sel * frame_vec;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t n = i / frame_vec, v = i - n * frame_vec;
+        const size_t f = (size_t)idx[n];
+        if (SCATTER) dst[f * frame_vec + v] = src[i];
+        else dst[i] = src[f * frame_vec + v];
+    }
+}
+
 }  // namespace rvt
 
 namespace rvt {

@@ -414,3 +414,33 @@ def state_reset_masked(st: Tensor, mask: Tensor) -> None:
     B = st.shape[0]
     m = mask.to(device=st.device, dtype=torch.uint8).contiguous()
     L.call('rvt_state_reset_masked', L.ptr(st), L.ptr(m), L.dtype_code(st.dtype), B, st.numel() // B, L.stream_of(st))
+
+
+class _GatherFrames(torch.autograd.Function):
+    """frames (N, ...) contiguous -> frames[idx] (one HIP gather; backward = one scatter into zeros)."""
+
+    @staticmethod
+    def forward(ctx, frames: Tensor, idx: Tensor) -> Tensor:
+        n = int(idx.numel())
+        out = torch.empty((n, *frames.shape[1:]), dtype=frames.dtype, device=frames.device)
+        fb = frames[0].numel() * frames.element_size()
+        L.call('rvt_gather_frames', L.ptr(frames), L.ptr(idx), L.ptr(out), n, fb, 0, L.stream_of(frames))
+        ctx.save_for_backward(idx)
+        ctx.shape = tuple(frames.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout: Tensor):
+        (idx,) = ctx.saved_tensors
+        dout = dout.contiguous()
+        d = torch.zeros(ctx.shape, dtype=dout.dtype, device=dout.device)
+        fb = d[0].numel() * d.element_size()
+        L.call('rvt_gather_frames', L.ptr(dout), L.ptr(idx), L.ptr(d), int(idx.numel()), fb, 1, L.stream_of(dout))
+        return d, None
+
+
+def gather_frames(frames: Tensor, idx: Tensor) -> Tensor:
+    """frames: (N, ...) contiguous; idx: int32 device tensor of DISTINCT frame indices.  Differentiable in `frames`."""
+    assert idx.dtype == torch.int32 and frames.is_contiguous()
+    return _GatherFrames.apply(frames, idx)
+

@@ -16,6 +16,7 @@ from typing import Any, Callable, Dict, List, Optional
 
 import torch
 
+from . import ops
 from .states import RNNStates, merge_mixed_batches
 from .types import DataType, Mode
 
@@ -53,19 +54,30 @@ class BackboneSequenceModule:
 
     @staticmethod
     def _select_labelled(feats, labels_seq, T, stages):
-        """BackboneFeatureSelector semantics: concatenate, over t, the batch rows that carry labels."""
-        sel_feats = {s: [] for s in stages}
+        """BackboneFeatureSelector semantics (modules/utils/detection.py:32-46): concatenate, over t, the batch rows that
+        carry labels — as ONE device gather per stage over the flattened (t, b) frame axis (rvt_gather_frames) instead of
+        T index_selects and a cat."""
+        flat_idx: List[int] = []
         labels = []
+        B = feats[stages[0]].shape[1]
         for t in range(T):
             cur, valid_idx = labels_seq[t].get_valid_labels_and_batch_indices()
             if len(cur) > 0:
-                idx = torch.as_tensor(valid_idx, device=feats[stages[0]].device)
-                for s in stages:
-                    sel_feats[s].append(feats[s][t].index_select(0, idx))
+                flat_idx.extend(t * B + int(b) for b in valid_idx)
                 labels.extend(cur)
         if not labels:
             return None, labels
-        return {s: torch.cat(v, dim=0) for s, v in sel_feats.items()}, labels
+        dev = feats[stages[0]].device
+        idx = torch.tensor(flat_idx, dtype=torch.int32).to(dev)
+        sel = {}
+        for s in stages:
+            f = feats[s]                                         # (T, B, C, H, W)-shaped view of channels-last storage
+            cl = f.permute(0, 1, 3, 4, 2)                        # (T, B, H, W, C): contiguous for the backbone's outputs
+            if not cl.is_contiguous():
+                cl = cl.contiguous()
+            g = ops.gather_frames(cl.reshape(cl.shape[0] * cl.shape[1], *cl.shape[2:]), idx)
+            sel[s] = g.permute(0, 3, 1, 2)                       # back to NCHW-shaped (channels-last strides), as the FPN expects
+        return sel, labels
 
     # -- Lightning-compatible entry points ------------------------------------------------------------------
     def training_step(self, batch: Any, batch_idx: int) -> Dict[str, Any]:

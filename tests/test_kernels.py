@@ -460,3 +460,17 @@ def test_mlp_bwd_fused_everything_on_chip(backend, dt, M, route, monkeypatch):
     assert torch.equal(dxm2.cpu(), dxm.cpu())
     close(dw1, 2 * w1r.grad, dt, 'mlp_bwd_fused dW1 accumulate', mult=2 * mult)
     close(cs2, 2 * f64(dy).sum(0), dt, 'mlp_bwd_fused cs2 accumulate', mult=mult)
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+def test_gather_frames(backend, dt):
+    """rvt_gather_frames (labelled-frame gather of the training step, modules/utils/detection.py:32-46) and its backward."""
+    frames = rnd((7, 3, 5, 16), backend, dt, 1).requires_grad_(True)
+    idx = torch.tensor([5, 0, 6, 2], dtype=torch.int32, device=backend)
+    out = ops.gather_frames(frames, idx)
+    assert torch.equal(out.detach().cpu(), frames.detach().cpu()[idx.cpu().long()])
+    cot = rnd(tuple(out.shape), backend, dt, 2)
+    out.backward(cot)
+    want = torch.zeros_like(frames.detach()).cpu()
+    want[idx.cpu().long()] = cot.cpu()
+    assert torch.equal(frames.grad.cpu(), want)
