@@ -704,6 +704,17 @@ gemm_kernel(ASrc as, AXf axf, BSrc bs, BXf bxf, Ep ep, int M, int N, int K, int 
             mt = t / n_tiles; nt = t - mt * n_tiles;
             return w < chunk && t < total;
         }
+        if (panel_major == 3) {
+            // several N tiles per 128-row panel and too few panels for panel-major sweeps: dealing tiles N-fastest over consecutive
+            // workgroup ids puts the n_tiles readers of one A panel on up to 8 XCDs, i.e. 8 private L2s each fetch it (measured on
+            // M = 120960, N = 2048, K = 512: 1.04 GB fetched for a 124 MB A).  Instead panel p belongs to XCD p % 8 (workgroup id
+            // mod 8) and that XCD's workgroups walk its (panel, N tile) list side by side: one fetch, then L2 hits.
+            const int per = G >> 3, xcd = bx & 7;
+            const int u = (bx >> 3) + seq * per;
+            const int np_x = (m_tiles - xcd + 7) >> 3;
+            mt = (u / n_tiles) * 8 + xcd; nt = u - (u / n_tiles) * n_tiles;
+            return u < np_x * n_tiles;
+        }
         if (panel_major) { mt = bx + (seq / n_tiles) * G; nt = seq % n_tiles; return mt < m_tiles; }
         const int t = bx + seq * G;
         mt = t / n_tiles; nt = t - mt * n_tiles;
@@ -977,6 +988,13 @@ inline void launch_gemm(const ASrc& as, const AXf& axf, const BSrc& bs, const BX
         if (total > resident) gx = resident;
         panel_major = (n_tiles > 1 && m_tiles >= 4 * gx) ? 1 : 0;
         if (ASrc::SPATIAL_REUSE && total > gx && (gx & 7) == 0) panel_major = 2;
+        static const int xcd_panels = getenv("RVT_GEMM_XCD_PANELS") ? atoi(getenv("RVT_GEMM_XCD_PANELS")) : 1;    // (A/B knob)
+        if (panel_major == 0 && n_tiles > 1 && xcd_panels && total >= 8 * gx) {
+            // XCD-grouped panels (tile_of, mode 3).  Only for long tile walks: the per-XCD lists differ by up to one panel, which
+            // on a one- or two-round launch (the per-step ConvLSTM GEMMs: measured +16 % on rvt_lstm_dgrad) is a whole extra round.
+            gx = (gx + 7) & ~7;
+            panel_major = 3;
+        }
     }
     if (one_k)                // whole contraction in one K tile: single operand stage, more workgroups per CU
         hipLaunchKernelGGL((gemm_kernel<T, BN, TN, true, ASrc, AXf, BSrc, BXf, Ep>), dim3(gx, nsplit), dim3(256), 0, stream,
