@@ -170,16 +170,20 @@ int rvt_lstm_wgrad(const void* dz, const void* x, const void* h_prev, float* dw,
  *        (NULL = zeros); wt = w^T [2C][4C]; writes dx_all [T][M][C], dz_all [T][M][4C] (pre-activation gradients, natural
  *        gate order, operand of rvt_lstm_wgrad), dh0 [M][C], dc0 fp32 [M][C]. */
 int rvt_lstm_scan_supported(int dtype, int C);
+/*        bf16, C = 128 (rvt_lstm_scan_saves_gates): the weights live in the register file; with gates_out != NULL the forward
+ *        also stores the activated gates [T][M][4C] (natural order f,i,o,g), and the backward given `gates` reads them instead
+ *        of recomputing (W^T in registers; x_all / Hall unused; dz_all written for rvt_lstm_wgrad). */
+int rvt_lstm_scan_saves_gates(int dtype, int C);
 int rvt_lstm_scan_fwd(const void* x_all, void* Hall, const float* c0, float* c_last, void* Csave, const void* w,
-                      const float* bias, int dtype, int M, int C, int T_steps, void* stream);
+                      const float* bias, void* gates_out, int dtype, int M, int C, int T_steps, void* stream);
 /*        With dw != NULL (rvt_lstm_scan_bwd_ws_floats(dtype, C, M) > 0: bf16, C <= 64) the weight gradients are accumulated
  *        inside the kernel: dw [4C][2C] += dz^T [x | h_prev], db [4C] += colsum(dz) (natural gate order, fp32), through
  *        per-workgroup partial records in ws; dz_all is then neither written nor needed (may be NULL). */
 size_t rvt_lstm_scan_bwd_ws_floats(int dtype, int C, int M);
 int rvt_lstm_scan_bwd(const void* x_all, const void* Hall, const void* Csave, const float* c0, const void* dH,
                       const float* dc_last, const void* w, const void* wt, const float* bias, void* dx_all, void* dz_all,
-                      void* dh0, float* dc0, float* dw, float* db, float* ws, int dtype, int M, int C, int T_steps,
-                      void* stream);
+                      void* dh0, float* dc0, float* dw, float* db, float* ws, const void* gates, int dtype, int M, int C,
+                      int T_steps, void* stream);
 
 /* Depth-wise k x k conv (k = 3; groups = channels, padding k/2, stride 1) of the DWS-ConvLSTM (rnn.py:25-29,50-54)
  * on channels-last maps: y[n][y][x][c] = b[c] + sum_taps w[c][ky][kx] x[...][c].  x / y rows have pitch ldx / ldy

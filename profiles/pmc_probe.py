@@ -76,6 +76,17 @@ elif op in ('ab_fwd', 'ab_bwd', 'ab_fwd_ln', 'ab_bwd_ln'):      # fused attentio
         dxm = rnd(F_, H, W, C)
         dlw, dlb = (torch.zeros(C, device=dev), torch.zeros(C, device=dev)) if ln else (None, None)
         fn = lambda: ops.attn_block_bwd(x4, dxm, lw, lb, wqkv, bqkv, wp.t().contiguous(), dlw, dlb, F_, H, W, C, 32, 6, 10, True, 1e-5)
+elif op in ('conv_fwd_stem', 'conv_wgrad_stem'):      # stem: 7x7 stride-4 conv, 24 (20 padded) -> 64 channels, 504 frames of 384x640
+    del x, dy4
+    F_, Hi, Wi, Cp, Co, k, st, pd = 504, 384, 640, 24, 64, 7, 4, 3
+    inp = rnd(F_, Hi, Wi, Cp)
+    w = rnd(Co, k * k * Cp) * 0.05
+    if op == 'conv_fwd_stem':
+        fn = lambda: ops.conv_fwd(inp, w, k, st, pd)
+    else:
+        dy = rnd(F_, Hi // st, Wi // st, Co)
+        dw = torch.zeros(Co, k * k * Cp, device=dev)
+        fn = lambda: ops.conv_wgrad(inp, dy, dw, k, st, pd)
 for _ in range(3):
     fn()
 torch.cuda.synchronize()

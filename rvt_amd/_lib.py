@@ -56,8 +56,8 @@ _SIGS = {
     'rvt_mlp_bwd_recompute_dgrad': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
     'rvt_mlp_bwd_recompute_wgrad': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
     'rvt_mlp_bwd_fused': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
-    'rvt_lstm_scan_fwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
-    'rvt_lstm_scan_bwd': [_vp] * 16 + [_i, _i, _i, _i, _vp],
+    'rvt_lstm_scan_fwd': [_vp] * 8 + [_i, _i, _i, _i, _vp],
+    'rvt_lstm_scan_bwd': [_vp] * 17 + [_i, _i, _i, _i, _vp],
     'rvt_layerscale_grad_table': [_vp, _i, _i, _vp],
 }
 EXPORTS = sorted(list(_SIGS) + ['rvt_last_error', 'rvt_is_emulator', 'rvt_wgrad_workspace_floats',
@@ -82,6 +82,8 @@ def _bind(lib: ctypes.CDLL) -> ctypes.CDLL:
     lib.rvt_mlp_bwd_fused_ws_floats.argtypes = [_i, _i, _i]
     lib.rvt_lstm_scan_bwd_ws_floats.restype = ctypes.c_size_t
     lib.rvt_lstm_scan_bwd_ws_floats.argtypes = [_i, _i, _i]
+    lib.rvt_lstm_scan_saves_gates.restype = ctypes.c_int
+    lib.rvt_lstm_scan_saves_gates.argtypes = [_i, _i]
     lib.rvt_attn_block_supported.restype = ctypes.c_int
     lib.rvt_attn_block_supported.argtypes = [_i, _i, _i, _i]
     lib.rvt_lstm_scan_supported.restype = ctypes.c_int

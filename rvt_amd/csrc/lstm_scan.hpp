@@ -70,22 +70,30 @@ template <class T, int C, int NT, int TM> __device__ __forceinline__ void tile_l
 // x_all [Tn][M][C], Hall [Tn+1][M][C] (slot 0 = incoming h, filled by the caller; slots 1.. written here),
 // c0 fp32 [M][C] or null (zeros), c_last fp32 [M][C], Csave [Tn][M][C] (slot t = c_t as T) or null,
 // W [4C][2C] natural gate order f,i,o,g and input order [x|h] (rnn.py:52-61), bias fp32 [4C].
-template <class T, int C, int NW, int RB, bool W_LDS>
+// W_REG (bf16, C = 128, one wave per SIMD): the weights do not fit the LDS (256 KB) but they do fit the REGISTER FILE — wave w
+// needs the rows {g C + 32 w + lane} of all four gates, 64 operand pieces = 256 registers, loaded once per launch; streaming
+// them from L2 every step instead (W_LDS = W_REG = false) is what bounded the C = 128 scan (15.5 GB of L2 reads per launch).
+// gates_out (nullable): the activated gates [Tn][M][4C] (natural order f,i,o,g), for the reverse scan that does not recompute them.
+template <class T, int C, int NW, int RB, bool W_LDS, bool W_REG = false>
 __global__ void __launch_bounds__(64 * NW)
 lstm_scan_fwd_kernel(const T* __restrict__ x_all, T* __restrict__ Hall, const float* __restrict__ c0, float* __restrict__ c_last,
-                     T* __restrict__ Csave, const T* __restrict__ W, const float* __restrict__ bias, int M, int Tn) {
+                     T* __restrict__ Csave, const T* __restrict__ W, const float* __restrict__ bias, T* __restrict__ gates_out,
+                     int M, int Tn) {
     typedef LstmScanGeom<T, C, NW> Gm;
     constexpr int NT = Gm::NT, NWC = Gm::NWC, NWM = Gm::NWM, KTC = Gm::KTC;
     constexpr int TM = NWM * RB * 32;
     constexpr int TILE = KTC * TM * 128;
     constexpr int WPART = KTC * (4 * C) * 128;             // one [4C][C] half of W
     constexpr int NFX = (TM * (C / 8) + NT - 1) / NT;
-    __shared__ __attribute__((aligned(16))) char smem[(W_LDS ? 2 * WPART : 0) + 4 * TILE];
+    constexpr int GT = W_REG ? 4 * TILE : 0;               // gate staging [TM][4C] (four [TM][C] tiles)
+    static_assert(!(W_LDS && W_REG), "one home for the weights");
+    __shared__ __attribute__((aligned(16))) char smem[(W_LDS ? 2 * WPART : 0) + 4 * TILE + GT];
     char* const Wx = smem;
     char* const Wh = smem + (W_LDS ? WPART : 0);
     char* const Ax = smem + (W_LDS ? 2 * WPART : 0);
     char* const Ah0 = Ax + TILE;
     char* const Cs = Ax + 3 * TILE;
+    char* const Gs = Ax + 4 * TILE;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, half = lane >> 5;
@@ -101,6 +109,17 @@ lstm_scan_fwd_kernel(const T* __restrict__ x_all, T* __restrict__ Hall, const fl
             if (g8 < G) opm_store_frag<T>(Wx, 4 * C, n, g8, v);
             else opm_store_frag<T>(Wh, 4 * C, n, g8 - G, v);
         }
+    }
+    frag_t<T> wreg[W_REG ? 2 : 1][W_REG ? C / 16 : 1][W_REG ? 4 : 1];
+    if (W_REG) {
+#pragma unroll
+        for (int part = 0; part < 2; part++)
+#pragma unroll
+            for (int k16 = 0; k16 < C / 16; k16++)
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+                    wreg[W_REG ? part : 0][W_REG ? k16 : 0][W_REG ? g : 0] =
+                        frag_load<T>(W + (size_t)(g * C + wn * 32 + (lane & 31)) * 2 * C + part * C + (2 * k16 + (lane >> 5)) * 8);
     }
     // gate biases folded into the exp2 arguments; LDS byte offsets of this lane's 16 (row, channel) elements per row block
     // (fixed for the launch: computing the swizzle per element per step costs more VALU than the gate math itself)
@@ -142,7 +161,7 @@ lstm_scan_fwd_kernel(const T* __restrict__ x_all, T* __restrict__ Hall, const fl
 #pragma unroll
                 for (int g = 0; g < 4; g++) acc_zero(acc[i][g]);
             // (weights streamed from L2: keep the K loop rolled, or every B fragment of the step is hoisted and spilled)
-            constexpr int KUNROLL = W_LDS ? C / 16 : 1;
+            constexpr int KUNROLL = (W_LDS || W_REG) ? C / 16 : 1;
 #pragma unroll
             for (int part = 0; part < 2; part++) {         // [x_t | h_{t-1}] . W^T, K order = x columns then h columns
                 const char* const A = part ? Ah : Ax;
@@ -156,6 +175,7 @@ lstm_scan_fwd_kernel(const T* __restrict__ x_all, T* __restrict__ Hall, const fl
 #pragma unroll
                     for (int g = 0; g < 4; g++) {
                         if (W_LDS) b[g] = opm_load_frag<T>(Wl, 4 * C, g * C + ch, fcg);
+                        else if (W_REG) b[g] = wreg[W_REG ? part : 0][W_REG ? kc / 16 : 0][W_REG ? g : 0];
                         else b[g] = frag_load<T>(W + (size_t)(g * C + ch) * 2 * C + part * C + fcg * 8);
                     }
 #pragma unroll
@@ -178,6 +198,12 @@ lstm_scan_fwd_kernel(const T* __restrict__ x_all, T* __restrict__ Hall, const fl
                     const float hn = o * tanh_f(cn);
                     *reinterpret_cast<T*>(An + acc_elem_off(off0[i], r)) = (T)hn;
                     if (Csave != nullptr) *reinterpret_cast<T*>(Cs + acc_elem_off(off0[i], r)) = (T)cn;
+                    if (W_REG && gates_out != nullptr) {
+                        *reinterpret_cast<T*>(Gs + 0 * TILE + acc_elem_off(off0[i], r)) = (T)f;
+                        *reinterpret_cast<T*>(Gs + 1 * TILE + acc_elem_off(off0[i], r)) = (T)ig;
+                        *reinterpret_cast<T*>(Gs + 2 * TILE + acc_elem_off(off0[i], r)) = (T)o;
+                        *reinterpret_cast<T*>(Gs + 3 * TILE + acc_elem_off(off0[i], r)) = (T)g;
+                    }
                 }
             lds_barrier();                                 // h_t / c_t tiles complete; every wave is done with Ax
             {                                              // tile rows -> HBM in 16-byte pieces
@@ -189,6 +215,14 @@ lstm_scan_fwd_kernel(const T* __restrict__ x_all, T* __restrict__ Hall, const fl
                     if (m0 + row < M) {
                         frag_store<T>(hdst + (size_t)(m0 + row) * C + cg * 8, opm_load_frag<T>(An, TM, row, cg));
                         if (cdst != nullptr) frag_store<T>(cdst + (size_t)(m0 + row) * C + cg * 8, opm_load_frag<T>(Cs, TM, row, cg));
+                    }
+                }
+                if (W_REG && gates_out != nullptr) {
+                    T* const gdst = gates_out + (size_t)t * MC * 4;
+                    for (int f = tid; f < TM * 4 * G; f += NT) {
+                        const int row = f / (4 * G), gg = (f / G) % 4, cg = f % G;
+                        if (m0 + row < M)
+                            frag_store<T>(gdst + (size_t)(m0 + row) * 4 * C + gg * C + cg * 8, opm_load_frag<T>(Gs + gg * TILE, TM, row, cg));
                     }
                 }
             }
@@ -214,13 +248,16 @@ lstm_scan_fwd_kernel(const T* __restrict__ x_all, T* __restrict__ Hall, const fl
 // the whole launch (the dz tile and the [x | h] tiles are in LDS anyway; their token-contraction operands come out through the
 // transposing LDS read) and leave as one partial per workgroup in `ws` ([grid][4C x 2C | 4C] floats): dz never goes to HBM
 // (4 rows of C per token-step written + re-read by the weight-gradient GEMM otherwise).  Wave w owns dW rows 64 w .. 64 w + 63.
-template <class T, int C, int NW, bool W_LDS, bool WGRAD>
+// GATES (bf16, C = 128, one wave per SIMD): the activated gates saved by the W_REG forward are READ instead of recomputed, so
+// the only weights this kernel needs are the W^T pieces of its own 32 x- and 32 h-columns — 64 operand pieces = 256 registers,
+// loaded once per launch (x_all / Hall are then not read at all).
+template <class T, int C, int NW, bool W_LDS, bool WGRAD, bool GATES = false>
 __global__ void __launch_bounds__(64 * NW)
 lstm_scan_bwd_kernel(const T* __restrict__ x_all, const T* __restrict__ Hall, const T* __restrict__ Csave,
                      const float* __restrict__ c0, const T* __restrict__ dH, const float* __restrict__ dc_last,
                      const T* __restrict__ W, const T* __restrict__ Wt, const float* __restrict__ bias,
                      T* __restrict__ dx_all, T* __restrict__ dz_all, T* __restrict__ dh0, float* __restrict__ dc0,
-                     float* __restrict__ ws, int M, int Tn) {
+                     float* __restrict__ ws, const T* __restrict__ gates, int M, int Tn) {
     typedef LstmScanGeom<T, C, NW> Gm;
     constexpr int NT = Gm::NT, NWC = Gm::NWC, NWM = Gm::NWM, KTC = Gm::KTC, BK = Gm::BK;
     constexpr int TM = NWM * 32;
@@ -231,7 +268,8 @@ lstm_scan_bwd_kernel(const T* __restrict__ x_all, const T* __restrict__ Hall, co
     constexpr int DZ = KT4 * TM * 128;
     constexpr int G = C / 8;
     constexpr int NFX = (TM * G + NT - 1) / NT;
-    __shared__ __attribute__((aligned(16))) char smem[(W_LDS ? 2 * WPART : 0) + 5 * TILE + DZ];
+    static_assert(!GATES || (!W_LDS && !WGRAD), "the gate-reading variant keeps W^T in registers and leaves dz to the weight-gradient GEMM");
+    __shared__ __attribute__((aligned(16))) char smem[(W_LDS ? 2 * WPART : 0) + 5 * TILE + DZ + (GATES ? 4 * TILE : 0)];
     char* const Wx = smem;
     char* const Wh = smem + (W_LDS ? WPART : 0);
     char* const Ax = smem + (W_LDS ? 2 * WPART : 0);
@@ -240,6 +278,7 @@ lstm_scan_bwd_kernel(const T* __restrict__ x_all, const T* __restrict__ Hall, co
     char* const Sd = Ax + 3 * TILE;
     char* const Sx = Ax + 4 * TILE;
     char* const Adz = Ax + 5 * TILE;
+    char* const Sg = Adz + DZ;                             // saved gates of the step: four [TM][C] tiles (f, i, o, g)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, half = lane >> 5;
@@ -304,10 +343,40 @@ lstm_scan_bwd_kernel(const T* __restrict__ x_all, const T* __restrict__ Hall, co
         for (int j = 0; j < WG_CB; j++) tr_xh[j].init((j * 32) % C, TM, lane);
     }
 
+    frag_t<T> wtreg[GATES ? 2 : 1][GATES ? 4 * C / 16 : 1];
+    if (GATES) {
+#pragma unroll
+        for (int part = 0; part < 2; part++)
+#pragma unroll
+            for (int k16 = 0; k16 < 4 * C / 16; k16++)
+                wtreg[GATES ? part : 0][GATES ? k16 : 0] = frag_load<T>(Wt + (size_t)(part * C + ch) * 4 * C + 16 * k16 + half * 8);
+    }
+    // gates of step t, staged like the other tiles: rows [4C] of the saved tensor -> four [TM][C] tiles
+    auto load_gates = [&](frag_t<T> (&r)[4 * NFX], int t, int m0) {
+#pragma unroll
+        for (int q = 0; q < 4 * NFX; q++) {
+            const int f = tid + q * NT;
+            const int row = f / (4 * G);
+            const bool ok = f < TM * 4 * G && m0 + row < M;
+            r[q] = frag_load<T>(gates + (size_t)t * MC * 4 + (ok ? (size_t)(m0 + row) * 4 * C + (f % (4 * G)) * 8 : 0), ok);
+        }
+    };
+    auto store_gates = [&](const frag_t<T> (&r)[4 * NFX]) {
+#pragma unroll
+        for (int q = 0; q < 4 * NFX; q++) {
+            const int f = tid + q * NT;
+            if (f < TM * 4 * G) {
+                const int row = f / (4 * G), gg = (f / G) % 4, cg = f % G;
+                opm_store_frag<T>(Sg + gg * TILE, TM, row, cg, r[q]);
+            }
+        }
+    };
+
     const int n_tiles = (M + TM - 1) / TM;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int m0 = tile * TM;
         frag_t<T> rx[NFX], rh[NFX], rc[NFX], rd[NFX];
+        frag_t<T> rg[4 * NFX];                            // (only touched by the GATES variant)
         float dh_rec[16], dc_rec[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) {
@@ -317,32 +386,44 @@ lstm_scan_bwd_kernel(const T* __restrict__ x_all, const T* __restrict__ Hall, co
         }
         {
             const int t = Tn - 1;
-            tile_load_regs<T, C, NT, TM>(rx, x_all + (size_t)t * MC, m0, M, tid);
-            tile_load_regs<T, C, NT, TM>(rh, Hall + (size_t)t * MC, m0, M, tid);
+            if (!GATES) {
+                tile_load_regs<T, C, NT, TM>(rx, x_all + (size_t)t * MC, m0, M, tid);
+                tile_load_regs<T, C, NT, TM>(rh, Hall + (size_t)t * MC, m0, M, tid);
+            } else {
+                load_gates(rg, t, m0);
+            }
             load_cprev(rc, t, m0);
             tile_load_regs<T, C, NT, TM>(rd, dH != nullptr ? dH + (size_t)t * MC : nullptr, m0, M, tid);
         }
         lds_barrier();                                     // previous tile fully consumed
-        lds_tile_from_regs<T, C, NT, TM>(Ax, rx, tid);
-        lds_tile_from_regs<T, C, NT, TM>(Ah, rh, tid);
+        if (!GATES) {
+            lds_tile_from_regs<T, C, NT, TM>(Ax, rx, tid);
+            lds_tile_from_regs<T, C, NT, TM>(Ah, rh, tid);
+        } else {
+            store_gates(rg);
+        }
         lds_tile_from_regs<T, C, NT, TM>(Sc, rc, tid);
         lds_tile_from_regs<T, C, NT, TM>(Sd, rd, tid);
         for (int t = Tn - 1; t >= 0; t--) {
             lds_barrier();                                 // tiles of step t are in LDS
             if (t > 0) {
-                tile_load_regs<T, C, NT, TM>(rx, x_all + (size_t)(t - 1) * MC, m0, M, tid);
-                tile_load_regs<T, C, NT, TM>(rh, Hall + (size_t)(t - 1) * MC, m0, M, tid);
+                if (!GATES) {
+                    tile_load_regs<T, C, NT, TM>(rx, x_all + (size_t)(t - 1) * MC, m0, M, tid);
+                    tile_load_regs<T, C, NT, TM>(rh, Hall + (size_t)(t - 1) * MC, m0, M, tid);
+                } else {
+                    load_gates(rg, t - 1, m0);
+                }
                 load_cprev(rc, t - 1, m0);
                 tile_load_regs<T, C, NT, TM>(rd, dH != nullptr ? dH + (size_t)(t - 1) * MC : nullptr, m0, M, tid);
             }
             sched_fence();
-            // ---- recompute the pre-activations: z = [x_t | h_{t-1}] W^T ----
+            // ---- recompute the pre-activations: z = [x_t | h_{t-1}] W^T   (GATES: read the saved gates instead) ----
             f32x16 acc[4];
 #pragma unroll
             for (int g = 0; g < 4; g++) acc_zero(acc[g]);
             constexpr int KUNROLL = W_LDS ? C / 16 : 1;
 #pragma unroll
-            for (int part = 0; part < 2; part++) {
+            for (int part = 0; part < (GATES ? 0 : 2); part++) {
                 const char* const A = part ? Ah : Ax;
                 const char* const Wl = part ? Wh : Wx;
 #pragma clang loop unroll_count(KUNROLL)
@@ -361,10 +442,18 @@ lstm_scan_bwd_kernel(const T* __restrict__ x_all, const T* __restrict__ Hall, co
             // ---- gate backward (autograd of rnn.py:57-67) in registers; dz -> LDS as the next product's A operand ----
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const float f = sigmoid_zb(acc[0][r], nbf);
-                const float ig = sigmoid_zb(acc[1][r], nbi);
-                const float o = sigmoid_zb(acc[2][r], nbo);
-                const float g = tanh_zb(acc[3][r], tbg);
+                float f, ig, o, g;
+                if (GATES) {
+                    f = (float)*reinterpret_cast<const T*>(Sg + 0 * TILE + acc_elem_off(off0, r));
+                    ig = (float)*reinterpret_cast<const T*>(Sg + 1 * TILE + acc_elem_off(off0, r));
+                    o = (float)*reinterpret_cast<const T*>(Sg + 2 * TILE + acc_elem_off(off0, r));
+                    g = (float)*reinterpret_cast<const T*>(Sg + 3 * TILE + acc_elem_off(off0, r));
+                } else {
+                    f = sigmoid_zb(acc[0][r], nbf);
+                    ig = sigmoid_zb(acc[1][r], nbi);
+                    o = sigmoid_zb(acc[2][r], nbo);
+                    g = tanh_zb(acc[3][r], tbg);
+                }
                 const float cp = (float)*reinterpret_cast<const T*>(Sc + acc_elem_off(off0, r));
                 const float dh = (float)*reinterpret_cast<const T*>(Sd + acc_elem_off(off0, r)) + dh_rec[r];
                 const float tc = tanh_f(f * cp + ig * g);
@@ -382,14 +471,16 @@ lstm_scan_bwd_kernel(const T* __restrict__ x_all, const T* __restrict__ Hall, co
             // ---- [dx_t | dh_{t-1}] = dz W: this wave's 32 x-columns and its 32 h-columns ----
             f32x16 acc2[2];
             acc_zero(acc2[0]); acc_zero(acc2[1]);
-            constexpr int KUNROLL2 = W_LDS ? 4 : 1;
+            constexpr int KUNROLL2 = GATES ? 4 * C / 16 : (W_LDS ? 4 : 1);
 #pragma clang loop unroll_count(KUNROLL2)
             for (int kc = 0; kc < 4 * C; kc += 16) {
                 const frag_t<T> a = opm_load_frag<T>(Adz, TM, wm * 32 + li, kc / 8 + half);
 #pragma unroll
                 for (int part = 0; part < 2; part++) {
                     frag_t<T> b;
-                    if (W_LDS) {       // B[j][n] = W[n][j]: transposed fragments of the LDS image of W (rows n, columns j)
+                    if (GATES) {
+                        b = wtreg[GATES ? part : 0][GATES ? kc / 16 : 0];
+                    } else if (W_LDS) {       // B[j][n] = W[n][j]: transposed fragments of the LDS image of W (rows n, columns j)
                         const char* const Wl = part ? Wh : Wx;
                         if constexpr (sizeof(T) == 2) {
                             const int u = (kc >> 4) & 7;
@@ -441,8 +532,12 @@ lstm_scan_bwd_kernel(const T* __restrict__ x_all, const T* __restrict__ Hall, co
                 }
             }
             if (t > 0) {
-                lds_tile_from_regs<T, C, NT, TM>(Ax, rx, tid);
-                lds_tile_from_regs<T, C, NT, TM>(Ah, rh, tid);
+                if (!GATES) {
+                    lds_tile_from_regs<T, C, NT, TM>(Ax, rx, tid);
+                    lds_tile_from_regs<T, C, NT, TM>(Ah, rh, tid);
+                } else {
+                    store_gates(rg);
+                }
                 lds_tile_from_regs<T, C, NT, TM>(Sc, rc, tid);
                 lds_tile_from_regs<T, C, NT, TM>(Sd, rd, tid);
             }

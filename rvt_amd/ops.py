@@ -339,16 +339,21 @@ def lstm_scan_supported(dtype: torch.dtype, C: int) -> bool:
     return bool(L.get_lib().rvt_lstm_scan_supported(L.dtype_code(dtype), C))
 
 
+def lstm_scan_saves_gates(dtype: torch.dtype, C: int) -> bool:
+    """bf16 C = 128: the scan keeps its weights in the register file and saves the activated gates for the reverse scan."""
+    return dtype in L._DT and bool(L.get_lib().rvt_lstm_scan_saves_gates(L.dtype_code(dtype), C))
+
+
 def lstm_scan_fwd(x_all: Tensor, Hall: Tensor, c0: Optional[Tensor], c_last: Tensor, Csave: Optional[Tensor], w: Tensor,
-                  bias: Tensor) -> None:
-    """All T steps of the 1x1-conv ConvLSTM in one launch (time loop in the kernel).  x_all (T,...,C); Hall (T+1,...,C) with
-    slot 0 = incoming h; c0/c_last fp32 (...,C); Csave (T,...,C) or None; w [4C][2C] natural order, bias fp32 [4C]."""
+                  bias: Tensor, gates_out: Optional[Tensor] = None) -> None:
+    """All T steps of the 1x1-conv ConvLSTM in one launch.  x_all (T,M..,C); Hall (T+1,M..,C) with slot 0 = incoming h
+    (filled by the caller); c0 fp32 or None (zeros); c_last fp32 out; Csave (T,M..,C) copy of the cell states for BPTT or
+    None; w [4C][2C] natural gate order; gates_out (T,M..,4C) or None (only where lstm_scan_saves_gates)."""
     T_, C = x_all.shape[0], x_all.shape[-1]
     M = x_all[0].numel() // C
-    assert Hall.shape[0] == T_ + 1 and Hall.dtype == x_all.dtype and c_last.dtype == torch.float32
-    assert c0 is None or c0.dtype == torch.float32
+    assert c_last.dtype == torch.float32 and (c0 is None or c0.dtype == torch.float32)
     L.call('rvt_lstm_scan_fwd', L.ptr(x_all), L.ptr(Hall), L.ptr(c0), L.ptr(c_last), L.ptr(Csave), L.ptr(w), L.ptr(bias),
-           L.dtype_code(x_all.dtype), M, C, T_, L.stream_of(x_all))
+           L.ptr(gates_out), L.dtype_code(x_all.dtype), M, C, T_, L.stream_of(x_all))
 
 
 def lstm_scan_wgrad_supported(dtype: torch.dtype, C: int, M: int) -> bool:
@@ -358,9 +363,11 @@ def lstm_scan_wgrad_supported(dtype: torch.dtype, C: int, M: int) -> bool:
 
 def lstm_scan_bwd(x_all: Tensor, Hall: Tensor, Csave: Tensor, c0: Optional[Tensor], dH: Optional[Tensor],
                   dc_last: Optional[Tensor], w: Tensor, wt: Tensor, bias: Tensor, dx_all: Tensor, dz_all: Optional[Tensor],
-                  dh0: Tensor, dc0: Tensor, dw: Optional[Tensor] = None, db: Optional[Tensor] = None) -> None:
+                  dh0: Tensor, dc0: Tensor, dw: Optional[Tensor] = None, db: Optional[Tensor] = None,
+                  gates: Optional[Tensor] = None) -> None:
     """Reverse scan.  With dw / db (fp32 [4C][2C] / [4C], +=) the weight gradients are accumulated inside the kernel and
-    dz_all is not produced (pass None)."""
+    dz_all is not produced (pass None).  With `gates` (saved by lstm_scan_fwd where lstm_scan_saves_gates) the gates are read
+    instead of recomputed."""
     T_, C = x_all.shape[0], x_all.shape[-1]
     M = x_all[0].numel() // C
     assert dc0.dtype == torch.float32 and (dc_last is None or dc_last.dtype == torch.float32)
@@ -376,7 +383,7 @@ def lstm_scan_bwd(x_all: Tensor, Hall: Tensor, Csave: Tensor, c0: Optional[Tenso
             _WS[key] = ws
     L.call('rvt_lstm_scan_bwd', L.ptr(x_all), L.ptr(Hall), L.ptr(Csave), L.ptr(c0), L.ptr(dH), L.ptr(dc_last), L.ptr(w),
            L.ptr(wt), L.ptr(bias), L.ptr(dx_all), L.ptr(dz_all), L.ptr(dh0), L.ptr(dc0), L.ptr(dw), L.ptr(db), L.ptr(ws),
-           L.dtype_code(x_all.dtype), M, C, T_, st)
+           L.ptr(gates), L.dtype_code(x_all.dtype), M, C, T_, st)
 
 
 def dwconv(x: Tensor, w: Tensor, b: Optional[Tensor], k: int, transpose: bool = False, out: Optional[Tensor] = None) -> Tensor:

@@ -60,7 +60,7 @@ def use_lstm_scan(dtype, C: int, dws) -> bool:
     mode = os.environ.get('RVT_LSTM_SCAN', 'auto')
     if mode == '0' or dws is not None or not ops.lstm_scan_supported(dtype, C):
         return False
-    return True if mode == '1' else C <= 64
+    return True if mode == '1' else (C <= 64 or ops.lstm_scan_saves_gates(dtype, C))
 
 
 class SideStream:
@@ -196,9 +196,11 @@ def stage_seq_forward(sw: StageWeights, g: StageGeom, inp: Tensor, h0: Optional[
         # all T steps in ONE launch: h / c stay on chip, BPTT keeps only a T-typed copy of the cell states
         c_last = torch.empty((B, H, W, C), dtype=torch.float32, device=dev)
         Csave = torch.empty((T, B, H, W, C), dtype=dt, device=dev) if save else None
-        ops.lstm_scan_fwd(x.view(T, B, H, W, C), Hall, c0, c_last, Csave, sw.lstm_wn, sw.lstm_bn)
+        # C = 128 (bf16): weights in the register file; the gates are stored for a reverse scan that keeps W^T in registers
+        gsave = torch.empty((T, B, H, W, 4 * C), dtype=dt, device=dev) if save and ops.lstm_scan_saves_gates(dt, C) else None
+        ops.lstm_scan_fwd(x.view(T, B, H, W, C), Hall, c0, c_last, Csave, sw.lstm_wn, sw.lstm_bn, gates_out=gsave)
         if save:
-            sv.x_last, sv.Hall, sv.Call, sv.gates = x, Hall, None, None
+            sv.x_last, sv.Hall, sv.Call, sv.gates = x, Hall, None, gsave
             sv.xin_lstm, sv.hconv, sv.Csave, sv.c0 = x, None, Csave, c0
         return Hall, c_last, sv
     # cell states: all T+1 slots are kept for BPTT; a no-grad forward ping-pongs between two
@@ -259,14 +261,15 @@ def stage_seq_backward(sw: StageWeights, g: StageGeom, sv: StageSaved, dH: Optio
         # (bf16, C <= 64) the weight gradients are accumulated in the same kernel and dz never exists in HBM
         dh_rec = torch.empty((B, H, W, C), dtype=dt, device=dev)
         dc_rec = torch.empty((B, H, W, C), dtype=f32, device=dev)
-        lstm_wgrad_done = os.environ.get('RVT_LSTM_SCAN_WGRAD', '1') != '0' and ops.lstm_scan_wgrad_supported(dt, C, B * H * W)
+        lstm_wgrad_done = sv.gates is None and os.environ.get('RVT_LSTM_SCAN_WGRAD', '1') != '0' and \
+            ops.lstm_scan_wgrad_supported(dt, C, B * H * W)
         if not lstm_wgrad_done:
             dz = torch.empty((T, B, H, W, 4 * C), dtype=dt, device=dev)
         ops.lstm_scan_bwd(sv.xin_lstm.view(T, B, H, W, C), sv.Hall, sv.Csave, sv.c0, dH,
                           None if dc_last is None else dc_last.to(f32).contiguous(), sw.lstm_wn, sw.lstm_wt, sw.lstm_bn,
                           dx, dz, dh_rec, dc_rec,
                           dw=G(pre + 'lstm.conv1x1.weight').view(4 * C, 2 * C) if lstm_wgrad_done else None,
-                          db=G(pre + 'lstm.conv1x1.bias') if lstm_wgrad_done else None)
+                          db=G(pre + 'lstm.conv1x1.bias') if lstm_wgrad_done else None, gates=sv.gates)
     else:
         dz = torch.empty((T, B, H, W, 4 * C), dtype=dt, device=dev)
         if dH is None:

@@ -99,6 +99,25 @@ def test_lstm_scan_fwd_bwd(backend, dt, C, M, T, zero_state):
     assert rel(dzc.t() @ xh, wr.grad) <= tol * 2, ('dW', rel(dzc.t() @ xh, wr.grad))
     assert rel(dzc.sum(0), br.grad) <= tol * 2, ('db', rel(dzc.sum(0), br.grad))
 
+    # saved-gates route (bf16, C = 128: weights in the register file): the forward also stores the activated gates, the reverse
+    # scan reads them instead of recomputing (same numbers as the recompute route up to the bf16 rounding of the stored gates)
+    if ops.lstm_scan_saves_gates(dt, C):
+        gates = torch.empty(T, M, 4 * C, dtype=dt, device=dev)
+        Hall3 = torch.empty_like(Hall)
+        Hall3[0].copy_(h0)
+        c_last3, Csave3 = torch.empty_like(c_last), torch.empty_like(Csave)
+        ops.lstm_scan_fwd(x, Hall3, c0, c_last3, Csave3, w, b, gates_out=gates)
+        assert torch.equal(Hall3.cpu(), Hall.cpu()) and torch.equal(Csave3.cpu(), Csave.cpu())
+        dx3, dz3 = torch.empty_like(dx), torch.empty_like(dz)
+        dh03, dc03 = torch.empty_like(dh0), torch.empty_like(dc0)
+        ops.lstm_scan_bwd(x, Hall, Csave, c0, dH, dc_last, w, w.t().contiguous(), b, dx3, dz3, dh03, dc03, gates=gates)
+        assert rel(dx3, xr.grad) <= tol, ('gates dx', rel(dx3, xr.grad))
+        assert rel(dh03, h0r.grad) <= tol and rel(dc03, c0r.grad) <= tol
+        dzc3 = dz3.double().cpu().reshape(T * M, 4 * C)
+        assert rel(dzc3.t() @ xh, wr.grad) <= tol * 2, ('gates dW', rel(dzc3.t() @ xh, wr.grad))
+    else:
+        assert dt == torch.float32 or C != 128
+
     # in-kernel weight gradients (bf16, LDS-resident weights): same dx / dh0 / dc0, dW and db accumulated (+=) without a dz tensor
     if ops.lstm_scan_wgrad_supported(dt, C, M):
         dw = torch.ones(4 * C, 2 * C, dtype=torch.float32, device=dev)
