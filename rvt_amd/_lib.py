@@ -62,7 +62,8 @@ _SIGS = {
 }
 EXPORTS = sorted(list(_SIGS) + ['rvt_last_error', 'rvt_is_emulator', 'rvt_wgrad_workspace_floats',
                                'rvt_mlp_fused_supported', 'rvt_lstm_scan_supported', 'rvt_mlp_bwd_fused_supported',
-                               'rvt_mlp_bwd_fused_ws_floats', 'rvt_attn_block_supported', 'rvt_lstm_scan_bwd_ws_floats'])
+                               'rvt_mlp_bwd_fused_ws_floats', 'rvt_attn_block_supported', 'rvt_lstm_scan_bwd_ws_floats',
+                               'rvt_lstm_scan_saves_gates'])
 
 
 def _bind(lib: ctypes.CDLL) -> ctypes.CDLL:
