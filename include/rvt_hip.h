@@ -52,6 +52,19 @@ int rvt_conv_dgrad(const void* dy, const void* wd, const void* add, void* din, i
 int rvt_conv_wgrad(const void* in, const void* dy, float* dw, float* ws, int dtype, int F, int H, int W, int Cin,
                    int Cout, int k, int stride, int pad, void* stream);
 
+/* The stem on the loader's uint8 planes (replaces rvt_prepack_input + rvt_conv_fwd + rvt_layernorm_fwd, and
+ * rvt_conv_wgrad, for the first stage: maxvit.py:160-177 on the cast + padded input of modules/detection.py:133-134 and
+ * utils/padding.py:29-44).  src [F][Cin][h][w] uint8, zero padded to H x W on the fly; w = the packed conv weight of
+ * rvt_conv_fwd ([64][7*7*cp], tap-major, cin fastest, cp >= Cin); y0 = conv output, x = LayerNorm(y0), both
+ * [F][Ho][Wo][64].  rvt_stem_supported: bf16, uint8 planes, 7x7 / stride 4 / pad 3, Cout = 64, Cin <= 20, w % 4 == 0. */
+int rvt_stem_supported(int dtype, int src_u8, int Cin, int Cout, int k, int stride, int pad, int w);
+int rvt_stem_fwd(const void* src, const void* w, const float* ln_w, const float* ln_b, void* y0, void* x, int dtype, int F,
+                 int Cin, int cp, int h, int wd, int H, int W, float eps, void* stream);
+/* dw[64][7*7*cp] (float32, the layout of rvt_conv_wgrad) += dy^T im2col(src); ws: rvt_stem_wgrad_ws_floats floats. */
+size_t rvt_stem_wgrad_ws_floats(int Cin, int F, int H, int W);
+int rvt_stem_wgrad(const void* src, const void* dy, float* dw, float* ws, int dtype, int F, int Cin, int cp, int h, int wd,
+                   int H, int W, void* stream);
+
 /* LayerNorm over channels (maxvit.py:172,177,229,241). */
 int rvt_layernorm_fwd(const void* x, const float* w, const float* b, void* y, int dtype, int rows, int C,
                       float eps, void* stream);

@@ -28,6 +28,8 @@ _SIGS = {
     'rvt_conv_fwd': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     'rvt_conv_dgrad': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     'rvt_conv_wgrad': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    'rvt_stem_fwd': [_vp] * 6 + [_i] * 8 + [_f, _vp],
+    'rvt_stem_wgrad': [_vp] * 4 + [_i] * 8 + [_vp],
     'rvt_layernorm_fwd': [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
     'rvt_layernorm_bwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
     'rvt_linear_fwd': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
@@ -63,7 +65,7 @@ _SIGS = {
 EXPORTS = sorted(list(_SIGS) + ['rvt_last_error', 'rvt_is_emulator', 'rvt_wgrad_workspace_floats',
                                'rvt_mlp_fused_supported', 'rvt_lstm_scan_supported', 'rvt_mlp_bwd_fused_supported',
                                'rvt_mlp_bwd_fused_ws_floats', 'rvt_attn_block_supported', 'rvt_lstm_scan_bwd_ws_floats',
-                               'rvt_lstm_scan_saves_gates'])
+                               'rvt_lstm_scan_saves_gates', 'rvt_stem_supported', 'rvt_stem_wgrad_ws_floats'])
 
 
 def _bind(lib: ctypes.CDLL) -> ctypes.CDLL:
@@ -89,6 +91,10 @@ def _bind(lib: ctypes.CDLL) -> ctypes.CDLL:
     lib.rvt_attn_block_supported.argtypes = [_i, _i, _i, _i]
     lib.rvt_lstm_scan_supported.restype = ctypes.c_int
     lib.rvt_lstm_scan_supported.argtypes = [_i, _i]
+    lib.rvt_stem_supported.restype = ctypes.c_int
+    lib.rvt_stem_supported.argtypes = [_i] * 8
+    lib.rvt_stem_wgrad_ws_floats.restype = ctypes.c_size_t
+    lib.rvt_stem_wgrad_ws_floats.argtypes = [_i] * 4
     lib.rvt_wgrad_workspace_floats.restype = ctypes.c_size_t
     lib.rvt_wgrad_workspace_floats.argtypes = [_i, _i, _i, _i, _i]
     return lib

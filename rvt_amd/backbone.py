@@ -267,7 +267,11 @@ class _BackboneSeqFn(torch.autograd.Function):
         src = xs.reshape(T * B, Cin, h, w)
         if src.dtype not in (torch.uint8, torch.float32):
             src = src.float()
-        inp = ops.prepack_input(src, Hm, Wm, round8(Cin), dt)
+        g0 = geoms[0]
+        if ops.stem_supported(src, dt, g0.C, g0.k, g0.stride, g0.pad):
+            inp = src.contiguous()           # the stem kernels read the planes themselves (no channels-last copy)
+        else:
+            inp = ops.prepack_input(src, Hm, Wm, round8(Cin), dt)
         mw = mod.model_weights(params, geoms, dt, need_grad)
         svs, outs = [], []
         for si in range(ns):

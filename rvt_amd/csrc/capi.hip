@@ -16,6 +16,7 @@
 #include "events.hpp"
 #include "pack.hpp"
 #include "lstm_scan.hpp"
+#include "stem.hpp"
 #include "../../include/rvt_hip.h"
 
 namespace rvt {
@@ -200,6 +201,61 @@ int rvt_conv_wgrad(const void* in, const void* dy, float* dw, float* ws, int dty
         }
     });
     return check_launch("conv_wgrad");
+}
+
+// ---- the stem on the uint8 planes (stem.hpp) ----
+static const int STEM_FWD_PB = 4, STEM_FWD_D = 4;
+static int stem_wgrad_grid(int n_tiles) {            // one workgroup per CU; RVT_STEM_GRID: a smaller grid (tests: multi-tile walks)
+    static const int cap = getenv("RVT_STEM_GRID") ? atoi(getenv("RVT_STEM_GRID")) : 256;
+    return n_tiles < 1 ? 1 : (n_tiles < cap ? n_tiles : cap);
+}
+
+int rvt_stem_supported(int dtype, int src_u8, int Cin, int Cout, int k, int stride, int pad, int w) {
+    static const int on = getenv("RVT_STEM") ? atoi(getenv("RVT_STEM")) : 1;
+    return on && dtype == RVT_BF16 && src_u8 && Cout == STEM_CO && k == STEM_K && stride == STEM_STRIDE && pad == STEM_PAD &&
+           Cin >= 1 && Cin * STEM_K <= 2 * STEM_KSP_MAX && Cin * STEM_K <= STEM_WG_ROWS && (w % 4) == 0;
+}
+
+int rvt_stem_fwd(const void* src, const void* w, const float* ln_w, const float* ln_b, void* y0, void* x, int dtype, int F,
+                 int Cin, int cp, int h, int wd, int H, int W, float eps, void* stream) {
+    RVT_CHECK(rvt_stem_supported(dtype, 1, Cin, STEM_CO, STEM_K, STEM_STRIDE, STEM_PAD, wd), "stem_fwd: unsupported shape Cin=%d w=%d", Cin, wd);
+    RVT_CHECK(h <= H && wd <= W && cp >= Cin, "stem_fwd: planes %dx%d larger than the model resolution %dx%d", h, wd, H, W);
+    StemGeom g;
+    g.F = F; g.Cin = Cin; g.cp = cp; g.h = h; g.w = wd;
+    g.Ho = (H + 2 * STEM_PAD - STEM_K) / STEM_STRIDE + 1; g.Wo = (W + 2 * STEM_PAD - STEM_K) / STEM_STRIDE + 1;
+    g.NR = Cin * STEM_K; g.KS = (g.NR + 1) / 2; g.KSP = (g.KS + STEM_FWD_D - 1) / STEM_FWD_D * STEM_FWD_D;
+    g.XS = (g.Wo + 31) / 32; g.OG = (g.Ho + STEM_FWD_PB - 1) / STEM_FWD_PB;
+    g.n_items = F * g.OG * g.XS;
+    g.dXS = FastDiv(g.XS); g.dOG = FastDiv(g.OG); g.d7 = FastDiv(STEM_K);
+    const int grid = stem_wgrad_grid((g.n_items + 7) / 8);
+    hipLaunchKernelGGL((stem_fwd_kernel<STEM_FWD_PB, STEM_FWD_D>), dim3(grid), dim3(512), 0, (hipStream_t)stream, (const uint8_t*)src,
+                       (const bf16*)w, ln_w, ln_b, (bf16*)y0, (bf16*)x, g, eps);
+    return check_launch("stem_fwd");
+}
+
+size_t rvt_stem_wgrad_ws_floats(int Cin, int F, int H, int W) {
+    const int Ho = (H + 2 * STEM_PAD - STEM_K) / STEM_STRIDE + 1, Wo = (W + 2 * STEM_PAD - STEM_K) / STEM_STRIDE + 1;
+    const int NJB = (Cin * STEM_K + 3) / 4;
+    return (size_t)stem_wgrad_grid(F * Ho * ((Wo + 31) / 32)) * (size_t)(NJB * 32) * STEM_CO;
+}
+
+int rvt_stem_wgrad(const void* src, const void* dy, float* dw, float* ws, int dtype, int F, int Cin, int cp, int h, int wd,
+                   int H, int W, void* stream) {
+    RVT_CHECK(rvt_stem_supported(dtype, 1, Cin, STEM_CO, STEM_K, STEM_STRIDE, STEM_PAD, wd), "stem_wgrad: unsupported shape Cin=%d w=%d", Cin, wd);
+    RVT_CHECK(h <= H && wd <= W && cp >= Cin && ws != nullptr, "stem_wgrad: bad arguments");
+    StemWgGeom g;
+    g.F = F; g.Cin = Cin; g.h = h; g.w = wd;
+    g.Ho = (H + 2 * STEM_PAD - STEM_K) / STEM_STRIDE + 1; g.Wo = (W + 2 * STEM_PAD - STEM_K) / STEM_STRIDE + 1;
+    g.NR = Cin * STEM_K; g.NJB = (g.NR + 3) / 4;
+    g.XS = (g.Wo + 31) / 32; g.n_tiles = F * g.Ho * g.XS;
+    const int grid = stem_wgrad_grid(g.n_tiles);
+    g.per_wg = (g.n_tiles + grid - 1) / grid;
+    g.dXS = FastDiv(g.XS); g.dHo = FastDiv(g.Ho); g.d7 = FastDiv(STEM_K);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(grid), dim3(512), 0, st, (const uint8_t*)src, (const bf16*)dy, ws, g);
+    const int total = STEM_CO * STEM_K * STEM_K * Cin;
+    hipLaunchKernelGGL(stem_wgrad_fold_kernel, dim3((total + 255) / 256), dim3(256), 0, st, (const float*)ws, dw, grid, Cin, cp, g.NJB);
+    return check_launch("stem_wgrad");
 }
 
 int rvt_conv_dgrad(const void* dy, const void* wd, const void* add, void* din, int dtype, int F, int H, int W, int Cin,

@@ -235,6 +235,16 @@ __device__ __forceinline__ void lds_barrier() {
 #endif
 }
 
+// a value that is the same in every lane of the wave, moved to a scalar register (the compiler cannot know that e.g.
+// threadIdx.x >> 6 is wave-uniform): addresses built from it take the scalar-base + 32-bit lane-offset form
+__device__ __forceinline__ int wave_uniform(int v) {
+#ifdef RVT_EMU
+    return v;
+#else
+    return __builtin_amdgcn_readfirstlane(v);
+#endif
+}
+
 // keep the instruction scheduler from moving anything across this point (used to pin prefetch loads early)
 __device__ __forceinline__ void sched_fence() {
 #ifndef RVT_EMU

@@ -60,6 +60,42 @@ def conv_fwd(x: Tensor, w: Tensor, k: int, stride: int, pad: int, out: Optional[
     return y
 
 
+def stem_supported(src: Tensor, dtype: torch.dtype, Cout: int, k: int, stride: int, pad: int) -> bool:
+    """The stem kernels (csrc/stem.hpp) take the loader's uint8 planes; everything else goes prepack + conv + LayerNorm."""
+    return bool(L.get_lib().rvt_stem_supported(L.dtype_code(dtype), int(src.dtype == torch.uint8), src.shape[1], Cout, k, stride,
+                                               pad, src.shape[3]))
+
+
+def stem_fwd(src: Tensor, w: Tensor, ln_w: Tensor, ln_b: Tensor, H: int, W: int, eps: float):
+    """src (F,Cin,h,w) uint8, w = packed conv weight (64, 49*cp) -> y0 = conv(pad(src)), x = LayerNorm(y0), (F,Ho,Wo,64)."""
+    assert src.dim() == 4 and src.dtype == torch.uint8 and src.is_contiguous()
+    F_, Cin, h, wd = src.shape
+    cp = w.shape[1] // 49
+    assert w.shape[0] == 64 and w.shape[1] == 49 * cp and cp >= Cin
+    Ho, Wo = conv_out_hw(H, W, 7, 4, 3)
+    y0 = torch.empty((F_, Ho, Wo, 64), dtype=w.dtype, device=src.device)
+    x = torch.empty_like(y0)
+    L.call('rvt_stem_fwd', L.ptr(src), L.ptr(w), L.ptr(ln_w), L.ptr(ln_b), L.ptr(y0), L.ptr(x), L.dtype_code(w.dtype), F_, Cin, cp,
+           h, wd, H, W, float(eps), L.stream_of(y0))
+    return y0, x
+
+
+def stem_wgrad(src: Tensor, dy: Tensor, dw: Tensor, H: int, W: int) -> None:
+    """dw (64, 49*cp) fp32 += dy^T im2col(pad(src)) — the layout conv_wgrad writes."""
+    assert src.dtype == torch.uint8 and src.is_contiguous() and dy.is_contiguous() and dw.dtype == torch.float32
+    F_, Cin, h, wd = src.shape
+    cp = dw.shape[1] // 49
+    assert tuple(dw.shape) == (64, 49 * cp) and tuple(dy.shape[:1]) == (F_,) and dy.shape[-1] == 64
+    n = L.get_lib().rvt_stem_wgrad_ws_floats(Cin, F_, H, W)
+    st = L.stream_of(dy)
+    key = ('stem', dy.device.type, dy.device.index, 0 if st is None else int(st))
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < n:
+        ws = torch.empty(n, dtype=torch.float32, device=dy.device)
+        _WS[key] = ws
+    L.call('rvt_stem_wgrad', L.ptr(src), L.ptr(dy), L.ptr(dw), L.ptr(ws), L.dtype_code(dy.dtype), F_, Cin, cp, h, wd, H, W, st)
+
+
 def conv_dgrad(dy: Tensor, wd: Tensor, add: Optional[Tensor], H: int, W: int, Cin: int, k: int, stride: int, pad: int,
                out: Optional[Tensor] = None) -> Tensor:
     F_, Ho, Wo, Cout = dy.shape

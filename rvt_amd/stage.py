@@ -137,14 +137,18 @@ class StageSaved:
 def stage_seq_forward(sw: StageWeights, g: StageGeom, inp: Tensor, h0: Optional[Tensor], c0: Optional[Tensor],
                       T: int, B: int, save: bool, token_mask: Optional[Tensor] = None,
                       mask_token: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Optional[StageSaved]]:
-    """inp: (T*B, H_in, W_in, cin_pad).  Returns Hall (T+1,B,H,W,C), the final cell state (B,H,W,C) fp32, saved."""
+    """inp: (T*B, H_in, W_in, cin_pad), or the uint8 planes (T*B, Cin, h, w) where ops.stem_supported.  Returns Hall (T+1,B,H,W,C), the final cell state (B,H,W,C) fp32, saved."""
     F_ = T * B
     H, W, C = g.H, g.W, g.C
-    dt, dev = inp.dtype, inp.device
+    dt, dev = sw.conv_w.dtype, inp.device
     sv = StageSaved() if save else None
 
-    y0 = ops.conv_fwd(inp, sw.conv_w, g.k, g.stride, g.pad)                      # maxvit.py:175
-    x = ops.layernorm_fwd(y0, sw.ln_w, sw.ln_b, g.eps)                            # maxvit.py:177
+    if inp.dtype == torch.uint8:
+        # first stage on the loader's planes (T*B, Cin, h, w): cast + pad + conv + LayerNorm in one launch (csrc/stem.hpp)
+        y0, x = ops.stem_fwd(inp, sw.conv_w, sw.ln_w, sw.ln_b, g.H_in, g.W_in, g.eps)
+    else:
+        y0 = ops.conv_fwd(inp, sw.conv_w, g.k, g.stride, g.pad)                  # maxvit.py:175
+        x = ops.layernorm_fwd(y0, sw.ln_w, sw.ln_b, g.eps)                        # maxvit.py:177
     mask_u8 = None
     if token_mask is not None:                                                    # maxvit_rnn.py:174-176
         mask_u8 = token_mask.reshape(F_ * H * W).to(torch.uint8).contiguous()
@@ -398,7 +402,10 @@ def stage_seq_backward(sw: StageWeights, g: StageGeom, sv: StageSaved, dH: Optio
     dy0 = ops.layernorm_bwd(sv.y0, sw.ln_w, dx, None, G(pre + 'downsample_cf2cl.norm.weight'),
                             G(pre + 'downsample_cf2cl.norm.bias'), g.eps)
     def conv_wgrad_fn():
-        ops.conv_wgrad(sv.inp, dy0, G('raw/conv'), g.k, g.stride, g.pad)
+        if sv.inp.dtype == torch.uint8:
+            ops.stem_wgrad(sv.inp, dy0, G('raw/conv'), g.H_in, g.W_in)
+        else:
+            ops.conv_wgrad(sv.inp, dy0, G('raw/conv'), g.k, g.stride, g.pad)
         if finalize is not None:
             finalize()           # in stream order behind every weight-gradient GEMM of this stage
     side.run(conv_wgrad_fn, sv.inp, dy0)

@@ -12,6 +12,9 @@ os.environ.setdefault('RVT_GEMM_RESIDENT', '8')     # (a multiple of 8: also rea
 os.environ.setdefault('RVT_WGRAD_SLICE_TOKENS', '128')
 # ConvLSTM scan kernels for every width they are built for (production default: only where the weights fit the LDS)
 os.environ.setdefault('RVT_LSTM_SCAN', '1')
+# stem kernels (one workgroup per CU in production): a 3-workgroup grid, so that test sizes walk several items / tiles per
+# workgroup (the double-buffered LDS image of the weight gradient, the persistent item loop of the forward)
+os.environ.setdefault('RVT_STEM_GRID', '3')
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

@@ -381,6 +381,54 @@ def test_conv(backend, dt, case):
         close(din, xr.grad.permute(0, 2, 3, 1) + f64(add), dt, 'conv_dgrad')
 
 
+STEM_CASES = [  # F, Cin, h, w, H, W  (uint8 planes h x w, zero padded to the model resolution H x W)
+    (1, 20, 24, 40, 24, 40),          # one partial 32-pixel segment, row groups past Ho
+    (2, 20, 30, 136, 32, 136),        # two segments (second partial), bottom padding rows (h < H)
+    (1, 20, 16, 260, 16, 264),        # three segments, columns past the real width (w < W)
+    (1, 3, 40, 132, 40, 132),         # few planes: odd number of contraction rows (21), 11 k-steps padded to 12
+    (1, 20, 48, 136, 48, 136),        # has an interior item (second segment, rows 13..31): the unchecked load path
+]
+
+
+@pytest.mark.parametrize('case', STEM_CASES)
+def test_stem(backend, case):
+    """The stem kernels on the uint8 planes (csrc/stem.hpp) against fp64 conv2d + layer_norm of the cast + padded input
+    (reference maxvit.py:160-177 on modules/detection.py:133-134, utils/padding.py:29-44) and against the prepack + GEMM route."""
+    dt = torch.bfloat16
+    Fr, Cin, h, w, H, W = case
+    g = torch.Generator().manual_seed(5)
+    src = torch.randint(0, 256, (Fr, Cin, h, w), generator=g, dtype=torch.uint8)
+    src[:, :, ::3, ::5] = 0
+    cp = weights.round8(Cin)
+    wt = rnd((64, Cin, 7, 7), backend, torch.float32, 2, 0.02).to(dt)
+    wp = weights.pack_conv_fwd(wt.float(), cp, dt)
+    lw, lb = (1 + rnd((64,), backend, torch.float32, 3, 0.2)), rnd((64,), backend, torch.float32, 4, 0.2)
+    srcd = src.to(backend)
+    assert ops.stem_supported(srcd, dt, 64, 7, 4, 3)
+    assert not ops.stem_supported(srcd.float(), dt, 64, 7, 4, 3) and not ops.stem_supported(srcd, torch.float32, 64, 7, 4, 3)
+    y0, x = ops.stem_fwd(srcd, wp, lw, lb, H, W, 1e-5)
+    xin = torch.zeros(Fr, Cin, H, W, dtype=torch.float64)
+    xin[:, :, :h, :w] = src.double()
+    wr = f64(wt).requires_grad_(True)
+    yr = F.conv2d(xin, wr, None, 4, 3)
+    close(y0, yr.permute(0, 2, 3, 1), dt, 'stem y0')
+    # LayerNorm of the STORED (bf16) conv output: what the backward differentiates
+    xr = F.layer_norm(f64(y0), (64,), f64(lw), f64(lb), 1e-5)
+    close(x, xr, dt, 'stem LN(y0)')
+    # same products as the GEMM route on the prepacked copy (uint8 is exact in bf16): only the summation order differs
+    inp = ops.prepack_input(srcd, H, W, cp, dt)
+    y_ref = ops.conv_fwd(inp, wp, 7, 4, 3)
+    close(y0, f64(y_ref), dt, 'stem vs conv_fwd', mult=0.5)
+    dy = rnd(tuple(y0.shape), backend, dt, 6)
+    yr.backward(f64(dy).permute(0, 3, 1, 2))
+    dw = torch.full((64, 49 * cp), 0.5, device=backend)           # += semantics (gradient buckets accumulate)
+    ops.stem_wgrad(srcd, dy, dw, H, W)
+    got = weights.unpack_conv_wgrad(dw - 0.5, Cin, 7)
+    close(got, wr.grad, dt, 'stem wgrad')
+    pad_cols = (dw - 0.5).view(64, 49, cp)[:, :, Cin:]
+    assert float(pad_cols.abs().max()) == 0.0 if cp > Cin else True
+
+
 @pytest.mark.parametrize('dt', DTYPES)
 @pytest.mark.parametrize('N,H,W,C', [(2, 5, 7, 16), (1, 6, 4, 48), (3, 3, 3, 8)])
 def test_dwconv(backend, dt, N, H, W, C):
