@@ -87,6 +87,19 @@ elif op in ('conv_fwd_stem', 'conv_wgrad_stem'):      # stem: 7x7 stride-4 conv,
         dy = rnd(F_, Hi // st, Wi // st, Co)
         dw = torch.zeros(Co, k * k * Cp, device=dev)
         fn = lambda: ops.conv_wgrad(inp, dy, dw, k, st, pd)
+elif op in ('stem_fwd', 'stem_wgrad'):                # the same stem on the uint8 planes (csrc/stem.hpp)
+    del x, dy4
+    from rvt_amd import weights
+    F_, Cin, h, w_, H, W = 504, 20, 360, 640, 384, 640
+    src = torch.randint(0, 11, (F_, Cin, h, w_), dtype=torch.uint8, device=dev)
+    wp = weights.pack_conv_fwd(torch.randn(64, Cin, 7, 7, device=dev) * 0.05, 24, dt)
+    lw, lb = torch.ones(64, device=dev), torch.zeros(64, device=dev)
+    if op == 'stem_fwd':
+        fn = lambda: ops.stem_fwd(src, wp, lw, lb, H, W, 1e-5)
+    else:
+        dy = rnd(F_, 96, 160, 64)
+        dw = torch.zeros(64, 49 * 24, device=dev)
+        fn = lambda: ops.stem_wgrad(src, dy, dw, H, W)
 for _ in range(3):
     fn()
 torch.cuda.synchronize()

@@ -204,7 +204,11 @@ int rvt_conv_wgrad(const void* in, const void* dy, float* dw, float* ws, int dty
 }
 
 // ---- the stem on the uint8 planes (stem.hpp) ----
-static const int STEM_FWD_PB = 4, STEM_FWD_D = 4;
+static const int STEM_FWD_PB = 4;
+static int stem_fwd_depth() {                          // software-pipeline depth of the forward's plane loads (k-steps in flight)
+    static const int d = getenv("RVT_STEM_D") ? atoi(getenv("RVT_STEM_D")) : 4;
+    return d == 5 ? 5 : 4;
+}
 static int stem_wgrad_grid(int n_tiles) {            // one workgroup per CU; RVT_STEM_GRID: a smaller grid (tests: multi-tile walks)
     static const int cap = getenv("RVT_STEM_GRID") ? atoi(getenv("RVT_STEM_GRID")) : 256;
     return n_tiles < 1 ? 1 : (n_tiles < cap ? n_tiles : cap);
@@ -223,13 +227,20 @@ int rvt_stem_fwd(const void* src, const void* w, const float* ln_w, const float*
     StemGeom g;
     g.F = F; g.Cin = Cin; g.cp = cp; g.h = h; g.w = wd;
     g.Ho = (H + 2 * STEM_PAD - STEM_K) / STEM_STRIDE + 1; g.Wo = (W + 2 * STEM_PAD - STEM_K) / STEM_STRIDE + 1;
-    g.NR = Cin * STEM_K; g.KS = (g.NR + 1) / 2; g.KSP = (g.KS + STEM_FWD_D - 1) / STEM_FWD_D * STEM_FWD_D;
+    const int D = stem_fwd_depth();
+    g.NR = Cin * STEM_K; g.KS = (g.NR + 1) / 2; g.KSP = (g.KS + D - 1) / D * D;
+    RVT_CHECK(g.KSP <= STEM_KSP_MAX, "stem_fwd: %d k-steps do not fit the LDS", g.KSP);
     g.XS = (g.Wo + 31) / 32; g.OG = (g.Ho + STEM_FWD_PB - 1) / STEM_FWD_PB;
-    g.n_items = F * g.OG * g.XS;
-    g.dXS = FastDiv(g.XS); g.dOG = FastDiv(g.OG); g.d7 = FastDiv(STEM_K);
-    const int grid = stem_wgrad_grid((g.n_items + 7) / 8);
-    hipLaunchKernelGGL((stem_fwd_kernel<STEM_FWD_PB, STEM_FWD_D>), dim3(grid), dim3(512), 0, (hipStream_t)stream, (const uint8_t*)src,
-                       (const bf16*)w, ln_w, ln_b, (bf16*)y0, (bf16*)x, g, eps);
+    const int og8 = (g.OG + 7) / 8;
+    g.n_items = F * og8;
+    g.dOG = FastDiv(og8); g.d7 = FastDiv(STEM_K);
+    const int grid = stem_wgrad_grid(g.n_items);
+    if (D == 5)
+        hipLaunchKernelGGL((stem_fwd_kernel<STEM_FWD_PB, 5>), dim3(grid), dim3(512), 0, (hipStream_t)stream, (const uint8_t*)src,
+                           (const bf16*)w, ln_w, ln_b, (bf16*)y0, (bf16*)x, g, eps);
+    else
+        hipLaunchKernelGGL((stem_fwd_kernel<STEM_FWD_PB, 4>), dim3(grid), dim3(512), 0, (hipStream_t)stream, (const uint8_t*)src,
+                           (const bf16*)w, ln_w, ln_b, (bf16*)y0, (bf16*)x, g, eps);
     return check_launch("stem_fwd");
 }
 

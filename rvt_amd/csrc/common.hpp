@@ -245,6 +245,16 @@ __device__ __forceinline__ int wave_uniform(int v) {
 #endif
 }
 
+// wait for every outstanding global access of this wave (loads AND stores).  Besides the obvious use: stores and loads
+// retire out of order with respect to each other, so while stores are pending the compiler can only wait with vmcnt(0) —
+// a software-pipelined load loop entered with stores in flight (the previous item's epilogue) gets a full drain at its loop
+// header in EVERY iteration.  Draining once in front of the loop restores the counted waits inside it.
+__device__ __forceinline__ void drain_vmem() {
+#ifndef RVT_EMU
+    __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0), expcnt / lgkmcnt untouched
+#endif
+}
+
 // keep the instruction scheduler from moving anything across this point (used to pin prefetch loads early)
 __device__ __forceinline__ void sched_fence() {
 #ifndef RVT_EMU

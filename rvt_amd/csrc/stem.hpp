@@ -33,8 +33,8 @@ struct StemGeom {
     int F, Cin, cp, h, w, Ho, Wo;          // planes [F][Cin][h][w]; output [F][Ho][Wo][64]; cp = padded Cin of the weights
     int NR, KS, KSP;                       // contraction rows (c, ky), k-steps of two rows, k-steps padded to the pipeline depth
     int XS, OG;                            // 32-pixel segments per output row, groups of PB output rows
-    int n_items;
-    FastDiv dXS, dOG, d7;
+    int n_items;                           // workgroup items: (frame, eight consecutive row groups)
+    FastDiv dOG, d7;                       // dOG: by the number of eight-row-group sets per frame
 };
 
 constexpr int STEM_K = 7, STEM_STRIDE = 4, STEM_PAD = 3, STEM_CO = 64;
@@ -69,8 +69,10 @@ __device__ __forceinline__ void stem_fwd_item(f32x16 (&acc)[2][PB], const uint8_
     const int hw = g.h * g.w, coff_max = (g.Cin - 1) * hw;
     int coff = 0, ky = half, kyw = half * g.w;                      // row r = 2 ks + half -> (c, ky); coff = c h w, kyw = ky w
     uint32_t raw[D][PB][2];
-    auto load_step = [&](uint32_t (&dst)[PB][2]) {
+    uint32_t msk[D];                                               // border items: bit j = window row of block j exists
+    auto load_step = [&](uint32_t (&dst)[PB][2], uint32_t& m) {
         const int cc = coff < coff_max ? coff : coff_max;           // rows past the last plane: zero weights, any finite data
+        m = 0;
 #pragma unroll
         for (int j = 0; j < PB; j++) {
             const int iy0 = 4 * (oy0 + j) - STEM_PAD;               // uniform
@@ -79,12 +81,13 @@ __device__ __forceinline__ void stem_fwd_item(f32x16 (&acc)[2][PB], const uint8_
                 dst[j][0] = v.a;
                 dst[j][1] = v.b;
             } else {
+                // unconditional loads from clamped addresses; the zeros are selected when the fragment is built (a load that
+                // is only conditionally needed becomes a branch with a wait inside — no pipelining left)
                 const bool rowok = (unsigned)(iy0 + ky) < (unsigned)g.h;
                 const uint32_t ro = (uint32_t)(cc + (rowok ? iy0 * g.w + kyw : 0));
-                const uint32_t d0 = *reinterpret_cast<const uint32_t*>(plane0 + (ro + (uint32_t)xo0));
-                const uint32_t d1 = *reinterpret_cast<const uint32_t*>(plane0 + (ro + (uint32_t)xo1));
-                dst[j][0] = (rowok && x0ok) ? d0 : 0u;
-                dst[j][1] = (rowok && x1ok) ? d1 : 0u;
+                dst[j][0] = *reinterpret_cast<const uint32_t*>(plane0 + (ro + (uint32_t)xo0));
+                dst[j][1] = *reinterpret_cast<const uint32_t*>(plane0 + (ro + (uint32_t)xo1));
+                m |= rowok ? (1u << j) : 0u;
             }
         }
         ky += 2;
@@ -94,22 +97,45 @@ __device__ __forceinline__ void stem_fwd_item(f32x16 (&acc)[2][PB], const uint8_
         kyw -= wrap ? STEM_K * g.w : 0;
         coff += wrap ? hw : 0;
     };
+    drain_vmem();                                                   // (the previous item's stores: see common.hpp)
 #pragma unroll
-    for (int d = 0; d < D; d++) load_step(raw[d]);
+    for (int d = 0; d < D; d++) { load_step(raw[d], msk[d]); sched_fence(); }       // in THIS order: the loop waits for the oldest first
+    // weight fragments one k-step ahead as well: read right in front of the MFMAs that need them, every k-step would start
+    // with an LDS round trip
+    bf16x8 b0 = *reinterpret_cast<const bf16x8*>(wl), b1 = *reinterpret_cast<const bf16x8*>(wl + 1024);
     for (int ks0 = 0; ks0 < g.KSP; ks0 += D) {
 #pragma unroll
         for (int d = 0; d < D; d++) {
             bf16x8 a[PB];
 #pragma unroll
-            for (int j = 0; j < PB; j++) a[j] = stem_frag_u8(raw[d][j][0], raw[d][j][1]);
-            load_step(raw[d]);                                      // rows of k-step ks0 + d + D
-            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(wl + (size_t)(ks0 + d) * 2048);
-            const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(wl + (size_t)(ks0 + d) * 2048 + 1024);
+            for (int j = 0; j < PB; j++) {
+                uint32_t d0 = raw[d][j][0], d1 = raw[d][j][1];
+                if (!INTERIOR) {
+                    const bool rowok = (msk[d] >> j) & 1u;
+                    d0 = (rowok && x0ok) ? d0 : 0u;
+                    d1 = (rowok && x1ok) ? d1 : 0u;
+                }
+#if STEM_EXP == 1
+                { typedef __attribute__((ext_vector_type(4))) uint32_t u4_; u4_ q_ = {d0, d1, d0, d1}; a[j] = __builtin_bit_cast(bf16x8, q_); }
+#else
+                a[j] = stem_frag_u8(d0, d1);
+#endif
+            }
+            // the fences pin the software pipeline: left alone, the scheduler sinks the loads next to their uses (one k-step
+            // of latency cover instead of D) and drains the queue at every loop back-edge
+            sched_fence();
+            load_step(raw[d], msk[d]);                              // rows of k-step ks0 + d + D
+            const int kn = ks0 + d + 1 < g.KSP ? ks0 + d + 1 : 0;
+            const bf16x8 n0 = *reinterpret_cast<const bf16x8*>(wl + (size_t)kn * 2048);
+            const bf16x8 n1 = *reinterpret_cast<const bf16x8*>(wl + (size_t)kn * 2048 + 1024);
+            sched_fence();
 #pragma unroll
             for (int j = 0; j < PB; j++) {
                 mma32(acc[0][j], b0, a[j]);                         // rows = channels, column = this lane's pixel
                 mma32(acc[1][j], b1, a[j]);
             }
+            b0 = n0;
+            b1 = n1;
         }
     }
 }
@@ -142,11 +168,18 @@ stem_fwd_kernel(const uint8_t* __restrict__ src, const bf16* __restrict__ wp, co
     __syncthreads();
 
     const size_t hw = (size_t)g.h * g.w;
-    for (int item = wave_uniform(blockIdx.x * 8 + wave); item < g.n_items; item += gridDim.x * 8) {
-        uint32_t fo, xs, f, og;
-        g.dXS.divmod((uint32_t)item, fo, xs);
-        g.dOG.divmod(fo, f, og);
-        const int oy0 = PB * (int)og, ox = 32 * (int)xs + li;
+    // Work split: a workgroup item = eight consecutive row groups of one frame, one per wave; the wave walks its row group
+    // segment by segment.  The window of a segment reaches one dword into the cache line of the segment to its left, and
+    // three plane rows into the row group above: both are lines this wave / the neighbouring wave has just pulled in.
+    // (Items of (row group, segment) dealt round-robin fetched 4.4 GB for 2.3 GB of planes.)
+    const int wv = wave_uniform(wave);
+    for (int item = blockIdx.x; item < g.n_items; item += gridDim.x)
+    for (int xs = 0; xs < g.XS; xs++) {
+        uint32_t f, og8;
+        g.dOG.divmod((uint32_t)item, f, og8);
+        const int og = 8 * (int)og8 + wv;
+        if (og >= g.OG) continue;
+        const int oy0 = PB * og, ox = 32 * xs + li;
         const bool colok = ox < g.Wo;
         // per-lane source columns: d0 = bytes x 4ox-4 .. 4ox-1 (the zero padding at ox = 0), d1 = bytes x 4ox .. 4ox+3 (zeros past
         // the real width w).  A lane whose pixel does not exist only needs SAFE addresses: it is a column nobody stores.
@@ -166,6 +199,11 @@ stem_fwd_kernel(const uint8_t* __restrict__ src, const bf16* __restrict__ wp, co
         const char* wl = Wl + (size_t)(li * 2 + half) * 16;
         if (interior) stem_fwd_item<PB, D, true>(acc, plane0, wl, g, oy0, half, xo0, xo1, x0ok, x1ok);
         else stem_fwd_item<PB, D, false>(acc, plane0, wl, g, oy0, half, xo0, xo1, x0ok, x1ok);
+#if STEM_EXP == 2
+        { float t_ = 0.f;
+          for (int nb = 0; nb < 2; nb++) for (int j = 0; j < PB; j++) for (int r = 0; r < 16; r++) t_ += acc[nb][j][r];
+          if (colok) y0[(((size_t)f * g.Ho + oy0) * g.Wo + ox) * STEM_CO] = (bf16)t_; }
+#else
         // epilogue: y0 (bf16, what the LayerNorm backward reads) and LN(y0) as 16-byte row pieces
 #pragma unroll
         for (int j = 0; j < PB; j++) {
@@ -210,6 +248,7 @@ stem_fwd_kernel(const uint8_t* __restrict__ src, const bf16* __restrict__ wp, co
                     }
             }
         }
+#endif
     }
 }
 
@@ -218,8 +257,8 @@ constexpr int STEM_WG_ROWB = 304;          // bytes per LDS image row: 136 bf16 
 constexpr int STEM_WG_ROWS = 144;          // image rows (c, ky)  (Cin <= 20)
 constexpr int STEM_WG_DYB = 144;           // bytes per dy tile row (64 bf16 + pad)
 constexpr int STEM_WG_JW = 5;              // row-blocks (4 rows x 8 slots) per wave: 8 x 5 >= 35
-constexpr int STEM_WG_DPR = 34;            // dwords (4 source bytes each) per image row: x' = 0 .. 135
-constexpr int STEM_WG_RPR = 15;            // image rows per staging round: 15 x 34 = 510 of the 512 threads
+constexpr int STEM_WG_DPR = 33;            // dwords (4 source bytes each) per image row: x' = 0 .. 131 (the last one read)
+constexpr int STEM_WG_RPR = 15;            // image rows per staging round: 15 x 33 = 495 of the 512 threads
 constexpr int STEM_WG_ROUNDS = 10;
 
 struct StemWgGeom {
@@ -234,15 +273,30 @@ __global__ void __launch_bounds__(512)
 stem_wgrad_kernel(const uint8_t* __restrict__ src, const bf16* __restrict__ dy, float* __restrict__ ws, StemWgGeom g) {
     typedef bf16 T;
     constexpr int IMG = STEM_WG_ROWS * STEM_WG_ROWB, DYT = 32 * STEM_WG_DYB;
-    __shared__ __attribute__((aligned(16))) char smem[2 * IMG + 2 * DYT];
+    __shared__ __attribute__((aligned(16))) char smem[2 * IMG + 2 * DYT + STEM_WG_ROUNDS * 512 * 4];
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, half = lane >> 5, wave = tid >> 6;
-    const size_t hw = (size_t)g.h * g.w;
+    const int hw = g.h * g.w;
+    uint32_t* const voff = reinterpret_cast<uint32_t*>(smem + 2 * IMG + 2 * DYT) + tid;       // [k][thread]: see below
 
-    // staging role of this thread: dword column dq of image rows row0 + 15 k
+    // Staging role of this thread: dword column dq of the image rows row0 + 15 k, k = 0..9.  What does not depend on the tile
+    // is computed once: the source offset of each of the ten dwords relative to the tile's window origin (kept in an LDS
+    // table this thread alone reads: ten registers less), the tap row ky of each (3 bits), and which of them exist at all.
     const int row0 = tid / STEM_WG_DPR, dq = tid - row0 * STEM_WG_DPR;
-    const bool stager = row0 < STEM_WG_RPR;
-    uint32_t c0, ky0;
-    g.d7.divmod((uint32_t)row0, c0, ky0);
+    uint32_t kys = 0, rmask = 0;
+    {
+        uint32_t c, ky;
+        g.d7.divmod((uint32_t)row0, c, ky);
+#pragma unroll
+        for (int k = 0; k < STEM_WG_ROUNDS; k++) {
+            const bool ok = row0 < STEM_WG_RPR && row0 + STEM_WG_RPR * k < g.NR;
+            voff[512 * k] = ok ? (uint32_t)((int)c * hw + (int)ky * g.w + 4 * dq) : 0u;
+            kys |= ky << (3 * k);
+            rmask |= ok ? (1u << k) : 0u;
+            c += 2;                                                // + 15 rows = + 2 planes + 1 tap row
+            ky += 1;
+            if (ky >= STEM_K) { ky -= STEM_K; c += 1; }
+        }
+    }
     // dy tile: 32 rows x 128 B = 512 pieces of 8 bytes
     const int dyr = tid >> 4, dyc = tid & 15;
 
@@ -257,64 +311,62 @@ stem_wgrad_kernel(const uint8_t* __restrict__ src, const bf16* __restrict__ dy, 
     for (int i = 0; i < STEM_WG_JW; i++) { acc_zero(acc[i][0]); acc_zero(acc[i][1]); }
 
     const int t_begin = blockIdx.x * g.per_wg, t_end = (t_begin + g.per_wg < g.n_tiles) ? t_begin + g.per_wg : g.n_tiles;
-    uint32_t raw[STEM_WG_ROUNDS];
+    // Two tiles of source dwords in flight per thread (register sets A, B): a tile is requested two iterations before it is
+    // converted into the LDS image.
     typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
-    u32x2 dyraw;
-    auto fetch = [&](int tile) {                 // global -> registers
+    struct Stage { uint32_t raw[STEM_WG_ROUNDS]; u32x2 dyraw; uint32_t ok; };
+    auto fetch = [&](Stage& st, int tile) {      // global -> registers
+        if (tile >= t_end) return;
         uint32_t fo, xs, f, oy;
         g.dXS.divmod((uint32_t)tile, fo, xs);
         g.dHo.divmod(fo, f, oy);
-        const int x = 128 * (int)xs - 4 + 4 * dq;                  // first source byte of this thread's dword
-        const bool xok = x >= 0 && x < g.w;
-        const uint8_t* const base = src + (size_t)f * g.Cin * hw + (xok ? x : 0);
-        int coff = (int)c0 * (int)hw, ky = (int)ky0, row = row0;
+        const int x0 = 128 * (int)xs - 4, iy0 = 4 * (int)oy - STEM_PAD;        // window origin (uniform)
+        const uint8_t* const org = src + ((size_t)f * g.Cin * hw + (ptrdiff_t)iy0 * g.w + x0);
+        if (x0 >= 0 && x0 + 4 * STEM_WG_DPR <= g.w && iy0 >= 0 && iy0 + STEM_K <= g.h) {
+            // interior tile: every dword of the window exists — scalar base + precomputed lane offsets, no bounds logic
 #pragma unroll
-        for (int k = 0; k < STEM_WG_ROUNDS; k++) {
-            const int iy = 4 * (int)oy - STEM_PAD + ky;
-            const bool ok = stager && xok && row < g.NR && (unsigned)iy < (unsigned)g.h;
-            const uint32_t v = *reinterpret_cast<const uint32_t*>(ok ? base + coff + (size_t)iy * g.w : src);
-            raw[k] = ok ? v : 0u;
-            row += STEM_WG_RPR;                                    // + 15 rows = + 2 planes + 1 tap row
-            coff += 2 * (int)hw;
-            ky += 1;
-            const bool wrap = ky >= STEM_K;
-            ky -= wrap ? STEM_K : 0;
-            coff += wrap ? (int)hw : 0;
+            for (int k = 0; k < STEM_WG_ROUNDS; k++) st.raw[k] = *reinterpret_cast<const uint32_t*>(org + voff[512 * k]);
+            st.ok = rmask;
+        } else {
+            const int x = x0 + 4 * dq;
+            const bool xok = x >= 0 && x < g.w;
+            uint32_t okm = 0;
+#pragma unroll
+            for (int k = 0; k < STEM_WG_ROUNDS; k++) {
+                const int iy = iy0 + (int)((kys >> (3 * k)) & 7u);
+                const bool ok = ((rmask >> k) & 1u) && xok && (unsigned)iy < (unsigned)g.h;
+                st.raw[k] = *reinterpret_cast<const uint32_t*>(ok ? org + voff[512 * k] : src);      // (zeroed when stashed)
+                okm |= ok ? (1u << k) : 0u;
+            }
+            st.ok = okm;
         }
         const int ox = 32 * (int)xs + dyr;
         const bool dok = ox < g.Wo;
         const u32x2 z = {0u, 0u};
         const u32x2 v = *reinterpret_cast<const u32x2*>(dy + ((((size_t)f * g.Ho + oy) * g.Wo + (dok ? ox : 0)) * STEM_CO + 4 * dyc));
-        dyraw = dok ? v : z;
+        st.dyraw = dok ? v : z;
     };
-    auto stash = [&](int buf) {                  // registers -> bf16 LDS image
-        char* const img = smem + buf * IMG;
-        if (stager) {
+    auto stash = [&](const Stage& st, int tile, int buf) {         // registers -> bf16 LDS image
+        if (tile >= t_end) return;
+        char* const img = smem + buf * IMG + row0 * STEM_WG_ROWB + dq * 8;
+        if (row0 < STEM_WG_RPR) {
 #pragma unroll
             for (int k = 0; k < STEM_WG_ROUNDS; k++) {
-                const int row = row0 + STEM_WG_RPR * k;
-                if (row < STEM_WG_ROWS) {
+                if (STEM_WG_RPR * k + STEM_WG_RPR <= STEM_WG_ROWS || row0 + STEM_WG_RPR * k < STEM_WG_ROWS) {
                     typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+                    const uint32_t v = ((st.ok >> k) & 1u) ? st.raw[k] : 0u;
                     bf16x4 q;
-                    q[0] = (bf16)(float)(raw[k] & 0xffu);
-                    q[1] = (bf16)(float)((raw[k] >> 8) & 0xffu);
-                    q[2] = (bf16)(float)((raw[k] >> 16) & 0xffu);
-                    q[3] = (bf16)(float)(raw[k] >> 24);
-                    *reinterpret_cast<bf16x4*>(img + row * STEM_WG_ROWB + dq * 8) = q;
+                    q[0] = (bf16)(float)(v & 0xffu);
+                    q[1] = (bf16)(float)((v >> 8) & 0xffu);
+                    q[2] = (bf16)(float)((v >> 16) & 0xffu);
+                    q[3] = (bf16)(float)(v >> 24);
+                    *reinterpret_cast<bf16x4*>(img + STEM_WG_RPR * k * STEM_WG_ROWB) = q;
                 }
             }
         }
-        *reinterpret_cast<u32x2*>(smem + 2 * IMG + buf * DYT + dyr * STEM_WG_DYB + dyc * 8) = dyraw;
+        *reinterpret_cast<u32x2*>(smem + 2 * IMG + buf * DYT + dyr * STEM_WG_DYB + dyc * 8) = st.dyraw;
     };
-    if (t_begin < t_end) {
-        fetch(t_begin);
-        stash(0);
-    }
-    lds_barrier();
-    for (int tile = t_begin; tile < t_end; tile++) {
-        const int buf = (tile - t_begin) & 1;
-        const bool more = tile + 1 < t_end;
-        if (more) fetch(tile + 1);
+    auto compute = [&](int buf) {
         const char* const img = smem + buf * IMG;
         const char* const dyt = smem + 2 * IMG + buf * DYT;
         bf16x8 bq[2][2];
@@ -338,7 +390,26 @@ stem_wgrad_kernel(const uint8_t* __restrict__ src, const bf16* __restrict__ dy, 
                 }
             }
         }
-        if (more) stash(buf ^ 1);
+    };
+    // The two waves that share a SIMD (w and w + 4) take the two halves of an iteration in opposite order: one feeds the
+    // matrix pipe while the other converts — in lockstep both would convert, then both would queue on the pipe.
+    const bool mfma_first = wave < 4;
+    Stage sa, sb;
+    fetch(sa, t_begin);
+    fetch(sb, t_begin + 1);
+    stash(sa, t_begin, 0);
+    fetch(sa, t_begin + 2);
+    lds_barrier();
+    for (int tile = t_begin; tile < t_end; tile += 2) {
+        if (mfma_first) compute(0);               // tile
+        stash(sb, tile + 1, 1);
+        fetch(sb, tile + 3);
+        if (!mfma_first) compute(0);
+        lds_barrier();
+        if (mfma_first && tile + 1 < t_end) compute(1);       // tile + 1
+        stash(sa, tile + 2, 0);
+        fetch(sa, tile + 4);
+        if (!mfma_first && tile + 1 < t_end) compute(1);
         lds_barrier();
     }
     float* const out = ws + (size_t)blockIdx.x * (size_t)(g.NJB * 32) * STEM_CO;
