@@ -255,6 +255,25 @@ __device__ __forceinline__ void drain_vmem() {
 #endif
 }
 
+// sum over the 16 lanes of a DPP row (lanes 16 r .. 16 r + 15), result in all of them: four row rotations
+__device__ __forceinline__ float row16_sum(float v) {
+#ifdef RVT_EMU
+    auto buf = emu::exchange(&v, sizeof(v));
+    const int base = emu::g.cur->lane & ~15;
+    float s = 0.f;
+    for (int i = 0; i < 16; i++) { float t; memcpy(&t, buf[base + i], 4); s += t; }
+    return s;
+#else
+#define RVT_DPP_ROR(x, n) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x120 + (n), 0xf, 0xf, false))
+    v += RVT_DPP_ROR(v, 8);
+    v += RVT_DPP_ROR(v, 4);
+    v += RVT_DPP_ROR(v, 2);
+    v += RVT_DPP_ROR(v, 1);
+#undef RVT_DPP_ROR
+    return v;
+#endif
+}
+
 // keep the instruction scheduler from moving anything across this point (used to pin prefetch loads early)
 __device__ __forceinline__ void sched_fence() {
 #ifndef RVT_EMU

@@ -85,4 +85,42 @@ __device__ __forceinline__ void gelu_both_lut8(const float* lut, const float (&x
     }
 }
 
+// ---- both functions from ONE 16-byte gather -------------------------------------------------------------------------------
+// interleaved table: entry i = { Phi(x_i), Phi(x_i+1) - Phi(x_i), GELU'(x_i), GELU'(x_i+1) - GELU'(x_i) }
+constexpr int GELU_LUT4_BYTES = GELU_LUT_N * 16;
+__device__ __forceinline__ void gelu_lut4_fill(float* lut, int tid, int nthreads) {
+    const float h = 2.0f * GELU_LUT_X / (float)GELU_LUT_N;
+    for (int i = tid; i < GELU_LUT_N; i += nthreads) {
+        const float x0 = -GELU_LUT_X + h * (float)i, x1 = x0 + h;
+        float e0, e1;
+        const float f0 = gelu_phi(x0, e0), f1 = gelu_phi(x1, e1);
+        const float g0 = fmaf(x0 * 0.3989422804014327f, e0, f0), g1 = fmaf(x1 * 0.3989422804014327f, e1, f1);
+        *reinterpret_cast<f32x4*>(lut + 4 * i) = f32x4{f0, f1 - f0, g0, g1 - g0};
+    }
+}
+// g = x Phi(x), gp = GELU'(x) for eight values: all indices, all gathers, all interpolations (the gathers overlap)
+__device__ __forceinline__ void gelu_both_lut4_8(const float* lut, const float (&x)[8], float (&g)[8], float (&gp)[8]) {
+    const float s = (float)GELU_LUT_N / (2.0f * GELU_LUT_X);
+    float fr[8];
+    const f32x4* p[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        float t = fmaf(x[r], s, GELU_LUT_X * s);
+        t = fminf(fmaxf(t, 0.0f), (float)GELU_LUT_N - 0.001f);
+        const float fl = floorf(t);
+        fr[r] = t - fl;
+        p[r] = reinterpret_cast<const f32x4*>(lut) + (int)fl;
+    }
+    sched_fence();
+    f32x4 ab[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) ab[r] = *p[r];
+    sched_fence();
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        g[r] = x[r] * fmaf(fr[r], ab[r][1], ab[r][0]);
+        gp[r] = fmaf(fr[r], ab[r][3], ab[r][2]);
+    }
+}
+
 }  // namespace rvt

@@ -115,11 +115,7 @@ __device__ __forceinline__ void stem_fwd_item(f32x16 (&acc)[2][PB], const uint8_
                     d0 = (rowok && x0ok) ? d0 : 0u;
                     d1 = (rowok && x1ok) ? d1 : 0u;
                 }
-#if STEM_EXP == 1
-                { typedef __attribute__((ext_vector_type(4))) uint32_t u4_; u4_ q_ = {d0, d1, d0, d1}; a[j] = __builtin_bit_cast(bf16x8, q_); }
-#else
                 a[j] = stem_frag_u8(d0, d1);
-#endif
             }
             // the fences pin the software pipeline: left alone, the scheduler sinks the loads next to their uses (one k-step
             // of latency cover instead of D) and drains the queue at every loop back-edge
@@ -199,11 +195,6 @@ stem_fwd_kernel(const uint8_t* __restrict__ src, const bf16* __restrict__ wp, co
         const char* wl = Wl + (size_t)(li * 2 + half) * 16;
         if (interior) stem_fwd_item<PB, D, true>(acc, plane0, wl, g, oy0, half, xo0, xo1, x0ok, x1ok);
         else stem_fwd_item<PB, D, false>(acc, plane0, wl, g, oy0, half, xo0, xo1, x0ok, x1ok);
-#if STEM_EXP == 2
-        { float t_ = 0.f;
-          for (int nb = 0; nb < 2; nb++) for (int j = 0; j < PB; j++) for (int r = 0; r < 16; r++) t_ += acc[nb][j][r];
-          if (colok) y0[(((size_t)f * g.Ho + oy0) * g.Wo + ox) * STEM_CO] = (bf16)t_; }
-#else
         // epilogue: y0 (bf16, what the LayerNorm backward reads) and LN(y0) as 16-byte row pieces
 #pragma unroll
         for (int j = 0; j < PB; j++) {
@@ -248,7 +239,6 @@ stem_fwd_kernel(const uint8_t* __restrict__ src, const bf16* __restrict__ wp, co
                     }
             }
         }
-#endif
     }
 }
 
