@@ -562,6 +562,7 @@ size_t rvt_mlp_bwd_fused_ws_floats(int dtype, int C, int M) {
     size_t grid = dtype == RVT_BF16 ? mlp_bwd_fused_grid<bf16, 0>(M) : mlp_bwd_fused_grid<float, 0>(M);
     const size_t g2 = dtype == RVT_BF16 ? mlp_bwd_fused_grid<bf16, 2>(M) : mlp_bwd_fused_grid<float, 2>(M);
     if (g2 > grid) grid = g2;
+    if (grid < 256) grid = 256;                          // mlpc_bwd_wgrad_kernel: one workgroup per CU
     return grid * ((size_t)2 * 4 * C * C + 2 * 4 * C + C);
 }
 
@@ -610,6 +611,14 @@ int rvt_mlp_bwd_recompute_wgrad(const void* dxout, const void* xmid, const float
     RVT_CHECK(ws != nullptr && M >= 1, "mlp_bwd_recompute_wgrad: workspace required");
     hipStream_t st = (hipStream_t)stream;
     int grid = 0;
+    static const int chain_wgrad = getenv("RVT_MLP_CHAIN_WGRAD") ? atoi(getenv("RVT_MLP_CHAIN_WGRAD")) : 1;
+    if (chain_wgrad && dtype == RVT_BF16 && mlp_chain_on(dtype, C)) {
+        grid = stem_wgrad_grid((M + 31) / 32);          // one workgroup per CU (tests: RVT_STEM_GRID)
+        hipLaunchKernelGGL(mlpc_bwd_wgrad_kernel, dim3(grid), dim3(512), 0, st, (const bf16*)dxout, (const bf16*)xmid, ln_w, ln_b,
+                           (const bf16*)w1, b1, (const bf16*)w2g_t, ws, M, eps);
+        mlp_fold_partials(ws, grid, C, dw1, db1, s2, cs2, st);
+        return check_launch("mlp_bwd_recompute_wgrad(chain)");
+    }
     DISPATCH_DTYPE(dtype, {
         grid = mlp_bwd_fused_grid<T, 2>(M);
         hipLaunchKernelGGL((mlp_bwd_fused_kernel<T, 64, 2>), dim3(grid, 2), dim3(256), 0, st, (const T*)dxout, (const T*)xmid,

@@ -301,4 +301,171 @@ mlpc_bwd_dgrad_kernel(const T* __restrict__ dxout, const T* __restrict__ xmid, T
     }
 }
 
+// =========================================================================== backward: weight gradients (bf16, C = 64)
+//   dW1[j][c] = sum_t dh[t][j] v2[t][c],  db1[j] = sum_t dh[t][j],  S2[c][j] = sum_t dxout[t][c] g[t][j],  cs2[c] = sum_t dxout[t][c]
+//   with v2 = LN2(xmid), h = v2 W1^T + b1, g = GELU(h), dh = (dxout (gamma W2)) GELU'(h)      (everything recomputed)
+// A workgroup of eight waves walks 32-token tiles; wave w owns the hidden columns j = 32 w .. 32 w + 31 and keeps its
+// rows of W1 and (gamma W2)^T in registers (no weights in LDS).  Per tile the v2 rows (LayerNorm done once, sixteen lanes
+// per row) and the dxout rows go into two small LDS tiles; from there every operand is a plain or a transposing read:
+//   h, dg    A = token rows (16-byte row pieces), B = the wave's weight rows -> accumulator column = hidden j (this lane),
+//            registers = the tile's tokens in accumulator order;
+//   dW1, S2  contract over the TOKENS: one operand is g / dh straight from those accumulator registers, the other is
+//            v2^T / dxout^T = ds_read_b64_tr_b16 on the row-major tiles, addressed in the same (accumulator) token order.
+// No identity-MFMA transposes, no copies of the hidden activations anywhere; GELU and GELU' come from one 16-byte table gather.
+// Partial results per workgroup in `ws`, laid out as mlp_fold_partials expects:
+// [dW1: grid x 4C x C][S2: grid x C x 4C][db1: 2 grid x 4C][cs2: grid x C].
+constexpr int MCW_ROWB = 144;              // LDS row pitch of the [32 tokens][64 channels] bf16 tiles (bank spread for the transposing reads)
+__global__ void __launch_bounds__(512)
+mlpc_bwd_wgrad_kernel(const bf16* __restrict__ dxout, const bf16* __restrict__ xmid, const float* __restrict__ ln_w,
+                      const float* __restrict__ ln_b, const bf16* __restrict__ W1, const float* __restrict__ b1,
+                      const bf16* __restrict__ W2gT, float* __restrict__ ws, int M, float eps) {
+    typedef bf16 T;
+    constexpr int C = 64, KS = C / 16, NCB = C / 32, HID = 4 * C, TILE = 32 * MCW_ROWB;
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE + GELU_LUT4_BYTES];
+    char* const V2 = smem;
+    char* const DX = smem + 2 * TILE;
+    float* const lut = reinterpret_cast<float*>(smem + 4 * TILE);
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, half = lane >> 5, wave = tid >> 6;
+    gelu_lut4_fill(lut, tid, 512);
+    // this wave's weight rows j = 32 wave + li, as B operands (k-step ks: channels 16 ks + 8 half ..)
+    frag_t<T> w1f[KS], w2f[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) {
+        w1f[ks] = frag_load<T>(W1 + (size_t)(32 * wave + li) * C + 16 * ks + 8 * half);
+        w2f[ks] = frag_load<T>(W2gT + (size_t)(32 * wave + li) * C + 16 * ks + 8 * half);
+    }
+    const float b1v = b1[32 * wave + li];
+    // staging role: 16 threads per token row, 4 channels each
+    const int srow = tid >> 4, spc = tid & 15;
+    float lw[4], lb[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { lw[i] = ln_w[4 * spc + i]; lb[i] = ln_b[4 * spc + i]; }
+    // transposing reads in accumulator token order: slots 0..3 = tokens 16 q + 4 half + 0..3, slots 4..7 = those + 8
+    const int tr_off = (4 * half + ((lane & 15) >> 2)) * MCW_ROWB + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+
+    f32x16 dw1[NCB], s2[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) { acc_zero(dw1[cb]); acc_zero(s2[cb]); }
+    float db1 = 0.f, cs[4] = {0.f, 0.f, 0.f, 0.f};
+
+    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+    struct Stage { u32x2 x, d; };
+    const int n_tiles = (M + 31) / 32;
+    auto fetch = [&](Stage& st, int tile) {
+        const int row = tile * 32 + srow;
+        const bool ok = tile < n_tiles && row < M;
+        const size_t off = (size_t)(ok ? row : 0) * C + 4 * spc;
+        const u32x2 z = {0u, 0u};
+        const u32x2 vx = *reinterpret_cast<const u32x2*>(xmid + off), vd = *reinterpret_cast<const u32x2*>(dxout + off);
+        st.x = ok ? vx : z;
+        st.d = ok ? vd : z;
+    };
+    auto stash = [&](const Stage& st, int tile, int buf) {
+        if (tile >= n_tiles) return;
+        const bf16x4 xb = __builtin_bit_cast(bf16x4, st.x), db = __builtin_bit_cast(bf16x4, st.d);
+        float x[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) { x[i] = (float)xb[i]; cs[i] += (float)db[i]; }
+        const float mean = row16_sum((x[0] + x[1]) + (x[2] + x[3])) * (1.0f / C);
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { x[i] -= mean; ss += x[i] * x[i]; }
+        const float rstd = 1.0f / sqrtf(row16_sum(ss) * (1.0f / C) + eps);
+        bf16x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[i] = (T)fmaf(x[i] * rstd, lw[i], lb[i]);
+        *reinterpret_cast<bf16x4*>(V2 + buf * TILE + srow * MCW_ROWB + spc * 8) = v;
+        *reinterpret_cast<u32x2*>(DX + buf * TILE + srow * MCW_ROWB + spc * 8) = st.d;
+    };
+    auto compute = [&](int buf) {
+        const char* const v2t = V2 + buf * TILE;
+        const char* const dxt = DX + buf * TILE;
+        // accumulator column = hidden j (this lane), registers = the tile's tokens
+        f32x16 h, dg;
+#pragma unroll
+        for (int r = 0; r < 16; r++) h[r] = b1v;
+        acc_zero(dg);
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            mma32(h, *reinterpret_cast<const frag_t<T>*>(v2t + li * MCW_ROWB + (2 * ks + half) * 16), w1f[ks]);
+            mma32(dg, *reinterpret_cast<const frag_t<T>*>(dxt + li * MCW_ROWB + (2 * ks + half) * 16), w2f[ks]);
+        }
+        frag_t<T> gf[2], dhf[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {               // slot q of the operands = accumulator registers 8q .. 8q+7
+            float x8[8], g8[8], p8[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) x8[e] = h[8 * q + e];
+            gelu_both_lut4_8(lut, x8, g8, p8);
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float d = dg[8 * q + e] * p8[e];
+                db1 += d;
+                gf[q][e] = (T)g8[e];
+                dhf[q][e] = (T)d;
+            }
+        }
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++)
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int o = tr_off + 16 * q * MCW_ROWB + 64 * cb;
+                const frag_t<T> vT = frag_from_tr<T>(reinterpret_cast<const bf16*>(v2t + o), reinterpret_cast<const bf16*>(v2t + o + 8 * MCW_ROWB));
+                const frag_t<T> dT = frag_from_tr<T>(reinterpret_cast<const bf16*>(dxt + o), reinterpret_cast<const bf16*>(dxt + o + 8 * MCW_ROWB));
+                mma32(dw1[cb], dhf[q], vT);         // rows j, columns c
+                mma32(s2[cb], dT, gf[q]);           // rows c, columns j
+            }
+    };
+    // (same pipeline as the stem weight gradient, csrc/stem.hpp: two tiles in flight, the waves sharing a SIMD staggered)
+    const bool mfma_first = wave < 4;
+    const int t0 = blockIdx.x, G = gridDim.x;
+    Stage sa, sb;
+    fetch(sa, t0);
+    fetch(sb, t0 + G);
+    __syncthreads();                                // table
+    stash(sa, t0, 0);
+    fetch(sa, t0 + 2 * G);
+    lds_barrier();
+    for (int tile = t0; tile < n_tiles; tile += 2 * G) {
+        if (mfma_first) compute(0);
+        stash(sb, tile + G, 1);
+        fetch(sb, tile + 3 * G);
+        if (!mfma_first) compute(0);
+        lds_barrier();
+        if (mfma_first && tile + G < n_tiles) compute(1);
+        stash(sa, tile + 2 * G, 0);
+        fetch(sa, tile + 4 * G);
+        if (!mfma_first && tile + G < n_tiles) compute(1);
+        lds_barrier();
+    }
+    const size_t nwg = gridDim.x, wg = blockIdx.x;
+    float* const p_dw1 = ws + wg * (size_t)(HID * C);
+    float* const p_s2 = ws + nwg * (size_t)(HID * C) + wg * (size_t)(C * HID);
+    float* const p_db1 = ws + 2 * nwg * (size_t)(HID * C) + (wg * 2) * (size_t)HID;
+    float* const p_cs2 = ws + 2 * nwg * (size_t)(HID * C) + 2 * nwg * (size_t)HID + wg * (size_t)C;
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            p_dw1[(size_t)(32 * wave + acc_row(r, lane)) * C + 32 * cb + li] = dw1[cb][r];
+            p_s2[(size_t)(32 * cb + acc_row(r, lane)) * HID + 32 * wave + li] = s2[cb][r];
+        }
+    db1 += __shfl_xor(db1, 32);
+    if (half == 0) {
+        p_db1[32 * wave + li] = db1;
+        p_db1[HID + 32 * wave + li] = 0.f;
+    }
+    // column sums of dxout: fold the 32 row slots through LDS (the tiles are done with)
+    float* const red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < 4; i++) red[srow * C + 4 * spc + i] = cs[i];
+    __syncthreads();
+    if (tid < C) {
+        float s = 0.f;
+        for (int r = 0; r < 32; r++) s += red[r * C + tid];
+        p_cs2[tid] = s;
+    }
+}
+
 }  // namespace rvt
