@@ -62,6 +62,11 @@ int rvt_stem_fwd(const void* src, const void* w, const float* ln_w, const float*
                  int Cin, int cp, int h, int wd, int H, int W, float eps, void* stream);
 /* dw[64][7*7*cp] (float32, the layout of rvt_conv_wgrad) += dy^T im2col(src); ws: rvt_stem_wgrad_ws_floats floats. */
 size_t rvt_stem_wgrad_ws_floats(int Cin, int F, int H, int W);
+/* ... with the LayerNorm backward (maxvit.py:177) folded in: dx = gradient at x = LayerNorm(y0); dw as above,
+ * dln_w[64] += sum dx xhat, dln_b[64] += sum dx; the gradient at y0 itself is never written (replaces
+ * rvt_layernorm_bwd + rvt_conv_wgrad of the first stage, whose input needs no gradient). */
+int rvt_stem_wgrad_ln(const void* src, const void* dx, const void* y0, const float* ln_w, float* dw, float* dln_w, float* dln_b,
+                      float* ws, int dtype, int F, int Cin, int cp, int h, int wd, int H, int W, float eps, void* stream);
 int rvt_stem_wgrad(const void* src, const void* dy, float* dw, float* ws, int dtype, int F, int Cin, int cp, int h, int wd,
                    int H, int W, void* stream);
 

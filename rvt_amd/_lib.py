@@ -30,6 +30,7 @@ _SIGS = {
     'rvt_conv_wgrad': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     'rvt_stem_fwd': [_vp] * 6 + [_i] * 8 + [_f, _vp],
     'rvt_stem_wgrad': [_vp] * 4 + [_i] * 8 + [_vp],
+    'rvt_stem_wgrad_ln': [_vp] * 8 + [_i] * 8 + [_f, _vp],
     'rvt_layernorm_fwd': [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
     'rvt_layernorm_bwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
     'rvt_linear_fwd': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],

@@ -250,8 +250,8 @@ size_t rvt_stem_wgrad_ws_floats(int Cin, int F, int H, int W) {
     return (size_t)stem_wgrad_grid(F * Ho * ((Wo + 31) / 32)) * (size_t)(NJB * 32) * STEM_CO;
 }
 
-int rvt_stem_wgrad(const void* src, const void* dy, float* dw, float* ws, int dtype, int F, int Cin, int cp, int h, int wd,
-                   int H, int W, void* stream) {
+static int stem_wgrad_launch(const void* src, const void* dy, const void* y0, const float* ln_w, float* dln_w, float* dln_b, float* dw,
+                             float* ws, int dtype, int F, int Cin, int cp, int h, int wd, int H, int W, float eps, void* stream) {
     RVT_CHECK(rvt_stem_supported(dtype, 1, Cin, STEM_CO, STEM_K, STEM_STRIDE, STEM_PAD, wd), "stem_wgrad: unsupported shape Cin=%d w=%d", Cin, wd);
     RVT_CHECK(h <= H && wd <= W && cp >= Cin && ws != nullptr, "stem_wgrad: bad arguments");
     StemWgGeom g;
@@ -263,10 +263,26 @@ int rvt_stem_wgrad(const void* src, const void* dy, float* dw, float* ws, int dt
     g.per_wg = (g.n_tiles + grid - 1) / grid;
     g.dXS = FastDiv(g.XS); g.dHo = FastDiv(g.Ho); g.d7 = FastDiv(STEM_K);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(grid), dim3(512), 0, st, (const uint8_t*)src, (const bf16*)dy, ws, g);
+    if (y0 != nullptr)
+        hipLaunchKernelGGL(stem_wgrad_kernel<true>, dim3(grid), dim3(512), 0, st, (const uint8_t*)src, (const bf16*)dy, (const bf16*)y0, ln_w,
+                           dln_w, dln_b, ws, g, eps);
+    else
+        hipLaunchKernelGGL(stem_wgrad_kernel<false>, dim3(grid), dim3(512), 0, st, (const uint8_t*)src, (const bf16*)dy, (const bf16*)nullptr,
+                           (const float*)nullptr, (float*)nullptr, (float*)nullptr, ws, g, 0.f);
     const int total = STEM_CO * STEM_K * STEM_K * Cin;
     hipLaunchKernelGGL(stem_wgrad_fold_kernel, dim3((total + 255) / 256), dim3(256), 0, st, (const float*)ws, dw, grid, Cin, cp, g.NJB);
     return check_launch("stem_wgrad");
+}
+
+int rvt_stem_wgrad(const void* src, const void* dy, float* dw, float* ws, int dtype, int F, int Cin, int cp, int h, int wd,
+                   int H, int W, void* stream) {
+    return stem_wgrad_launch(src, dy, nullptr, nullptr, nullptr, nullptr, dw, ws, dtype, F, Cin, cp, h, wd, H, W, 0.f, stream);
+}
+
+int rvt_stem_wgrad_ln(const void* src, const void* dx, const void* y0, const float* ln_w, float* dw, float* dln_w, float* dln_b,
+                      float* ws, int dtype, int F, int Cin, int cp, int h, int wd, int H, int W, float eps, void* stream) {
+    RVT_CHECK(y0 != nullptr && ln_w != nullptr && dln_w != nullptr && dln_b != nullptr, "stem_wgrad_ln: null argument");
+    return stem_wgrad_launch(src, dx, y0, ln_w, dln_w, dln_b, dw, ws, dtype, F, Cin, cp, h, wd, H, W, eps, stream);
 }
 
 int rvt_conv_dgrad(const void* dy, const void* wd, const void* add, void* din, int dtype, int F, int H, int W, int Cin,

@@ -259,11 +259,18 @@ struct StemWgGeom {
 };
 
 // ws: [workgroup][j = 8 r + e'][cout] partial sums, r = (c, ky) row, e' = kx + 1 (e' = 0 unused)
+// LNB: `dy` is the gradient at the LayerNorm OUTPUT and `y0` the conv output: the LayerNorm backward (maxvit.py:177) is done
+// while the dy tile is staged (sixteen threads per pixel row hold it anyway) — dy0 never exists in HBM, its parameter
+// gradients are accumulated per thread in LDS and added to dln_w / dln_b at the end.
+template <bool LNB>
 __global__ void __launch_bounds__(512)
-stem_wgrad_kernel(const uint8_t* __restrict__ src, const bf16* __restrict__ dy, float* __restrict__ ws, StemWgGeom g) {
+stem_wgrad_kernel(const uint8_t* __restrict__ src, const bf16* __restrict__ dy, const bf16* __restrict__ y0,
+                  const float* __restrict__ ln_w, float* __restrict__ dln_w, float* __restrict__ dln_b, float* __restrict__ ws,
+                  StemWgGeom g, float eps) {
     typedef bf16 T;
     constexpr int IMG = STEM_WG_ROWS * STEM_WG_ROWB, DYT = 32 * STEM_WG_DYB;
-    __shared__ __attribute__((aligned(16))) char smem[2 * IMG + 2 * DYT + STEM_WG_ROUNDS * 512 * 4];
+    __shared__ __attribute__((aligned(16))) char smem[2 * IMG + 2 * DYT + STEM_WG_ROUNDS * 512 * 4 + (LNB ? 512 * 32 : 16)];
+    float* const dlp = reinterpret_cast<float*>(smem + 2 * IMG + 2 * DYT + STEM_WG_ROUNDS * 512 * 4) + 8 * threadIdx.x;   // LNB: this thread's dln_w / dln_b partials
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, half = lane >> 5, wave = tid >> 6;
     const int hw = g.h * g.w;
     uint32_t* const voff = reinterpret_cast<uint32_t*>(smem + 2 * IMG + 2 * DYT) + tid;       // [k][thread]: see below
@@ -304,7 +311,8 @@ stem_wgrad_kernel(const uint8_t* __restrict__ src, const bf16* __restrict__ dy, 
     // Two tiles of source dwords in flight per thread (register sets A, B): a tile is requested two iterations before it is
     // converted into the LDS image.
     typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
-    struct Stage { uint32_t raw[STEM_WG_ROUNDS]; u32x2 dyraw; uint32_t ok; };
+    struct Stage { uint32_t raw[STEM_WG_ROUNDS]; u32x2 dyraw, y0raw; uint32_t ok; };
+    if (LNB) { *reinterpret_cast<f32x4*>(dlp) = f32x4{0.f, 0.f, 0.f, 0.f}; *reinterpret_cast<f32x4*>(dlp + 4) = f32x4{0.f, 0.f, 0.f, 0.f}; }
     auto fetch = [&](Stage& st, int tile) {      // global -> registers
         if (tile >= t_end) return;
         uint32_t fo, xs, f, oy;
@@ -333,8 +341,13 @@ stem_wgrad_kernel(const uint8_t* __restrict__ src, const bf16* __restrict__ dy, 
         const int ox = 32 * (int)xs + dyr;
         const bool dok = ox < g.Wo;
         const u32x2 z = {0u, 0u};
-        const u32x2 v = *reinterpret_cast<const u32x2*>(dy + ((((size_t)f * g.Ho + oy) * g.Wo + (dok ? ox : 0)) * STEM_CO + 4 * dyc));
+        const size_t doff = (((size_t)f * g.Ho + oy) * g.Wo + (dok ? ox : 0)) * STEM_CO + 4 * dyc;
+        const u32x2 v = *reinterpret_cast<const u32x2*>(dy + doff);
         st.dyraw = dok ? v : z;
+        if (LNB) {
+            const u32x2 vy = *reinterpret_cast<const u32x2*>(y0 + doff);
+            st.y0raw = dok ? vy : z;
+        }
     };
     auto stash = [&](const Stage& st, int tile, int buf) {         // registers -> bf16 LDS image
         if (tile >= t_end) return;
@@ -354,7 +367,37 @@ stem_wgrad_kernel(const uint8_t* __restrict__ src, const bf16* __restrict__ dy, 
                 }
             }
         }
-        *reinterpret_cast<u32x2*>(smem + 2 * IMG + buf * DYT + dyr * STEM_WG_DYB + dyc * 8) = st.dyraw;
+        u32x2 dyv = st.dyraw;
+        if (LNB) {
+            typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+            const bf16x4 yb = __builtin_bit_cast(bf16x4, st.y0raw), gb = __builtin_bit_cast(bf16x4, st.dyraw);
+            const f32x4 lw = *reinterpret_cast<const f32x4*>(ln_w + 4 * dyc);
+            float x[4], gq[4], dyf[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) { x[i] = (float)yb[i]; dyf[i] = (float)gb[i]; }
+            const float mean = row16_sum((x[0] + x[1]) + (x[2] + x[3])) * (1.0f / STEM_CO);
+            float ss = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; i++) { x[i] -= mean; ss += x[i] * x[i]; }
+            const float rstd = 1.0f / sqrtf(row16_sum(ss) * (1.0f / STEM_CO) + eps);
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; i++) { x[i] *= rstd; gq[i] = dyf[i] * lw[i]; s1 += gq[i]; s2 += gq[i] * x[i]; }
+            s1 = row16_sum(s1) * (1.0f / STEM_CO);
+            s2 = row16_sum(s2) * (1.0f / STEM_CO);
+            bf16x4 o;
+            f32x4 pw = *reinterpret_cast<const f32x4*>(dlp), pb = *reinterpret_cast<const f32x4*>(dlp + 4);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                o[i] = (bf16)(rstd * (gq[i] - s1 - x[i] * s2));
+                pw[i] += dyf[i] * x[i];
+                pb[i] += dyf[i];
+            }
+            *reinterpret_cast<f32x4*>(dlp) = pw;
+            *reinterpret_cast<f32x4*>(dlp + 4) = pb;
+            dyv = __builtin_bit_cast(u32x2, o);
+        }
+        *reinterpret_cast<u32x2*>(smem + 2 * IMG + buf * DYT + dyr * STEM_WG_DYB + dyc * 8) = dyv;
     };
     auto compute = [&](int buf) {
         const char* const img = smem + buf * IMG;
@@ -411,6 +454,16 @@ stem_wgrad_kernel(const uint8_t* __restrict__ src, const bf16* __restrict__ dy, 
             for (int nb = 0; nb < 2; nb++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) out[(size_t)(32 * jb + acc_row(r, lane)) * STEM_CO + 32 * nb + li] = acc[i][nb][r];
+        }
+    }
+    if (LNB) {                                     // thread (row slot dyr, piece dyc) -> channel sums over the 32 row slots
+        __syncthreads();
+        if (tid < 2 * STEM_CO) {
+            const int c = tid & (STEM_CO - 1), which = tid >> 6;
+            const float* p = reinterpret_cast<const float*>(smem + 2 * IMG + 2 * DYT + STEM_WG_ROUNDS * 512 * 4) + 8 * (c >> 2) + 4 * which + (c & 3);
+            float sum = 0.f;
+            for (int r = 0; r < 32; r++) sum += p[r * 16 * 8];
+            atomicAdd((which ? dln_b : dln_w) + c, sum);
         }
     }
 }

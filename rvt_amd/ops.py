@@ -80,8 +80,10 @@ def stem_fwd(src: Tensor, w: Tensor, ln_w: Tensor, ln_b: Tensor, H: int, W: int,
     return y0, x
 
 
-def stem_wgrad(src: Tensor, dy: Tensor, dw: Tensor, H: int, W: int) -> None:
-    """dw (64, 49*cp) fp32 += dy^T im2col(pad(src)) — the layout conv_wgrad writes."""
+def stem_wgrad(src: Tensor, dy: Tensor, dw: Tensor, H: int, W: int, y0: Optional[Tensor] = None, ln_w: Optional[Tensor] = None,
+               dln_w: Optional[Tensor] = None, dln_b: Optional[Tensor] = None, eps: float = 1e-5) -> None:
+    """dw (64, 49*cp) fp32 += dy^T im2col(pad(src)) — the layout conv_wgrad writes.  With y0 (the conv output): `dy` is the
+    gradient at LayerNorm(y0) and the LayerNorm backward runs inside the kernel (dln_w, dln_b += its parameter gradients)."""
     assert src.dtype == torch.uint8 and src.is_contiguous() and dy.is_contiguous() and dw.dtype == torch.float32
     F_, Cin, h, wd = src.shape
     cp = dw.shape[1] // 49
@@ -93,7 +95,12 @@ def stem_wgrad(src: Tensor, dy: Tensor, dw: Tensor, H: int, W: int) -> None:
     if ws is None or ws.numel() < n:
         ws = torch.empty(n, dtype=torch.float32, device=dy.device)
         _WS[key] = ws
-    L.call('rvt_stem_wgrad', L.ptr(src), L.ptr(dy), L.ptr(dw), L.ptr(ws), L.dtype_code(dy.dtype), F_, Cin, cp, h, wd, H, W, st)
+    if y0 is None:
+        L.call('rvt_stem_wgrad', L.ptr(src), L.ptr(dy), L.ptr(dw), L.ptr(ws), L.dtype_code(dy.dtype), F_, Cin, cp, h, wd, H, W, st)
+    else:
+        assert y0.is_contiguous() and y0.shape == dy.shape and y0.dtype == dy.dtype
+        L.call('rvt_stem_wgrad_ln', L.ptr(src), L.ptr(dy), L.ptr(y0), L.ptr(ln_w), L.ptr(dw), L.ptr(dln_w), L.ptr(dln_b), L.ptr(ws),
+               L.dtype_code(dy.dtype), F_, Cin, cp, h, wd, H, W, float(eps), st)
 
 
 def conv_dgrad(dy: Tensor, wd: Tensor, add: Optional[Tensor], H: int, W: int, Cin: int, k: int, stride: int, pad: int,

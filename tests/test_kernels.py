@@ -427,6 +427,17 @@ def test_stem(backend, case):
     close(got, wr.grad, dt, 'stem wgrad')
     pad_cols = (dw - 0.5).view(64, 49, cp)[:, :, Cin:]
     assert float(pad_cols.abs().max()) == 0.0 if cp > Cin else True
+    # ... and with the LayerNorm backward folded in: gradient dx at x = LN(y0) -> dW, dln_w, dln_b (y0 = the stored bf16 conv output)
+    y0r = f64(y0).requires_grad_(True)
+    lwr, lbr = f64(lw).requires_grad_(True), f64(lb).requires_grad_(True)
+    F.layer_norm(y0r, (64,), lwr, lbr, 1e-5).backward(f64(dy))
+    wr.grad = None
+    F.conv2d(xin, wr, None, 4, 3).backward(y0r.grad.to(dt).double().permute(0, 3, 1, 2))      # (the kernel rounds dy0 to bf16 too)
+    dw2, dlw, dlb = torch.zeros(64, 49 * cp, device=backend), torch.full((64,), 0.25, device=backend), torch.full((64,), -0.5, device=backend)
+    ops.stem_wgrad(srcd, dy, dw2, H, W, y0=y0, ln_w=lw, dln_w=dlw, dln_b=dlb, eps=1e-5)
+    close(weights.unpack_conv_wgrad(dw2, Cin, 7), wr.grad, dt, 'stem wgrad with LN backward')
+    close(dlw - 0.25, lwr.grad, dt, 'stem dln_w')
+    close(dlb + 0.5, lbr.grad, dt, 'stem dln_b')
 
 
 @pytest.mark.parametrize('dt', DTYPES)
