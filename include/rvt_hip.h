@@ -174,6 +174,11 @@ int rvt_lstm_gates_bwd(const void* dh_in, const void* dh_rec, float* dc_rec, con
                        const float* c_prev, void* dz, int dtype, int M, int C, void* stream);
 /* [dx | dh_rec] = dz W : wt = W^T [2C][4C] natural gate order. */
 int rvt_lstm_dgrad(const void* dz, const void* wt, void* dx, void* dh_rec, int dtype, int M, int C, void* stream);
+/* One BPTT step in one launch: dx_t = (dz_t W)[:, :C]; the recurrent half (dz_t W)[:, C:] is consumed in the epilogue by the
+ * gate backward of step t-1 (the arithmetic of rvt_lstm_gates_bwd with dh_rec = that half, rounded to dtype): reads
+ * dh_in_prev [M][C], gates_prev [M][4C], c_new_prev / c_prev_prev [M][C] fp32, updates dc_rec in place, writes dz_prev. */
+int rvt_lstm_dgrad_gates(const void* dz, const void* wt, void* dx, const void* dh_in_prev, float* dc_rec, const void* gates_prev,
+                         const float* c_new_prev, const float* c_prev_prev, void* dz_prev, int dtype, int M, int C, void* stream);
 /* dw[4C][2C] (float32) += dz^T [x | h_prev];  dz_colsum[4C] += column sums of dz if non-NULL (bias gradient). */
 int rvt_lstm_wgrad(const void* dz, const void* x, const void* h_prev, float* dw, float* dz_colsum, float* ws, int dtype,
                    int M, int C, void* stream);

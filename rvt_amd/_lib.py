@@ -48,6 +48,7 @@ _SIGS = {
     'rvt_lstm_fwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     'rvt_lstm_gates_bwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     'rvt_lstm_dgrad': [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    'rvt_lstm_dgrad_gates': [_vp] * 9 + [_i, _i, _i, _vp],
     'rvt_lstm_wgrad': [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     'rvt_dwconv_fwd': [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     'rvt_dwconv_wgrad': [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],

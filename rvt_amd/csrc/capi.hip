@@ -819,6 +819,19 @@ int rvt_lstm_dgrad(const void* dz, const void* wt, void* dx, void* dh_rec, int d
     return check_launch("lstm_dgrad");
 }
 
+int rvt_lstm_dgrad_gates(const void* dz, const void* wt, void* dx, const void* dh_in_prev, float* dc_rec, const void* gates_prev,
+                         const float* c_new_prev, const float* c_prev_prev, void* dz_prev, int dtype, int M, int C, void* stream) {
+    RVT_CHECK(C % 8 == 0, "lstm_dgrad_gates: C=%d must be a multiple of 8", C);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_DTYPE(dtype, {
+        PlainSrc<T> a{(const T*)dz, 4 * C, M, 4 * C};
+        PlainSrc<T> b{(const T*)wt, 4 * C, 2 * C, 4 * C};
+        EpLstmBwd<T> ep{(T*)dx, C, (const T*)dh_in_prev, dc_rec, (const T*)gates_prev, c_new_prev, c_prev_prev, (T*)dz_prev};
+        DISPATCH_BN(2 * C, (launch_gemm<T, BN, false>(a, XfNone(), b, XfNone(), ep, M, 2 * C, 4 * C, 1, st)));
+    });
+    return check_launch("lstm_dgrad_gates");
+}
+
 int rvt_lstm_wgrad(const void* dz, const void* x, const void* h_prev, float* dw, float* dz_colsum, float* ws, int dtype,
                    int M, int C, void* stream) {
     RVT_CHECK(C % 8 == 0, "lstm_wgrad: C=%d must be a multiple of 8", C);

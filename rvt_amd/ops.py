@@ -369,6 +369,15 @@ def lstm_dgrad(dz: Tensor, wt: Tensor, dx: Tensor, dh_rec: Tensor) -> None:
            L.stream_of(dz))
 
 
+def lstm_dgrad_gates(dz: Tensor, wt: Tensor, dx: Tensor, dh_in_prev: Tensor, dc_rec: Tensor, gates_prev: Tensor, c_new_prev: Tensor,
+                     c_prev_prev: Tensor, dz_prev: Tensor) -> None:
+    """lstm_dgrad of step t with lstm_gates_bwd of step t-1 in its epilogue (the recurrent dh never goes to HBM)."""
+    C = dx.shape[-1]
+    M = dx.numel() // C
+    L.call('rvt_lstm_dgrad_gates', L.ptr(dz), L.ptr(wt), L.ptr(dx), L.ptr(dh_in_prev), L.ptr(dc_rec), L.ptr(gates_prev),
+           L.ptr(c_new_prev), L.ptr(c_prev_prev), L.ptr(dz_prev), L.dtype_code(dz.dtype), M, C, L.stream_of(dz))
+
+
 def lstm_wgrad(dz: Tensor, x: Tensor, h_prev: Tensor, dw: Tensor, colsum_out: Optional[Tensor] = None) -> None:
     C = x.shape[-1]
     M = x.numel() // C

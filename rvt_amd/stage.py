@@ -286,9 +286,18 @@ def stage_seq_backward(sw: StageWeights, g: StageGeom, sv: StageSaved, dH: Optio
         dhc = torch.empty((T, B, H, W, C), dtype=dt, device=dev) if dws is not None else None   # d(dwconv(h_{t-1}))
         if dws is not None:
             wh = dws['w'] if dws['only_hidden'] else dws['w'][C:]
+        # (rvt_lstm_dgrad_gates: one launch per step instead of two, but the side inputs of the gate backward are then loaded behind
+        # the product instead of streamed by a bandwidth-bound kernel: 113 us per step against 42 + 32 at stages 3-4 — opt-in)
+        fuse_gates = dws is None and os.environ.get('RVT_LSTM_FUSE_GATES', '0') == '1'
         for t in range(T - 1, -1, -1):
-            ops.lstm_gates_bwd(dH[t], dh_rec, dc_rec, sv.gates[t], sv.Call[t + 1], sv.Call[t], dz[t])
+            if not fuse_gates or t == T - 1:
+                ops.lstm_gates_bwd(dH[t], dh_rec, dc_rec, sv.gates[t], sv.Call[t + 1], sv.Call[t], dz[t])
             nxt = dh_buf[t & 1]
+            if fuse_gates and t > 0:
+                # one launch per step: the gate backward of step t-1 is the epilogue of this step's input-gradient product
+                ops.lstm_dgrad_gates(dz[t], sw.lstm_wt, dx[t], dH[t - 1], dc_rec, sv.gates[t - 1], sv.Call[t], sv.Call[t - 1],
+                                     dz[t - 1])
+                continue
             if dws is None:
                 ops.lstm_dgrad(dz[t], sw.lstm_wt, dx[t], nxt)
             else:

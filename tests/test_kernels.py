@@ -340,6 +340,15 @@ def test_lstm_cell(backend, dt, M, C):
     ops.lstm_dgrad(dz, w_t.t().contiguous(), dx, dhp)
     close(dx, xr.grad, dt, 'lstm dx', mult=2.0)
     close(dhp, hr.grad, dt, 'lstm dh_prev', mult=2.0)
+    # one-launch step: the same gate backward as the EPILOGUE of an input-gradient product (dh_rec = its recurrent half)
+    dz_b, dz2, dc2, dx2 = rnd((M, 4 * C), backend, dt, 9), torch.empty_like(dz), dc_rec.clone(), torch.empty_like(dx)
+    dhr = torch.empty(M, C, dtype=dt, device=backend)
+    ops.lstm_dgrad(dz_b, w_t.t().contiguous(), dx, dhr)
+    dz1, dc1 = torch.empty_like(dz), dc_rec.clone()
+    ops.lstm_gates_bwd(dh_in, dhr, dc1, gates, c_out, c, dz1)
+    ops.lstm_dgrad_gates(dz_b, w_t.t().contiguous(), dx2, dh_in, dc2, gates, c_out, c, dz2)
+    assert torch.equal(dx2.cpu(), dx.cpu()) and torch.equal(dz2.cpu(), dz1.cpu()) and torch.equal(dc2.cpu(), dc1.cpu())
+    ops.lstm_dgrad(dz, w_t.t().contiguous(), dx, dhp)
     dw = torch.zeros(4 * C, 2 * C, device=backend)
     dbias = torch.zeros(4 * C, device=backend)
     ops.lstm_wgrad(dz, x, h, dw, dbias)
