@@ -48,7 +48,8 @@ def test_prepack(backend, dt, u8, shape):
 @pytest.mark.parametrize('dt', DTYPES)
 @pytest.mark.parametrize('M,N,K,gelu', [(200, 72, 40, False), (130, 136, 64, True), (64, 16, 16, False), (257, 264, 136, False),
                                         (2100, 520, 72, False),      # 17 x 5 tiles on the 8-workgroup test grid: XCD-grouped panel walk (gemm.hpp, mode 3)
-                                        (1600, 264, 40, False), (1000, 40, 72, True)])
+                                        (1600, 264, 40, False), (1000, 40, 72, True),
+                                        (300, 512, 136, False)])     # N a multiple of 256: the 128 x 256 tile where it is enabled
 def test_linear_fwd(backend, dt, M, N, K, gelu):
     x, w = rnd((M, K), backend, dt, 1), rnd((N, K), backend, dt, 2, 0.3)
     b = rnd((N,), backend, torch.float32, 3)
