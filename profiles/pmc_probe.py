@@ -100,6 +100,23 @@ elif op in ('stem_fwd', 'stem_wgrad'):                # the same stem on the uin
         dy = rnd(F_, 96, 160, 64)
         dw = torch.zeros(64, 49 * 24, device=dev)
         fn = lambda: ops.stem_wgrad(src, dy, dw, H, W)
+elif op in ('lstm_scan_fwd', 'lstm_scan_bwd'):         # stage-1 ConvLSTM scans: 368640 pixels x 21 steps, C = 64
+    del x, dy4
+    T_, Mp, Cc = 21, 368640, 64
+    xa = rnd(T_, Mp, Cc)
+    Hall = rnd(T_ + 1, Mp, Cc) * 0.5
+    Cs = rnd(T_, Mp, Cc)
+    cl = torch.empty(Mp, Cc, device=dev)
+    w = rnd(4 * Cc, 2 * Cc) * 0.1
+    b = torch.zeros(4 * Cc, device=dev)
+    if op == 'lstm_scan_fwd':
+        fn = lambda: ops.lstm_scan_fwd(xa, Hall, None, cl, Cs, w, b)
+    else:
+        dH, dxa = rnd(T_, Mp, Cc), torch.empty(T_, Mp, Cc, device=dev, dtype=dt)
+        dh0, dc0 = torch.empty(Mp, Cc, device=dev, dtype=dt), torch.empty(Mp, Cc, device=dev)
+        dw, db = torch.zeros(4 * Cc, 2 * Cc, device=dev), torch.zeros(4 * Cc, device=dev)
+        wt = w.t().contiguous()
+        fn = lambda: ops.lstm_scan_bwd(xa, Hall, Cs, None, dH, None, w, wt, b, dxa, None, dh0, dc0, dw=dw, db=db)
 for _ in range(3):
     fn()
 torch.cuda.synchronize()

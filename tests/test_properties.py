@@ -118,3 +118,29 @@ def test_truncated_bptt_gradients_flow_through_carried_states(dtype, tol):
         scale = whole[n].abs().max().clamp_min(1e-20)
         worst = max(worst, float((p.grad - whole[n]).abs().max() / scale))
     assert worst <= tol, worst
+
+
+def test_stem_route_equals_gemm_route_at_full_resolution():
+    """The stem kernels on the uint8 planes (csrc/stem.hpp) against the prepack + im2col-GEMM + LayerNorm route they replace, at
+    the bench resolution (interior fast paths, five 32-pixel segments per row, bottom zero padding 360 -> 384): the products
+    are the same (uint8 is exact in bf16), only the fp32 summation order differs."""
+    from rvt_amd import ops, weights
+    dt = torch.bfloat16
+    F_, Cin, (h, w), H, W = 3, 20, HW, 384, 640
+    src = _inputs(1, F_, seed=3)[0].contiguous()
+    g = torch.Generator().manual_seed(4)
+    wt = (torch.randn(64, Cin, 7, 7, generator=g) * 0.05).cuda()
+    wp = weights.pack_conv_fwd(wt, 24, dt)
+    lw, lb = (1 + 0.2 * torch.randn(64, generator=g)).cuda(), (0.2 * torch.randn(64, generator=g)).cuda()
+    assert ops.stem_supported(src, dt, 64, 7, 4, 3)
+    y0, x = ops.stem_fwd(src, wp, lw, lb, H, W, 1e-5)
+    inp = ops.prepack_input(src, H, W, 24, dt)
+    y_ref = ops.conv_fwd(inp, wp, 7, 4, 3)
+    x_ref = ops.layernorm_fwd(y_ref, lw, lb, 1e-5)
+    assert _rel(y0, y_ref) < 8e-3 and _rel(x, x_ref) < 2e-2          # one bf16 ulp of the largest value / of a normalised row
+    assert float((y0.float() - y_ref.float()).abs().mean()) < 2e-3 * float(y_ref.float().abs().mean())
+    dy = (torch.randn(y0.shape, generator=g) * 0.5).to(dt).cuda()
+    dw_a, dw_b = torch.zeros(64, 49 * 24).cuda(), torch.zeros(64, 49 * 24).cuda()
+    ops.conv_wgrad(inp, dy, dw_a, 7, 4, 3)
+    ops.stem_wgrad(src, dy, dw_b, H, W)
+    assert _rel(dw_b, dw_a) < 1e-4                                    # fp32 accumulation of identical bf16 products
