@@ -32,6 +32,17 @@ elif op == 'dgrad_k1024':   # stage-3 fc1 input gradient: dx[M][256] = dh[M][102
     M3 = 483840
     dh, wt, dx = rnd(M3, 1024), rnd(256, 1024), torch.empty(M3, 256, device=dev, dtype=dt)
     fn = lambda: ops.linear_dgrad(dh, wt, out=dx)
+elif op == 'wgrad_s3':       # stage-3 fc1 weight gradient: dW[1024][256] = dh[M][1024]^T v[M][256]
+    M3 = 483840
+    dh3, v3 = rnd(M3, 1024), rnd(M3, 256)
+    dw3, cs3 = torch.zeros(1024, 256, device=dev), torch.zeros(1024, device=dev)
+    fn = lambda: ops.linear_wgrad(dh3, v3, dw3, colsum_out=cs3)
+elif op == 'lstm_fwd_s3':    # one ConvLSTM step of stage 3: 23040 pixels, C = 256
+    Mp, Cc = 23040, 256
+    xs, hs, cs_ = rnd(Mp, Cc), rnd(Mp, Cc), torch.randn(Mp, Cc, device=dev)
+    wl, bl = rnd(4 * Cc, 2 * Cc) * 0.05, torch.zeros(4 * Cc, device=dev)
+    ho, co, go = torch.empty(Mp, Cc, device=dev, dtype=dt), torch.empty(Mp, Cc, device=dev), torch.empty(Mp, 4 * Cc, device=dev, dtype=dt)
+    fn = lambda: ops.lstm_fwd(xs, hs, cs_, wl, bl, ho, co, go)
 elif op == 'fwd_k512':      # stage-4 fc1: y[M][2048] = x[M][512] W^T
     M4 = 120960
     x4, w4, b4 = rnd(M4, 512), rnd(2048, 512), torch.zeros(2048, device=dev)
