@@ -107,6 +107,9 @@ def run_case(name: str, out_dir: str):
         c_last = states[s][1].detach().numpy().reshape(-1)
         out[f'cell{s}_last_samples'] = c_last[idx]
         out[f'cell{s}_sums'] = np.array([states[s][1].sum().item(), states[s][1].abs().sum().item()])
+        if name in casegen.FULL_TENSOR_CASES:          # whole tensors, not samples (NCHW as the reference returns them)
+            out[f'feat{s}_last_full'] = feats_all[T - 1][s + 1].detach().numpy().copy()
+            out[f'cell{s}_last_full'] = states[s][1].detach().numpy().copy()
     for k, prm in m.named_parameters():
         g = prm.grad.detach().numpy().reshape(-1).astype(np.float64)
         out[f'grad/{k}/stats'] = np.array([g.sum(), np.sqrt((g * g).sum())])

@@ -38,36 +38,6 @@
 
 namespace rvt {
 
-// exchange between the two 32-lane halves of a wave: afterwards lanes 0-31 hold (own a, partner's a) and lanes 32-63
-// hold (partner's b, own b)   [v_permlane32_swap_b32: vdst.lanes[32..63] <-> src0.lanes[0..31]]
-__device__ __forceinline__ void swap32(float& a, float& b) {
-#ifdef RVT_EMU
-    float ab[2] = {a, b};
-    auto buf = emu::exchange(ab, sizeof(ab));
-    const int lane = emu::g.cur->lane;
-    const float* p = reinterpret_cast<const float*>(buf[lane ^ 32]);
-    if (lane < 32) b = p[0]; else a = p[1];
-#else
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    a = __uint_as_float(r[0]);
-    b = __uint_as_float(r[1]);
-#endif
-}
-
-// accumulator block (col = token = lane & 31, rows = 32 features) -> two 8-feature row pieces of this lane's token:
-// o[m][e] = feature 16 m + 8 (lane >> 5) + e — exactly the (k-step m, half) operand piece the rows were loaded in
-__device__ __forceinline__ void acc_to_rows(const f32x16& c, float (&o)[2][8]) {
-#pragma unroll
-    for (int m = 0; m < 2; m++)
-#pragma unroll
-        for (int w = 0; w < 4; w++) {
-            float a = c[8 * m + w], b = c[8 * m + 4 + w];
-            swap32(a, b);
-            o[m][w] = a;
-            o[m][4 + w] = b;
-        }
-}
-
 // per-row (= per accumulator register) additive constants of a T-form block: p points at the 32 values of the block
 __device__ __forceinline__ void acc_add_rows(f32x16& c, const float* p, int half) {
 #pragma unroll

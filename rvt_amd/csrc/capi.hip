@@ -7,6 +7,7 @@
 
 #include "common.hpp"
 #include "gemm.hpp"
+#include "ppgemm.hpp"
 #include "rowops.hpp"
 #include "attn.hpp"
 #include "attn_block.hpp"
@@ -114,6 +115,20 @@ static void launch_wgrad(const ASrc& a, const BSrc& b, const BXf& bxf, float* ou
         if (wgrad_bn(N) == 64) { constexpr int BN = 64; __VA_ARGS__; } \
         else { constexpr int BN = 128; __VA_ARGS__; }                \
     } while (0)
+
+// Route of a bf16 "row, k" x "row, k" product: the 256 x 256 LDS-DMA ping-pong kernel (ppgemm.hpp) where its tile shape
+// divides the problem and there are enough rows to fill it, else the 128-row register-staged engine (gemm.hpp).
+// RVT_PPGEMM=0 disables (A/B measurements); RVT_PPGEMM_MIN_M lowers the row threshold (tests).
+// contraction length from which an epilogue flavour goes to ppgemm (RVT_PPGEMM_ALL=1: always - the parity tests)
+static inline int pp_min_k(int k) {
+    static const int all = getenv("RVT_PPGEMM_ALL") ? atoi(getenv("RVT_PPGEMM_ALL")) : 0;
+    return all ? 0 : k;
+}
+static inline bool use_ppgemm(int dtype, int M, int N, int K, int ldx, int ldw, int kcut) {
+    static const int enabled = getenv("RVT_PPGEMM") ? atoi(getenv("RVT_PPGEMM")) : 1;
+    static const int min_m = getenv("RVT_PPGEMM_MIN_M") ? atoi(getenv("RVT_PPGEMM_MIN_M")) : 4096;
+    return enabled && dtype == RVT_BF16 && M >= min_m && ppgemm_shape_ok(M, N, K, ldx, ldw, kcut);
+}
 
 extern "C" {
 
@@ -362,6 +377,11 @@ int rvt_linear_fwd(const void* x, const void* w, const float* bias, void* y, int
                    void* stream) {
     RVT_CHECK(N % 8 == 0 && K % 8 == 0, "linear_fwd: N=%d K=%d must be multiples of 8", N, K);
     hipStream_t st = (hipStream_t)stream;
+    if (!gelu_in && use_ppgemm(dtype, M, N, K, K, K, K)) {
+        launch_ppgemm<PP_STORE>(PPMat{(const bf16*)x, (const bf16*)x, K, K}, PPMat{(const bf16*)w, (const bf16*)w, K, K},
+                                PPEpArgs{(bf16*)y, nullptr, nullptr, bias, nullptr, N}, M, N, K, st);
+        return check_launch("linear_fwd");
+    }
     DISPATCH_DTYPE(dtype, {
         PlainSrc<T> a{(const T*)x, K, M, K};
         PlainSrc<T> b{(const T*)w, K, N, K};
@@ -378,6 +398,11 @@ int rvt_linear_gelu_fwd(const void* x, const void* w, const float* bias, void* g
                         void* stream) {
     RVT_CHECK(N % 8 == 0 && K % 8 == 0 && bias, "linear_gelu_fwd: N=%d K=%d must be multiples of 8, bias required", N, K);
     hipStream_t st = (hipStream_t)stream;
+    if (K >= pp_min_k(512) && use_ppgemm(dtype, M, N, K, K, K, K)) {        // (measured: 0.51 vs 0.58 ms at K = 512, 0.87 vs 0.76 at K = 256)
+        launch_ppgemm<PP_GELU_DUAL>(PPMat{(const bf16*)x, (const bf16*)x, K, K}, PPMat{(const bf16*)w, (const bf16*)w, K, K},
+                                    PPEpArgs{(bf16*)g, (bf16*)gp, nullptr, bias, nullptr, N}, M, N, K, st);
+        return check_launch("linear_gelu_fwd");
+    }
     DISPATCH_DTYPE(dtype, {
         PlainSrc<T> a{(const T*)x, K, M, K};
         PlainSrc<T> b{(const T*)w, K, N, K};
@@ -392,6 +417,11 @@ int rvt_linear_scale_res_fwd(const void* x, const void* w, const float* bias, co
     RVT_CHECK(N % 8 == 0 && K % 8 == 0, "linear_scale_res_fwd: N=%d K=%d must be multiples of 8", N, K);
     RVT_CHECK(bias && gamma && res, "linear_scale_res_fwd: bias, gamma and res are required");
     hipStream_t st = (hipStream_t)stream;
+    if (!gelu_in && N <= PPGeom::MAX_CST / 2 && K >= pp_min_k(1024) && use_ppgemm(dtype, M, N, K, K, K, K)) {
+        launch_ppgemm<PP_SCALE_RES>(PPMat{(const bf16*)x, (const bf16*)x, K, K}, PPMat{(const bf16*)w, (const bf16*)w, K, K},
+                                    PPEpArgs{(bf16*)y, nullptr, (const bf16*)res, bias, gamma, N}, M, N, K, st);
+        return check_launch("linear_scale_res_fwd");
+    }
     DISPATCH_DTYPE(dtype, {
         PlainSrc<T> a{(const T*)x, K, M, K};
         PlainSrc<T> b{(const T*)w, K, N, K};
@@ -410,6 +440,15 @@ int rvt_linear_dgrad(const void* dy, const void* wt, const void* gelu_pre, const
     RVT_CHECK((gelu_pre != nullptr) + (add != nullptr) + (mul != nullptr) <= 1,
               "linear_dgrad: gelu_pre, add and mul are mutually exclusive");
     hipStream_t st = (hipStream_t)stream;
+    // dx[M][K] = dy[M][N] . wt[K][N]^T: output width K, contraction N.  With a side input (add / mul) the epilogue's late loads
+    // drain the load stream once per flushed block: only worth it for long contractions (measured: N >= 1024)
+    if (!gelu_pre && (!(add || mul) || N >= pp_min_k(1024)) && use_ppgemm(dtype, M, K, N, N, N, N)) {
+        const PPMat xs{(const bf16*)dy, (const bf16*)dy, N, N}, ws{(const bf16*)wt, (const bf16*)wt, N, N};
+        if (mul) launch_ppgemm<PP_MUL>(xs, ws, PPEpArgs{(bf16*)dx, nullptr, (const bf16*)mul, nullptr, nullptr, K}, M, K, N, st);
+        else if (add) launch_ppgemm<PP_ADD>(xs, ws, PPEpArgs{(bf16*)dx, nullptr, (const bf16*)add, nullptr, nullptr, K}, M, K, N, st);
+        else launch_ppgemm<PP_STORE>(xs, ws, PPEpArgs{(bf16*)dx, nullptr, nullptr, nullptr, nullptr, K}, M, K, N, st);
+        return check_launch("linear_dgrad");
+    }
     DISPATCH_DTYPE(dtype, {
         PlainSrc<T> a{(const T*)dy, N, M, N};
         PlainSrc<T> b{(const T*)wt, N, K, N};

@@ -66,6 +66,11 @@ __device__ __forceinline__ void mma32(f32x16& c, const f32x8& a, const f32x8& b)
 #pragma unroll
     for (int j = 0; j < 8; j++) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], c, 0, 0, 0);
 }
+// first product of an accumulation: C operand = 0 (an inline constant of the instruction: no zero fill of the accumulators)
+__device__ __forceinline__ void mma32_zero(f32x16& c, const bf16x8& a, const bf16x8& b) {
+    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, z, 0, 0, 0);
+}
 #else
 template <class F> inline void mma32_emu(f32x16& c, const F& a, const F& b) {
     float ab[16];
@@ -85,6 +90,7 @@ template <class F> inline void mma32_emu(f32x16& c, const F& a, const F& b) {
 }
 inline void mma32(f32x16& c, const bf16x8& a, const bf16x8& b) { mma32_emu(c, a, b); }
 inline void mma32(f32x16& c, const f32x8& a, const f32x8& b) { mma32_emu(c, a, b); }
+inline void mma32_zero(f32x16& c, const bf16x8& a, const bf16x8& b) { for (int i = 0; i < 16; i++) c[i] = 0.f; mma32_emu(c, a, b); }
 #endif
 
 __device__ __forceinline__ void acc_zero(f32x16& c) {
@@ -272,6 +278,36 @@ __device__ __forceinline__ float row16_sum(float v) {
 #undef RVT_DPP_ROR
     return v;
 #endif
+}
+
+// exchange between the two 32-lane halves of a wave: afterwards lanes 0-31 hold (own a, partner's a) and lanes 32-63
+// hold (partner's b, own b)   [v_permlane32_swap_b32: vdst.lanes[32..63] <-> src0.lanes[0..31]]
+__device__ __forceinline__ void swap32(float& a, float& b) {
+#ifdef RVT_EMU
+    float ab[2] = {a, b};
+    auto buf = emu::exchange(ab, sizeof(ab));
+    const int lane = emu::g.cur->lane;
+    const float* p = reinterpret_cast<const float*>(buf[lane ^ 32]);
+    if (lane < 32) b = p[0]; else a = p[1];
+#else
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+#endif
+}
+
+// accumulator block (col = token = lane & 31, rows = 32 features) -> two 8-feature row pieces of this lane's token:
+// o[m][e] = feature 16 m + 8 (lane >> 5) + e — exactly the (k-step m, half) operand piece the rows were loaded in
+__device__ __forceinline__ void acc_to_rows(const f32x16& c, float (&o)[2][8]) {
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            float a = c[8 * m + w], b = c[8 * m + 4 + w];
+            swap32(a, b);
+            o[m][w] = a;
+            o[m][4 + w] = b;
+        }
 }
 
 // keep the instruction scheduler from moving anything across this point (used to pin prefetch loads early)

@@ -44,7 +44,21 @@ CASES: Dict[str, dict] = {
     # RVT-Base on the 1Mpx shape, reduced B*T so that the CPU oracle finishes in seconds
     'base_1mpx': dict(embed_dim=64, dim_head=32, partition_size=(6, 10), hw=(360, 640), in_res=(384, 640),
                       T=2, B=1, gamma='rand'),
+    # ---- round 3: the depth every BASELINE GPU config runs at (T = 21, config/experiment/gen1/default.yaml:37) ----
+    # BASELINE configs[2] per sample: RVT-Base, 1Mpx, the full 21-step recurrence (B = 1 so that the CPU reference needs seconds)
+    'base_1mpx_t21': dict(embed_dim=64, dim_head=32, partition_size=(6, 10), hw=(360, 640), in_res=(384, 640),
+                          T=21, B=1, gamma='rand'),
+    # BASELINE configs[1] at reduced batch: RVT-Tiny, Gen1, T = 21
+    'tiny_gen1_t21': dict(embed_dim=32, dim_head=32, partition_size=(8, 10), hw=(240, 304), in_res=(256, 320),
+                          T=21, B=2, gamma='rand'),
+    # RVT-Base on Gen1 (config/experiment/gen1/base.yaml): C = 64 with the 8 x 10 = 80-token partitions (three 32-token blocks
+    # per partition in the fused attention-half kernels)
+    'base_gen1': dict(embed_dim=64, dim_head=32, partition_size=(8, 10), hw=(240, 304), in_res=(256, 320),
+                      T=2, B=2, gamma='rand'),
 }
+
+# cases whose fixtures additionally hold WHOLE tensors (last-step features and final cell states of every stage), not samples
+FULL_TENSOR_CASES = ('micro', 'base_qvga')
 
 CFG_DEFAULTS = dict(input_channels=20, dim_multiplier=(1, 2, 4, 8), num_blocks=(1, 1, 1, 1), patch_size=4,
                     overlap=True, norm_eps=1e-5, dws_conv=False, dws_conv_only_hidden=True,

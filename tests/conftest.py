@@ -15,6 +15,11 @@ os.environ.setdefault('RVT_LSTM_SCAN', '1')
 # stem kernels (one workgroup per CU in production): a 3-workgroup grid, so that test sizes walk several items / tiles per
 # workgroup (the double-buffered LDS image of the weight gradient, the persistent item loop of the forward)
 os.environ.setdefault('RVT_STEM_GRID', '3')
+# 256 x 256 LDS-DMA GEMM (csrc/ppgemm.hpp; production: >= 4096 rows, one workgroup per CU): test-size row counts, and an
+# 8-workgroup grid so that a workgroup walks several output tiles (load stream / accumulator flush across tile boundaries)
+os.environ.setdefault('RVT_PPGEMM_MIN_M', '256')
+os.environ.setdefault('RVT_PPGEMM_GRID', '8')
+os.environ.setdefault('RVT_PPGEMM_ALL', '1')            # every epilogue flavour through it, whatever the contraction length
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

@@ -37,6 +37,9 @@ def summarize(name: str, feats_all: List[Dict[int, torch.Tensor]], states, grads
             c_last = states[s][1].detach().float().cpu().contiguous().numpy().reshape(-1)
             out[f'cell{s}_last_samples'] = c_last[idx]
             out[f'cell{s}_sums'] = np.array([float(states[s][1].detach().double().sum()), float(states[s][1].detach().double().abs().sum())])
+            if name in casegen.FULL_TENSOR_CASES:      # compared element for element over the whole tensor
+                out[f'feat{s}_last_full'] = feats_all[T - 1][s + 1].detach().float().cpu().contiguous().numpy()
+                out[f'cell{s}_last_full'] = states[s][1].detach().float().cpu().contiguous().numpy()
     if grads is not None:
         for k, g in grads.items():
             g = g.detach().double().cpu().contiguous().numpy().reshape(-1)

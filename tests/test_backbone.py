@@ -114,10 +114,21 @@ def test_backbone_fp32_vs_reference_golden_gpu(name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('name', ['micro', 'tiny_gen1_gamma', 'base_qvga', 'base_1mpx'])
+@pytest.mark.parametrize('name', ['micro', 'tiny_gen1_gamma', 'base_qvga', 'base_1mpx', 'base_gen1'])
 def test_backbone_bf16_vs_reference_golden_gpu(name):
     """bf16 performance mode against the fp32 reference: stated looser bound (bf16 has 8 mantissa bits;
     errors accumulate through 4 stages x T recurrent steps): 3e-2 of the tensor scale on features, 5e-2 on gradients
     (round 2, tightened from 4e-2 / 8e-2: the worst measured ratios on MI355X are 0.86 of 2.5e-2 / 4e-2, profiles/r2/bf16_worst.txt)."""
     got = run_hip_case(name, torch.device('cuda', 0), torch.bfloat16, with_batch2=False)
     compare(got, load_golden(name), rtol=3e-2, what=f'hip bf16 vs reference [{name}]', grad_rtol=5e-2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['base_1mpx_t21', 'tiny_gen1_t21'])
+def test_backbone_bf16_vs_reference_golden_t21_gpu(name):
+    """bf16 against the fp32 REFERENCE over the full recurrent depth of the BASELINE GPU configs (T = 21).  Bound: 4e-2 of the
+    tensor scale on features / final cell states (the per-step drift of bf16 storage against fp32 saturates at ~2.1e-2 after a
+    few steps, tests/test_drift.py; the reference comparison adds the fp32 path's own ~1e-5), 5e-2 on gradient norms / samples."""
+    got = run_hip_case(name, torch.device('cuda', 0), torch.bfloat16, with_batch2=False)
+    worst = compare(got, load_golden(name), rtol=4e-2, what=f'hip bf16 vs reference [{name}]', grad_rtol=5e-2)
+    print(f'{name}: worst err/tol = {worst:.3e}')

@@ -62,6 +62,36 @@ def test_linear_fwd(backend, dt, M, N, K, gelu):
     close(y, xa @ f64(w).t() + f64(b), dt, 'linear_fwd')
 
 
+PP_CASES = [(256, 256, 64), (700, 512, 192), (2500, 256, 128), (1300, 768, 256)]
+
+
+@pytest.mark.parametrize('M,N,K', PP_CASES)
+def test_ppgemm_routes(backend, M, N, K):
+    """The 256 x 256 LDS-DMA GEMM (csrc/ppgemm.hpp) behind the linear entry points (bf16, N % 256 == 0, K % 64 == 0): every
+    epilogue it is wired to, ragged last row panel, several tiles per workgroup, against fp64."""
+    dt = torch.bfloat16
+    x, w = rnd((M, K), backend, dt, 1), rnd((N, K), backend, dt, 2, 0.3)
+    b, gam = rnd((N,), backend, torch.float32, 3), rnd((N,), backend, torch.float32, 4)
+    res = rnd((M, N), backend, dt, 5)
+    ref = f64(x) @ f64(w).t()
+    close(ops.linear_fwd(x, w, b), ref + f64(b), dt, 'ppgemm linear_fwd')
+    close(ops.linear_fwd(x, w, None), ref, dt, 'ppgemm linear_fwd (no bias)')
+    close(ops.linear_scale_res_fwd(x, w, b, gam, res), f64(res) + f64(gam) * (ref + f64(b)), dt, 'ppgemm linear_scale_res_fwd')
+    g, gp = ops.linear_gelu_fwd(x, w, b, want_grad=True)
+    pre = (ref + f64(b)).requires_grad_(True)
+    gr = F.gelu(pre)
+    gr.sum().backward()
+    close(g, gr, dt, 'ppgemm linear_gelu_fwd g')
+    close(gp, pre.grad, dt, 'ppgemm linear_gelu_fwd gp')
+    # input gradients: dx[M][N] = dy[M][K'] . wt[N][K']^T  (the entry point's (N, K) are this product's (K', N))
+    close(ops.linear_dgrad(x, w), ref, dt, 'ppgemm linear_dgrad')
+    close(ops.linear_dgrad(x, w, add=res), ref + f64(res), dt, 'ppgemm linear_dgrad + add')
+    close(ops.linear_dgrad(x, w, mul=res), ref * f64(res), dt, 'ppgemm linear_dgrad * mul')
+    p = f64(res).requires_grad_(True)
+    F.gelu(p).sum().backward()
+    close(ops.linear_dgrad(x, w, res), ref * p.grad, dt, "ppgemm linear_dgrad * gelu'")
+
+
 @pytest.mark.parametrize('dt', DTYPES)
 def test_linear_gelu_and_mul(backend, dt):
     M, N, K = 150, 136, 40
