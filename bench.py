@@ -134,6 +134,7 @@ def build_model(wl, dtype, device):
     torch.manual_seed(0)
     cfg = backbone_config(wl['size'], wl['dataset'])
     m = RNNDetector(cfg, compute_dtype=dtype).to(device)
+    m.zero_copy_grads = True      # .grad = persistent views of the stage buckets (stable addresses: fused optimizer, hipGraph, RCCL in place)
     return m
 
 
@@ -381,7 +382,7 @@ def main():
         # the same K steps replayed as ONE captured hipGraph per step (no Python, no per-kernel launch cost)
         from rvt_amd.graph import GraphedStep
         try:
-            gstep = GraphedStep(step, warmup=1, device=device)
+            gstep = GraphedStep(step, warmup=1, device=device, models=(model,))
             for _ in range(2):
                 gstep()
             wall, host_enqueue, per_step = timed_region(gstep)

@@ -62,11 +62,6 @@ int rvt_stem_fwd(const void* src, const void* w, const float* ln_w, const float*
                  int Cin, int cp, int h, int wd, int H, int W, float eps, void* stream);
 /* dw[64][7*7*cp] (float32, the layout of rvt_conv_wgrad) += dy^T im2col(src); ws: rvt_stem_wgrad_ws_floats floats. */
 size_t rvt_stem_wgrad_ws_floats(int Cin, int F, int H, int W);
-/* ... with the LayerNorm backward (maxvit.py:177) folded in: dx = gradient at x = LayerNorm(y0); dw as above,
- * dln_w[64] += sum dx xhat, dln_b[64] += sum dx; the gradient at y0 itself is never written (replaces
- * rvt_layernorm_bwd + rvt_conv_wgrad of the first stage, whose input needs no gradient). */
-int rvt_stem_wgrad_ln(const void* src, const void* dx, const void* y0, const float* ln_w, float* dw, float* dln_w, float* dln_b,
-                      float* ws, int dtype, int F, int Cin, int cp, int h, int wd, int H, int W, float eps, void* stream);
 int rvt_stem_wgrad(const void* src, const void* dy, float* dw, float* ws, int dtype, int F, int Cin, int cp, int h, int wd,
                    int H, int W, void* stream);
 
@@ -96,8 +91,6 @@ int rvt_linear_dgrad(const void* dy, const void* wt, const void* gelu_pre, const
  * (the bias gradient), computed from the tiles the kernel streams anyway. */
 int rvt_linear_wgrad(const void* dy, const void* x, float* dw, float* dy_colsum, float* ws, int dtype, int M, int N,
                      int K, int gelu_in, void* stream);
-/* out[N] (float32) += column sums of x[rows][N]. */
-int rvt_colsum(const void* x, float* out, int dtype, int rows, int N, void* stream);
 
 /* Fused MLP half of a block (maxvit.py:269 + :100-118), built for the HBM-bound stages:
  * rvt_mlp_fused_supported(dtype, C) != 0  (bf16: C in {64,128}; f32: C == 64).
@@ -123,9 +116,6 @@ int rvt_mlp_bwd_dgrad(const void* dxout, const void* gp, const void* xmid, void*
  * [4C][C]; w1_t = W1^T [C][4C].  ws: rvt_mlp_bwd_fused_ws_floats(dtype, C, M) floats (per-workgroup partials). */
 int rvt_mlp_bwd_fused_supported(int dtype, int C);
 size_t rvt_mlp_bwd_fused_ws_floats(int dtype, int C, int M);
-int rvt_mlp_bwd_fused(const void* dxout, const void* xmid, void* dxmid, const float* ln_w, const float* ln_b, const void* w1,
-                      const float* b1, const void* w2g_t, const void* w1_t, float* dln_w, float* dln_b, float* dw1, float* db1,
-                      float* s2, float* cs2, float* ws, int dtype, int M, int C, float eps, void* stream);
 /* The same kernel cut in two along the critical path of backward (both recompute LN2 / fc1 / GELU from xmid):
  *   rvt_mlp_bwd_recompute_dgrad: dxmid and dln_w / dln_b only — no weight-gradient accumulators, several workgroups per CU;
  *   rvt_mlp_bwd_recompute_wgrad: dw1, db1, s2, cs2 only (two groups of hidden chunks per tile column, 64 accumulator
@@ -174,11 +164,6 @@ int rvt_lstm_gates_bwd(const void* dh_in, const void* dh_rec, float* dc_rec, con
                        const float* c_prev, void* dz, int dtype, int M, int C, void* stream);
 /* [dx | dh_rec] = dz W : wt = W^T [2C][4C] natural gate order. */
 int rvt_lstm_dgrad(const void* dz, const void* wt, void* dx, void* dh_rec, int dtype, int M, int C, void* stream);
-/* One BPTT step in one launch: dx_t = (dz_t W)[:, :C]; the recurrent half (dz_t W)[:, C:] is consumed in the epilogue by the
- * gate backward of step t-1 (the arithmetic of rvt_lstm_gates_bwd with dh_rec = that half, rounded to dtype): reads
- * dh_in_prev [M][C], gates_prev [M][4C], c_new_prev / c_prev_prev [M][C] fp32, updates dc_rec in place, writes dz_prev. */
-int rvt_lstm_dgrad_gates(const void* dz, const void* wt, void* dx, const void* dh_in_prev, float* dc_rec, const void* gates_prev,
-                         const float* c_new_prev, const float* c_prev_prev, void* dz_prev, int dtype, int M, int C, void* stream);
 /* dw[4C][2C] (float32) += dz^T [x | h_prev];  dz_colsum[4C] += column sums of dz if non-NULL (bias gradient). */
 int rvt_lstm_wgrad(const void* dz, const void* x, const void* h_prev, float* dw, float* dz_colsum, float* ws, int dtype,
                    int M, int C, void* stream);

@@ -35,5 +35,3 @@ t_d = timeit(lambda: ops.mlp_bwd_recompute_dgrad(dy, x, lw, lb, w1, b1, w2gt, w1
 t_w = timeit(lambda: ops.mlp_bwd_recompute_wgrad(dy, x, lw, lb, w1, b1, w2gt, dw1, db1, s2, cs2, 1e-5))
 print(f'RVT_MLP_CHAIN={os.environ.get("RVT_MLP_CHAIN", "1")} C={C} M={M}: fwd (nothing saved) {t_f:.3f} ms | bwd dgrad {t_d:.3f} ms | '
       f'bwd wgrad {t_w:.3f} ms', flush=True)
-t_all = timeit(lambda: ops.mlp_bwd_fused(dy, x, lw, lb, w1, b1, w2gt, w1t, dlw, dlb, dw1, db1, s2, cs2, 1e-5))
-print(f'   everything-in-one-kernel backward (rvt_mlp_bwd_fused, LDS-staged, one workgroup per CU): {t_all:.3f} ms', flush=True)

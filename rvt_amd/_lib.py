@@ -30,7 +30,6 @@ _SIGS = {
     'rvt_conv_wgrad': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     'rvt_stem_fwd': [_vp] * 6 + [_i] * 8 + [_f, _vp],
     'rvt_stem_wgrad': [_vp] * 4 + [_i] * 8 + [_vp],
-    'rvt_stem_wgrad_ln': [_vp] * 8 + [_i] * 8 + [_f, _vp],
     'rvt_layernorm_fwd': [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
     'rvt_layernorm_bwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
     'rvt_linear_fwd': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
@@ -38,7 +37,6 @@ _SIGS = {
     'rvt_linear_dgrad': [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     'rvt_linear_gelu_fwd': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     'rvt_linear_wgrad': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
-    'rvt_colsum': [_vp, _vp, _i, _i, _i, _vp],
     'rvt_mlp_fwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
     'rvt_mlp_bwd_dgrad': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
     'rvt_attn_fwd': [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
@@ -48,7 +46,6 @@ _SIGS = {
     'rvt_lstm_fwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     'rvt_lstm_gates_bwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     'rvt_lstm_dgrad': [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
-    'rvt_lstm_dgrad_gates': [_vp] * 9 + [_i, _i, _i, _vp],
     'rvt_lstm_wgrad': [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     'rvt_dwconv_fwd': [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     'rvt_dwconv_wgrad': [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
@@ -59,7 +56,6 @@ _SIGS = {
     'rvt_pack_table': [_vp, _i, _i, _i, _vp],
     'rvt_mlp_bwd_recompute_dgrad': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
     'rvt_mlp_bwd_recompute_wgrad': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
-    'rvt_mlp_bwd_fused': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
     'rvt_lstm_scan_fwd': [_vp] * 8 + [_i, _i, _i, _i, _vp],
     'rvt_lstm_scan_bwd': [_vp] * 17 + [_i, _i, _i, _i, _vp],
     'rvt_layerscale_grad_table': [_vp, _i, _i, _vp],

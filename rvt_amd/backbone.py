@@ -15,6 +15,8 @@ parameter containers only and are never called.
 """
 from __future__ import annotations
 
+import weakref
+
 from typing import Dict, List, Optional, Sequence, Tuple, Union
 
 import torch
@@ -292,7 +294,8 @@ class _BackboneSeqFn(torch.autograd.Function):
         ctx.mod, ctx.geoms, ctx.mw, ctx.svs, ctx.p = mod, geoms, mw, svs, p
         ctx.T, ctx.B = T, B
         ctx.set_materialize_grads(False)
-        mod._last_saved = svs if need_grad else None      # (tests: a no_grad forward keeps nothing)
+        # (test hook: weak reference only - a forward whose backward never runs must not pin its activations on the module)
+        mod._last_saved = weakref.ref(svs[0]) if need_grad and svs and svs[0] is not None else None
         return tuple(outs)
 
     @staticmethod
@@ -339,7 +342,7 @@ class _BackboneSeqFn(torch.autograd.Function):
                                                 finalize=lambda si=si: mw.finalize_stage_grads(si))
             d_from_above = d_in
             if hook is not None:          # e.g. rvt_amd.dist.StageGradReducer: start this stage's all-reduce now
-                hook(si, mw.grads[si].param_region)
+                hook(si, mw.grads[si].param_region, accumulated=accumulate[si])
             if ctx.needs_input_grad[4 + 2 * si]:
                 state_grads[2 * si] = dh0.permute(0, 3, 1, 2)
                 state_grads[2 * si + 1] = dc0.permute(0, 3, 1, 2)
@@ -347,10 +350,13 @@ class _BackboneSeqFn(torch.autograd.Function):
         finish = getattr(mod, '_stage_grad_finish', None)
         if finish is not None:            # data parallel: order everything downstream after the per-stage all-reduces
             finish()
-        # Hand-off.  Default: the parameter's .grad BECOMES the bucket view (no copy, stable addresses — what a captured
-        # hipGraph and the fused optimizer want); a foreign .grad tensor gets the bucket added into it.  With
-        # mod.grads_through_autograd = True the views are returned to autograd instead (AccumulateGrad may clone).
-        through = getattr(mod, 'grads_through_autograd', False)
+        # Hand-off.  Default: the gradients go back through autograd as COPIES of the bucket views, so every autograd contract
+        # holds (torch.autograd.grad returns them, a p.grad kept across steps is never overwritten, AccumulateGrad may steal the
+        # tensor).  One pass over 51 MB of fp32 at RVT-Base: ~0.03 ms.  With mod.zero_copy_grads = True (bench.py, GraphedStep:
+        # stable addresses for a captured hipGraph and the fused optimizer) the parameter's .grad BECOMES the persistent bucket
+        # view instead and None is returned to autograd: then the next backward rewrites that memory, and
+        # torch.autograd.grad(...) sees no gradient for the backbone parameters.
+        zero_copy = getattr(mod, 'zero_copy_grads', False)
         pgrads = []
         for i, n in enumerate(mod._param_names):
             if not ctx.needs_input_grad[4 + 2 * ns + i]:
@@ -360,8 +366,8 @@ class _BackboneSeqFn(torch.autograd.Function):
             view = mw.grads[si].g(n)
             if view.dtype != p[n].dtype:
                 view = view.to(p[n].dtype)
-            if through:
-                pgrads.append(view)
+            if not zero_copy:
+                pgrads.append(view.clone())
                 continue
             pgrads.append(None)
             if p[n].grad is None:

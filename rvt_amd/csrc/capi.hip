@@ -278,11 +278,7 @@ static int stem_wgrad_launch(const void* src, const void* dy, const void* y0, co
     g.per_wg = (g.n_tiles + grid - 1) / grid;
     g.dXS = FastDiv(g.XS); g.dHo = FastDiv(g.Ho); g.d7 = FastDiv(STEM_K);
     hipStream_t st = (hipStream_t)stream;
-    if (y0 != nullptr)
-        hipLaunchKernelGGL(stem_wgrad_kernel<true>, dim3(grid), dim3(512), 0, st, (const uint8_t*)src, (const bf16*)dy, (const bf16*)y0, ln_w,
-                           dln_w, dln_b, ws, g, eps);
-    else
-        hipLaunchKernelGGL(stem_wgrad_kernel<false>, dim3(grid), dim3(512), 0, st, (const uint8_t*)src, (const bf16*)dy, (const bf16*)nullptr,
+    hipLaunchKernelGGL(stem_wgrad_kernel<false>, dim3(grid), dim3(512), 0, st, (const uint8_t*)src, (const bf16*)dy, (const bf16*)nullptr,
                            (const float*)nullptr, (float*)nullptr, (float*)nullptr, ws, g, 0.f);
     const int total = STEM_CO * STEM_K * STEM_K * Cin;
     hipLaunchKernelGGL(stem_wgrad_fold_kernel, dim3((total + 255) / 256), dim3(256), 0, st, (const float*)ws, dw, grid, Cin, cp, g.NJB);
@@ -292,12 +288,6 @@ static int stem_wgrad_launch(const void* src, const void* dy, const void* y0, co
 int rvt_stem_wgrad(const void* src, const void* dy, float* dw, float* ws, int dtype, int F, int Cin, int cp, int h, int wd,
                    int H, int W, void* stream) {
     return stem_wgrad_launch(src, dy, nullptr, nullptr, nullptr, nullptr, dw, ws, dtype, F, Cin, cp, h, wd, H, W, 0.f, stream);
-}
-
-int rvt_stem_wgrad_ln(const void* src, const void* dx, const void* y0, const float* ln_w, float* dw, float* dln_w, float* dln_b,
-                      float* ws, int dtype, int F, int Cin, int cp, int h, int wd, int H, int W, float eps, void* stream) {
-    RVT_CHECK(y0 != nullptr && ln_w != nullptr && dln_w != nullptr && dln_b != nullptr, "stem_wgrad_ln: null argument");
-    return stem_wgrad_launch(src, dx, y0, ln_w, dln_w, dln_b, dw, ws, dtype, F, Cin, cp, h, wd, H, W, eps, stream);
 }
 
 int rvt_conv_dgrad(const void* dy, const void* wd, const void* add, void* din, int dtype, int F, int H, int W, int Cin,
@@ -357,19 +347,6 @@ int rvt_layernorm_bwd(const void* x, const float* w, const void* dy, const void*
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ln_bwd_kernel<T>), dim3(grid), dim3(256), 0, st, (const T*)x, w,
                                              (const T*)dy, (const T*)dres, (T*)dx, dw, db, rows, C, G, eps));
     return check_launch("layernorm_bwd");
-}
-
-int rvt_colsum(const void* x, float* out, int dtype, int rows, int N, void* stream) {
-    RVT_CHECK(N % 8 == 0, "colsum: N=%d must be a multiple of 8", N);
-    hipStream_t st = (hipStream_t)stream;
-    int NC = N / 8;
-    int NCP = imin(256, pow2_ge(NC));
-    int gy = (NC + NCP - 1) / NCP;
-    int nrl = 256 / NCP;
-    int gx = imin(1024, imax(1, (rows + nrl * 8 - 1) / (nrl * 8)));
-    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((colsum_kernel<T>), dim3(gx, gy), dim3(256), 0, st, (const T*)x, out, rows,
-                                             N, NCP));
-    return check_launch("colsum");
 }
 
 // -------------------------------------------------------------------------------------------- linear
@@ -614,27 +591,9 @@ static void mlp_fold_partials(const float* ws, int grid, int C, float* dw1, floa
 extern "C" {
 size_t rvt_mlp_bwd_fused_ws_floats(int dtype, int C, int M) {
     if (!rvt_mlp_bwd_fused_supported(dtype, C)) return 0;
-    size_t grid = dtype == RVT_BF16 ? mlp_bwd_fused_grid<bf16, 0>(M) : mlp_bwd_fused_grid<float, 0>(M);
-    const size_t g2 = dtype == RVT_BF16 ? mlp_bwd_fused_grid<bf16, 2>(M) : mlp_bwd_fused_grid<float, 2>(M);
-    if (g2 > grid) grid = g2;
+    size_t grid = dtype == RVT_BF16 ? mlp_bwd_fused_grid<bf16, 2>(M) : mlp_bwd_fused_grid<float, 2>(M);
     if (grid < 256) grid = 256;                          // mlpc_bwd_wgrad_kernel: one workgroup per CU
     return grid * ((size_t)2 * 4 * C * C + 2 * 4 * C + C);
-}
-
-int rvt_mlp_bwd_fused(const void* dxout, const void* xmid, void* dxmid, const float* ln_w, const float* ln_b, const void* w1,
-                      const float* b1, const void* w2g_t, const void* w1_t, float* dln_w, float* dln_b, float* dw1, float* db1,
-                      float* s2, float* cs2, float* ws, int dtype, int M, int C, float eps, void* stream) {
-    RVT_CHECK(rvt_mlp_bwd_fused_supported(dtype, C), "mlp_bwd_fused: not built for dtype=%d C=%d", dtype, C);
-    RVT_CHECK(ws != nullptr && M >= 1, "mlp_bwd_fused: workspace required");
-    hipStream_t st = (hipStream_t)stream;
-    int grid = 0;
-    DISPATCH_DTYPE(dtype, {
-        grid = mlp_bwd_fused_grid<T, 0>(M);
-        hipLaunchKernelGGL((mlp_bwd_fused_kernel<T, 64, 0>), dim3(grid), dim3(256), 0, st, (const T*)dxout, (const T*)xmid, (T*)dxmid,
-                           ln_w, ln_b, (const T*)w1, b1, (const T*)w2g_t, (const T*)w1_t, dln_w, dln_b, ws, M, eps);
-    });
-    mlp_fold_partials(ws, grid, C, dw1, db1, s2, cs2, st);
-    return check_launch("mlp_bwd_fused");
 }
 
 int rvt_mlp_bwd_recompute_dgrad(const void* dxout, const void* xmid, void* dxmid, const float* ln_w, const float* ln_b,
@@ -856,19 +815,6 @@ int rvt_lstm_dgrad(const void* dz, const void* wt, void* dx, void* dh_rec, int d
         DISPATCH_BN(2 * C, (launch_gemm<T, BN, false>(a, XfNone(), b, XfNone(), ep, M, 2 * C, 4 * C, 1, st)));
     });
     return check_launch("lstm_dgrad");
-}
-
-int rvt_lstm_dgrad_gates(const void* dz, const void* wt, void* dx, const void* dh_in_prev, float* dc_rec, const void* gates_prev,
-                         const float* c_new_prev, const float* c_prev_prev, void* dz_prev, int dtype, int M, int C, void* stream) {
-    RVT_CHECK(C % 8 == 0, "lstm_dgrad_gates: C=%d must be a multiple of 8", C);
-    hipStream_t st = (hipStream_t)stream;
-    DISPATCH_DTYPE(dtype, {
-        PlainSrc<T> a{(const T*)dz, 4 * C, M, 4 * C};
-        PlainSrc<T> b{(const T*)wt, 4 * C, 2 * C, 4 * C};
-        EpLstmBwd<T> ep{(T*)dx, C, (const T*)dh_in_prev, dc_rec, (const T*)gates_prev, c_new_prev, c_prev_prev, (T*)dz_prev};
-        DISPATCH_BN(2 * C, (launch_gemm<T, BN, false>(a, XfNone(), b, XfNone(), ep, M, 2 * C, 4 * C, 1, st)));
-    });
-    return check_launch("lstm_dgrad_gates");
 }
 
 int rvt_lstm_wgrad(const void* dz, const void* x, const void* h_prev, float* dw, float* dz_colsum, float* ws, int dtype,

@@ -508,56 +508,6 @@ template <class T> struct EpSplit2 {
     }
 };
 
-// ConvLSTM BPTT, one launch per time step: [dx_t | dh_rec] = dz_t W, and on the recurrent half the element-wise gate
-// backward of step t-1 (rowops.hpp lstm_gates_bwd_kernel; reference forward rnn.py:57-67) right in the epilogue — dh_rec never
-// goes to HBM and the per-step gate kernel disappears.  The side inputs (gates, cell states, dc) are read inside apply():
-// prefetching them like the other epilogues' aux would cost 44 registers per 8-column unit.
-template <class T> struct EpLstmBwd {
-    __device__ __forceinline__ void begin_block(int) {}
-    static constexpr int UNIT = 8;
-    typedef EpNone Cols;
-    typedef EpNone Aux;
-    T* dx; int C;
-    const T* dh_in; float* dc_rec; const T* gates; const float* c_new; const float* c_prev; T* dz;      // all of step t-1
-    __device__ __forceinline__ Cols cols(int, bool) const { return Cols(); }
-    __device__ __forceinline__ Aux fetch(int, int) const { return Aux(); }
-    __device__ __forceinline__ void apply(int m, int n, float (&v)[8], const Aux&, const Cols&) const {
-        if (n < C) {
-            frag_store<T>(dx + (size_t)m * C + n, frag_from_float<T>(v));
-            return;
-        }
-        const int c0 = n - C;
-        float dh[8], r[8], f[8], ig[8], o[8], g[8];
-        frag_to_float<T>(frag_load<T>(dh_in + (size_t)m * C + c0), dh);
-        frag_to_float<T>(frag_from_float<T>(v), r);               // rounded to T like the stored dh_rec of the two-kernel route
-        const T* gp = gates + (size_t)m * 4 * C + c0;
-        frag_to_float<T>(frag_load<T>(gp), f);
-        frag_to_float<T>(frag_load<T>(gp + C), ig);
-        frag_to_float<T>(frag_load<T>(gp + 2 * C), o);
-        frag_to_float<T>(frag_load<T>(gp + 3 * C), g);
-        float zf[8], zi[8], zo[8], zg[8];
-        float* dcp = dc_rec + (size_t)m * C + c0;
-        const float* cn = c_new + (size_t)m * C + c0;
-        const float* cp = c_prev + (size_t)m * C + c0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const float d = dh[i] + r[i];
-            const float tc = tanh_f(cn[i]);
-            const float dc = dcp[i] + d * o[i] * (1.f - tc * tc);
-            zo[i] = d * tc * o[i] * (1.f - o[i]);
-            zf[i] = dc * cp[i] * f[i] * (1.f - f[i]);
-            zi[i] = dc * g[i] * ig[i] * (1.f - ig[i]);
-            zg[i] = dc * ig[i] * (1.f - g[i] * g[i]);
-            dcp[i] = dc * f[i];
-        }
-        T* zp = dz + (size_t)m * 4 * C + c0;
-        frag_store<T>(zp, frag_from_float<T>(zf));
-        frag_store<T>(zp + C, frag_from_float<T>(zi));
-        frag_store<T>(zp + 2 * C, frag_from_float<T>(zo));
-        frag_store<T>(zp + 3 * C, frag_from_float<T>(zg));
-    }
-};
-
 struct EpAtomicF32 {                           // direct atomic accumulation (kept for tiny problems / no workspace)
     static constexpr int UNIT = 8;
     typedef EpNone Cols;

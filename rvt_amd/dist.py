@@ -41,10 +41,15 @@ class StageGradReducer:
     def world_size(self) -> int:
         return dist.get_world_size(self.pg) if dist.is_initialized() else 1
 
-    def on_stage_done(self, stage_idx: int, bucket: torch.Tensor) -> None:
+    def on_stage_done(self, stage_idx: int, bucket: torch.Tensor, accumulated: bool = False) -> None:
         """All-reduce (mean) the flat fp32 gradient bucket of one stage in place.  Async: the collective waits for the
-        producing stream, the consumer waits in finish()."""
+        producing stream, the consumer waits in finish().  `accumulated`: the bucket still holds the (already reduced)
+        gradients of earlier backward passes (zero-copy hand-off without zeroing): averaging keeps them intact
+        (mean(g_prev + g_i) = g_prev + mean(g_i)), a SUM would multiply them by the world size."""
         ws = self.world_size
+        if accumulated and not self.average and ws > 1:
+            raise RuntimeError('StageGradReducer(average=False) with gradient accumulation into the persistent buckets: '
+                               'zero the gradients (set_to_none=True) before every backward, or use average=True')
         if (ws == 1 and not self.force) or bucket.numel() == 0:
             return
         if not dist.is_initialized():

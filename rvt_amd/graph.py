@@ -18,11 +18,16 @@ import torch
 
 
 class GraphedStep:
-    def __init__(self, fn: Callable[[], None], warmup: int = 3, device: Optional[torch.device] = None):
+    def __init__(self, fn: Callable[[], None], warmup: int = 3, device: Optional[torch.device] = None, models=()):
         """fn must read its inputs from tensors that stay alive and keep their addresses (copy new data INTO them), must
         not synchronise with the host, and should leave parameter gradients in place (rvt_amd assigns persistent bucket
         views to ``.grad``; use ``optimizer.zero_grad(set_to_none=True)`` inside fn)."""
         self.fn = fn
+        # models whose kernel-side weight copies the captured step re-packs: a replay updates the parameters without bumping
+        # their version counters on the host, so the next inference forward must not trust its cache
+        self.models = tuple(models)
+        for m in self.models:
+            m.zero_copy_grads = True             # stable gradient addresses inside the captured step
         dev = torch.device('cuda', torch.cuda.current_device()) if device is None else device
         for _ in range(max(1, warmup)):          # eager warm-up: sizes every grow-only workspace, the occupancy caches and
             fn()                                 # the optimizer state before anything is recorded
@@ -36,3 +41,5 @@ class GraphedStep:
 
     def __call__(self) -> None:
         self.graph.replay()
+        for m in self.models:
+            m.invalidate_weight_cache()

@@ -80,10 +80,8 @@ def stem_fwd(src: Tensor, w: Tensor, ln_w: Tensor, ln_b: Tensor, H: int, W: int,
     return y0, x
 
 
-def stem_wgrad(src: Tensor, dy: Tensor, dw: Tensor, H: int, W: int, y0: Optional[Tensor] = None, ln_w: Optional[Tensor] = None,
-               dln_w: Optional[Tensor] = None, dln_b: Optional[Tensor] = None, eps: float = 1e-5) -> None:
-    """dw (64, 49*cp) fp32 += dy^T im2col(pad(src)) — the layout conv_wgrad writes.  With y0 (the conv output): `dy` is the
-    gradient at LayerNorm(y0) and the LayerNorm backward runs inside the kernel (dln_w, dln_b += its parameter gradients)."""
+def stem_wgrad(src: Tensor, dy: Tensor, dw: Tensor, H: int, W: int) -> None:
+    """dw (64, 49*cp) fp32 += dy^T im2col(pad(src)) — the layout conv_wgrad writes."""
     assert src.dtype == torch.uint8 and src.is_contiguous() and dy.is_contiguous() and dw.dtype == torch.float32
     F_, Cin, h, wd = src.shape
     cp = dw.shape[1] // 49
@@ -95,12 +93,7 @@ def stem_wgrad(src: Tensor, dy: Tensor, dw: Tensor, H: int, W: int, y0: Optional
     if ws is None or ws.numel() < n:
         ws = torch.empty(n, dtype=torch.float32, device=dy.device)
         _WS[key] = ws
-    if y0 is None:
-        L.call('rvt_stem_wgrad', L.ptr(src), L.ptr(dy), L.ptr(dw), L.ptr(ws), L.dtype_code(dy.dtype), F_, Cin, cp, h, wd, H, W, st)
-    else:
-        assert y0.is_contiguous() and y0.shape == dy.shape and y0.dtype == dy.dtype
-        L.call('rvt_stem_wgrad_ln', L.ptr(src), L.ptr(dy), L.ptr(y0), L.ptr(ln_w), L.ptr(dw), L.ptr(dln_w), L.ptr(dln_b), L.ptr(ws),
-               L.dtype_code(dy.dtype), F_, Cin, cp, h, wd, H, W, float(eps), st)
+    L.call('rvt_stem_wgrad', L.ptr(src), L.ptr(dy), L.ptr(dw), L.ptr(ws), L.dtype_code(dy.dtype), F_, Cin, cp, h, wd, H, W, st)
 
 
 def conv_dgrad(dy: Tensor, wd: Tensor, add: Optional[Tensor], H: int, W: int, Cin: int, k: int, stride: int, pad: int,
@@ -213,24 +206,6 @@ def mlp_bwd_fused_supported(dtype: torch.dtype, C: int) -> bool:
     return bool(L.get_lib().rvt_mlp_bwd_fused_supported(L.dtype_code(dtype), C))
 
 
-def mlp_bwd_fused(dxout: Tensor, xmid: Tensor, ln_w: Tensor, ln_b: Tensor, w1: Tensor, b1: Tensor, w2g_t: Tensor, w1_t: Tensor,
-                  dln_w: Tensor, dln_b: Tensor, dw1: Tensor, db1: Tensor, s2: Tensor, cs2: Tensor, eps: float) -> Tensor:
-    """Whole backward of the MLP half from (dxout, xmid): returns dxmid; accumulates dln_w/dln_b, dw1 [4C][C], db1 [4C] and
-    the raw fc2 products s2 [C][4C], cs2 [C] (all fp32, +=)."""
-    C = xmid.shape[-1]
-    M = xmid.numel() // C
-    dt = L.dtype_code(xmid.dtype)
-    st = L.stream_of(xmid)
-    ws = _mlp_ws(xmid)
-    dxmid = torch.empty_like(xmid)
-    for t in (dw1, db1, s2, cs2, dln_w, dln_b):
-        assert t.dtype == torch.float32
-    L.call('rvt_mlp_bwd_fused', L.ptr(dxout), L.ptr(xmid), L.ptr(dxmid), L.ptr(ln_w), L.ptr(ln_b), L.ptr(w1), L.ptr(b1),
-           L.ptr(w2g_t), L.ptr(w1_t), L.ptr(dln_w), L.ptr(dln_b), L.ptr(dw1), L.ptr(db1), L.ptr(s2), L.ptr(cs2), L.ptr(ws), dt,
-           M, C, float(eps), st)
-    return dxmid
-
-
 def _mlp_ws(xmid: Tensor) -> Tensor:
     C = xmid.shape[-1]
     M = xmid.numel() // C
@@ -291,12 +266,6 @@ def linear_wgrad(dy: Tensor, x: Tensor, dw: Tensor, gelu_in: bool = False, colsu
     ws = _wgrad_ws(dy, N, K, M, colsum_out is not None)
     L.call('rvt_linear_wgrad', L.ptr(dy), L.ptr(x), L.ptr(dw), L.ptr(colsum_out), L.ptr(ws), L.dtype_code(dy.dtype),
            M, N, K, int(gelu_in), L.stream_of(dy))
-
-
-def colsum(x: Tensor, out: Tensor) -> None:
-    N = x.shape[-1]
-    assert out.dtype == torch.float32 and out.numel() == N
-    L.call('rvt_colsum', L.ptr(x), L.ptr(out), L.dtype_code(x.dtype), x.numel() // N, N, L.stream_of(x))
 
 
 def attn_fwd(qkv: Tensor, F_: int, H: int, W: int, C: int, dh: int, ph: int, pw: int, window: bool,
@@ -367,15 +336,6 @@ def lstm_dgrad(dz: Tensor, wt: Tensor, dx: Tensor, dh_rec: Tensor) -> None:
     M = dx.numel() // C
     L.call('rvt_lstm_dgrad', L.ptr(dz), L.ptr(wt), L.ptr(dx), L.ptr(dh_rec), L.dtype_code(dz.dtype), M, C,
            L.stream_of(dz))
-
-
-def lstm_dgrad_gates(dz: Tensor, wt: Tensor, dx: Tensor, dh_in_prev: Tensor, dc_rec: Tensor, gates_prev: Tensor, c_new_prev: Tensor,
-                     c_prev_prev: Tensor, dz_prev: Tensor) -> None:
-    """lstm_dgrad of step t with lstm_gates_bwd of step t-1 in its epilogue (the recurrent dh never goes to HBM)."""
-    C = dx.shape[-1]
-    M = dx.numel() // C
-    L.call('rvt_lstm_dgrad_gates', L.ptr(dz), L.ptr(wt), L.ptr(dx), L.ptr(dh_in_prev), L.ptr(dc_rec), L.ptr(gates_prev),
-           L.ptr(c_new_prev), L.ptr(c_prev_prev), L.ptr(dz_prev), L.dtype_code(dz.dtype), M, C, L.stream_of(dz))
 
 
 def lstm_wgrad(dz: Tensor, x: Tensor, h_prev: Tensor, dw: Tensor, colsum_out: Optional[Tensor] = None) -> None:

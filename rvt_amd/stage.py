@@ -23,13 +23,12 @@ import torch
 from . import ops
 from .weights import StageGrads, StageWeights
 
-_STEM_LN = os.environ.get('RVT_STEM_LN', '0') == '1'
 
 
 def use_fused_mlp(dtype, C: int, what: str) -> bool:
-    """Which MLP halves go through the fused kernels of csrc/mlp.hpp.
+    """Which MLP halves go through the fused kernels of csrc/mlp.hpp / mlp_chain.hpp.
       'bwd_fused' (C = 64): the whole backward — recompute of LN2 / fc1 / GELU, both input-gradient products, LayerNorm
-          backward AND the weight gradients (accumulated in registers) — from (dxout, xmid) alone; the forward then saves
+          backward and the weight gradients (two launches) — from (dxout, xmid) alone; the forward then saves
           nothing but the block input (3 + 2 rows of C per token through HBM for the MLP half instead of 32).
       'fwd_train' / 'fwd_infer' / 'bwd' (C in {64,128}): fused forward (optionally saving GELU, GELU', LN2 out) and the
           fused input-gradient chain.  Measured on MI355X (profiles/microbench_mlp.py, bf16, ms, fused vs op-by-op chain):
@@ -130,7 +129,7 @@ class StageGeom:
 
 class StageSaved:
     """Activations kept for backward (everything else is recomputed from these)."""
-    __slots__ = ('inp', 'y0', 'blocks', 'x_last', 'Hall', 'Call', 'gates', 'mask', 'xin_lstm', 'hconv', 'Csave', 'c0')
+    __slots__ = ('inp', 'y0', 'blocks', 'x_last', 'Hall', 'Call', 'gates', 'mask', 'xin_lstm', 'hconv', 'Csave', 'c0', '__weakref__')
 
     def __init__(self):
         self.blocks: List[Dict[str, Tensor]] = []
@@ -207,7 +206,9 @@ def stage_seq_forward(sw: StageWeights, g: StageGeom, inp: Tensor, h0: Optional[
         ops.lstm_scan_fwd(x.view(T, B, H, W, C), Hall, c0, c_last, Csave, sw.lstm_wn, sw.lstm_bn, gates_out=gsave)
         if save:
             sv.x_last, sv.Hall, sv.Call, sv.gates = x, Hall, None, gsave
-            sv.xin_lstm, sv.hconv, sv.Csave, sv.c0 = x, None, Csave, c0
+            # the incoming cell state may alias the caller's tensor (RNNStates resets states in place, modules/utils/detection.py:96-113):
+            # BPTT needs the value the forward saw, so it keeps a copy (B*H*W*C fp32 per stage)
+            sv.xin_lstm, sv.hconv, sv.Csave, sv.c0 = x, None, Csave, (None if c0 is None else c0.clone())
         return Hall, c_last, sv
     # cell states: all T+1 slots are kept for BPTT; a no-grad forward ping-pongs between two
     nc = T + 1 if save else 2
@@ -286,18 +287,9 @@ def stage_seq_backward(sw: StageWeights, g: StageGeom, sv: StageSaved, dH: Optio
         dhc = torch.empty((T, B, H, W, C), dtype=dt, device=dev) if dws is not None else None   # d(dwconv(h_{t-1}))
         if dws is not None:
             wh = dws['w'] if dws['only_hidden'] else dws['w'][C:]
-        # (rvt_lstm_dgrad_gates: one launch per step instead of two, but the side inputs of the gate backward are then loaded behind
-        # the product instead of streamed by a bandwidth-bound kernel: 113 us per step against 42 + 32 at stages 3-4 — opt-in)
-        fuse_gates = dws is None and os.environ.get('RVT_LSTM_FUSE_GATES', '0') == '1'
         for t in range(T - 1, -1, -1):
-            if not fuse_gates or t == T - 1:
-                ops.lstm_gates_bwd(dH[t], dh_rec, dc_rec, sv.gates[t], sv.Call[t + 1], sv.Call[t], dz[t])
+            ops.lstm_gates_bwd(dH[t], dh_rec, dc_rec, sv.gates[t], sv.Call[t + 1], sv.Call[t], dz[t])
             nxt = dh_buf[t & 1]
-            if fuse_gates and t > 0:
-                # one launch per step: the gate backward of step t-1 is the epilogue of this step's input-gradient product
-                ops.lstm_dgrad_gates(dz[t], sw.lstm_wt, dx[t], dH[t - 1], dc_rec, sv.gates[t - 1], sv.Call[t], sv.Call[t - 1],
-                                     dz[t - 1])
-                continue
             if dws is None:
                 ops.lstm_dgrad(dz[t], sw.lstm_wt, dx[t], nxt)
             else:
@@ -343,20 +335,15 @@ def stage_seq_backward(sw: StageWeights, g: StageGeom, sv: StageSaved, dH: Optio
             if s['hg'] is None:
                 # everything on chip: recompute, both input-gradient products, LayerNorm backward and the fc1 / fc2 weight
                 # gradients (accumulated in registers) in one kernel; nothing for the weight-gradient stream to do
-                if os.environ.get('RVT_MLP_BWD_SPLIT', '1') == '1':
-                    # two launches of the same kernel, cut along the critical path: the input-gradient half here, the
-                    # weight-gradient half (which needs all 2 x 64 x 256 accumulators) on the weight-gradient stream
-                    def mlp_wgrad_fn(dx=dx, s=s, bw=bw, bp=bp):
-                        ops.mlp_bwd_recompute_wgrad(dx, s['xmid'], bw['n2_w'], bw['n2_b'], bw['fc1_w'], bw['fc1_b'],
-                                                    bw['fc2_wt'], G(bp + 'mlp.net.0.0.weight'), G(bp + 'mlp.net.0.0.bias'),
-                                                    G(bp + 'S2'), G(bp + 'cs2'), g.eps)
-                    side.run(mlp_wgrad_fn, dx, s['xmid'])
-                    dxmid = ops.mlp_bwd_recompute_dgrad(dx, s['xmid'], bw['n2_w'], bw['n2_b'], bw['fc1_w'], bw['fc1_b'],
-                                                        bw['fc2_wt'], bw['fc1_wt'], dn2w, dn2b, g.eps)
-                else:
-                    dxmid = ops.mlp_bwd_fused(dx, s['xmid'], bw['n2_w'], bw['n2_b'], bw['fc1_w'], bw['fc1_b'], bw['fc2_wt'],
-                                              bw['fc1_wt'], dn2w, dn2b, G(bp + 'mlp.net.0.0.weight'),
-                                              G(bp + 'mlp.net.0.0.bias'), G(bp + 'S2'), G(bp + 'cs2'), g.eps)
+                # two launches, cut along the critical path: the input-gradient half here, the weight-gradient half (which
+                # needs all 2 x 64 x 256 accumulators) on the weight-gradient stream
+                def mlp_wgrad_fn(dx=dx, s=s, bw=bw, bp=bp):
+                    ops.mlp_bwd_recompute_wgrad(dx, s['xmid'], bw['n2_w'], bw['n2_b'], bw['fc1_w'], bw['fc1_b'],
+                                                bw['fc2_wt'], G(bp + 'mlp.net.0.0.weight'), G(bp + 'mlp.net.0.0.bias'),
+                                                G(bp + 'S2'), G(bp + 'cs2'), g.eps)
+                side.run(mlp_wgrad_fn, dx, s['xmid'])
+                dxmid = ops.mlp_bwd_recompute_dgrad(dx, s['xmid'], bw['n2_w'], bw['n2_b'], bw['fc1_w'], bw['fc1_b'],
+                                                    bw['fc2_wt'], bw['fc1_wt'], dn2w, dn2b, g.eps)
             else:
                 def fc2_wgrad_fn(dx=dx, s=s, bp=bp):
                     ops.linear_wgrad(dx, s['hg'], G(bp + 'S2'), colsum_out=G(bp + 'cs2'))
@@ -410,16 +397,10 @@ def stage_seq_backward(sw: StageWeights, g: StageGeom, sv: StageSaved, dH: Optio
     # ---- token mask, down-sampling LayerNorm + conv ---------------------------------------------------------
     if sv.mask is not None:
         ops.token_mask_bwd(dx, sv.mask, G(pre + 'mask_token').view(C))            # also zeroes dx on masked tokens
-    # LayerNorm backward inside the stem weight gradient (rvt_stem_wgrad_ln): measured 2.62 ms against 1.86 + 0.63 ms for the two
-    # kernels — the per-row reductions sit on the barrier-critical staging path of every tile — so it is opt-in
-    stem_ln = _STEM_LN and sv.inp.dtype == torch.uint8 and not need_input_grad
-    dy0 = dx if stem_ln else ops.layernorm_bwd(sv.y0, sw.ln_w, dx, None, G(pre + 'downsample_cf2cl.norm.weight'),
-                                               G(pre + 'downsample_cf2cl.norm.bias'), g.eps)
+    dy0 = ops.layernorm_bwd(sv.y0, sw.ln_w, dx, None, G(pre + 'downsample_cf2cl.norm.weight'),
+                            G(pre + 'downsample_cf2cl.norm.bias'), g.eps)
     def conv_wgrad_fn():
-        if stem_ln:
-            ops.stem_wgrad(sv.inp, dx, G('raw/conv'), g.H_in, g.W_in, y0=sv.y0, ln_w=sw.ln_w,
-                           dln_w=G(pre + 'downsample_cf2cl.norm.weight'), dln_b=G(pre + 'downsample_cf2cl.norm.bias'), eps=g.eps)
-        elif sv.inp.dtype == torch.uint8:
+        if sv.inp.dtype == torch.uint8:
             ops.stem_wgrad(sv.inp, dy0, G('raw/conv'), g.H_in, g.W_in)
         else:
             ops.conv_wgrad(sv.inp, dy0, G('raw/conv'), g.k, g.stride, g.pad)

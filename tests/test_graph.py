@@ -78,7 +78,7 @@ def test_training_step_graph_matches_eager():
     init = {n: p.detach().clone() for n, p in m_e.named_parameters()}
     eager, graphed_fn = step_of(m_e, opt_e), step_of(m_g, opt_g)
     warm = 2
-    gs = GraphedStep(graphed_fn, warmup=warm)      # the warm-up steps are REAL (eager) steps; the capture pass only records
+    gs = GraphedStep(graphed_fn, warmup=warm, models=(m_g,))      # the warm-up steps are REAL (eager) steps; the capture pass only records
     for _ in range(warm):
         eager()
     for _ in range(3):
@@ -92,3 +92,13 @@ def test_training_step_graph_matches_eager():
         num += float((a - b).double().pow(2).sum())
         den += float((b - init[n]).double().pow(2).sum())
     assert den > 0 and (num / den) ** 0.5 < 2e-2, (num, den)
+    # a replay moves the parameters without touching their host-side version counters: the next inference forward must re-pack
+    # the kernel-side weights (GraphedStep invalidates the cache), i.e. agree with the eager model on the same parameters
+    with torch.no_grad():
+        fg, _ = m_g.forward_sequence(xs, None)
+        for (_, a), (_, b) in zip(m_e.named_parameters(), m_g.named_parameters()):
+            a.copy_(b)
+        m_e.invalidate_weight_cache()
+        fe, _ = m_e.forward_sequence(xs, None)
+    for s_ in range(1, 5):
+        assert torch.equal(fg[s_], fe[s_])

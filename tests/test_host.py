@@ -267,6 +267,7 @@ def test_gradient_buckets_accumulate_and_reassign():
     from tests import casegen
     try:
         m = _emu_model()
+        m.zero_copy_grads = True                                 # opt-in (bench.py, GraphedStep); the default is tested below
         xs = torch.from_numpy(casegen.make_inputs('micro'))
         cots = [torch.from_numpy(a) for a in casegen.make_cotangents('micro')]
 
@@ -292,5 +293,41 @@ def test_gradient_buckets_accumulate_and_reassign():
         assert torch.allclose(w.grad, g1[n0] + 1.0)
         other = 'stages.2.att_blocks.0.att_grid.ls1.gamma'
         assert torch.equal(m.get_parameter(other).grad, g1[other])
+    finally:
+        _lib._install_test_library(None)
+
+
+def test_default_gradient_handoff_obeys_autograd_contracts():
+    """Default hand-off (no zero_copy_grads): gradients travel through autograd as tensors of their own - torch.autograd.grad
+    returns them and leaves .grad alone, a .grad reference kept across steps is not overwritten by the next backward,
+    accumulation without zeroing adds up."""
+    from tests import casegen
+    try:
+        m = _emu_model()
+        assert not getattr(m, 'zero_copy_grads', False)
+        xs = torch.from_numpy(casegen.make_inputs('micro'))
+        cots = [torch.from_numpy(a) for a in casegen.make_cotangents('micro')]
+        names = [n for n, _ in m.named_parameters()]
+        params = [p for _, p in m.named_parameters()]
+
+        def loss():
+            feats, _ = m.forward_sequence(xs)
+            return sum((feats[s + 1] * cots[s]).sum() for s in range(4))
+        got = torch.autograd.grad(loss(), params)
+        assert all(g is not None for g in got) and all(p.grad is None for p in params)
+        loss().backward()
+        kept = {n: p.grad for n, p in zip(names, params)}
+        snap = {n: g.clone() for n, g in kept.items()}
+        mw = m._mw_cache
+        for n, p in zip(names, params):
+            assert torch.equal(p.grad, got[names.index(n)]), n
+            assert p.grad.data_ptr() != mw.grads[int(n.split('.')[1])].g(n).data_ptr()      # not a view of the bucket
+        m.zero_grad(set_to_none=True)
+        (2.0 * loss()).backward()                                # a different gradient into the same buckets
+        for n in names:
+            assert torch.equal(kept[n], snap[n]), n              # the old reference still holds the old values
+        loss().backward()                                        # accumulate on top of the 2x gradients
+        for n, p in zip(names, params):
+            assert torch.allclose(p.grad, 3.0 * snap[n], rtol=1e-5, atol=1e-6 * float(snap[n].abs().max())), n
     finally:
         _lib._install_test_library(None)

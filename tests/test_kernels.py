@@ -204,15 +204,6 @@ def test_linear_wgrad(backend, dt, M, N, K, gelu):
 
 
 @pytest.mark.parametrize('dt', DTYPES)
-@pytest.mark.parametrize('rows,N', [(77, 144), (300, 16), (40, 2048 + 64)])
-def test_colsum(backend, dt, rows, N):
-    x = rnd((rows, N), backend, dt, 1)
-    out = torch.zeros(N, device=backend)
-    ops.colsum(x, out)
-    close(out, f64(x).sum(0), dt, 'colsum', mult=0.1 if dt == torch.bfloat16 else 1.0)
-
-
-@pytest.mark.parametrize('dt', DTYPES)
 @pytest.mark.parametrize('rows,C', [(37, 48), (100, 64), (9, 16), (21, 512), (33, 384)])
 def test_layernorm(backend, dt, rows, C):
     x = rnd((rows, C), backend, dt, 1, 2.0)
@@ -371,14 +362,6 @@ def test_lstm_cell(backend, dt, M, C):
     ops.lstm_dgrad(dz, w_t.t().contiguous(), dx, dhp)
     close(dx, xr.grad, dt, 'lstm dx', mult=2.0)
     close(dhp, hr.grad, dt, 'lstm dh_prev', mult=2.0)
-    # one-launch step: the same gate backward as the EPILOGUE of an input-gradient product (dh_rec = its recurrent half)
-    dz_b, dz2, dc2, dx2 = rnd((M, 4 * C), backend, dt, 9), torch.empty_like(dz), dc_rec.clone(), torch.empty_like(dx)
-    dhr = torch.empty(M, C, dtype=dt, device=backend)
-    ops.lstm_dgrad(dz_b, w_t.t().contiguous(), dx, dhr)
-    dz1, dc1 = torch.empty_like(dz), dc_rec.clone()
-    ops.lstm_gates_bwd(dh_in, dhr, dc1, gates, c_out, c, dz1)
-    ops.lstm_dgrad_gates(dz_b, w_t.t().contiguous(), dx2, dh_in, dc2, gates, c_out, c, dz2)
-    assert torch.equal(dx2.cpu(), dx.cpu()) and torch.equal(dz2.cpu(), dz1.cpu()) and torch.equal(dc2.cpu(), dc1.cpu())
     ops.lstm_dgrad(dz, w_t.t().contiguous(), dx, dhp)
     dw = torch.zeros(4 * C, 2 * C, device=backend)
     dbias = torch.zeros(4 * C, device=backend)
@@ -467,17 +450,6 @@ def test_stem(backend, case):
     close(got, wr.grad, dt, 'stem wgrad')
     pad_cols = (dw - 0.5).view(64, 49, cp)[:, :, Cin:]
     assert float(pad_cols.abs().max()) == 0.0 if cp > Cin else True
-    # ... and with the LayerNorm backward folded in: gradient dx at x = LN(y0) -> dW, dln_w, dln_b (y0 = the stored bf16 conv output)
-    y0r = f64(y0).requires_grad_(True)
-    lwr, lbr = f64(lw).requires_grad_(True), f64(lb).requires_grad_(True)
-    F.layer_norm(y0r, (64,), lwr, lbr, 1e-5).backward(f64(dy))
-    wr.grad = None
-    F.conv2d(xin, wr, None, 4, 3).backward(y0r.grad.to(dt).double().permute(0, 3, 1, 2))      # (the kernel rounds dy0 to bf16 too)
-    dw2, dlw, dlb = torch.zeros(64, 49 * cp, device=backend), torch.full((64,), 0.25, device=backend), torch.full((64,), -0.5, device=backend)
-    ops.stem_wgrad(srcd, dy, dw2, H, W, y0=y0, ln_w=lw, dln_w=dlw, dln_b=dlb, eps=1e-5)
-    close(weights.unpack_conv_wgrad(dw2, Cin, 7), wr.grad, dt, 'stem wgrad with LN backward')
-    close(dlw - 0.25, lwr.grad, dt, 'stem dln_w')
-    close(dlb + 0.5, lbr.grad, dt, 'stem dln_b')
 
 
 @pytest.mark.parametrize('dt', DTYPES)
@@ -511,11 +483,9 @@ def test_state_reset(backend, dt):
 
 @pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('M', [130, 1000])
-@pytest.mark.parametrize('route', ['fused', 'split'])
-def test_mlp_bwd_fused_everything_on_chip(backend, dt, M, route, monkeypatch):
-    """Recompute backward of the MLP half (C = 64) vs fp64 autograd: 'fused' = rvt_mlp_bwd_fused (one kernel: input gradient
-    + in-register weight gradients), 'split' = rvt_mlp_bwd_recompute_dgrad + rvt_mlp_bwd_recompute_wgrad (the register-chained
-    kernels of csrc/mlp_chain.hpp; the route the stage driver takes)."""
+def test_mlp_bwd_recompute(backend, dt, M):
+    """Recompute backward of the MLP half (C = 64) vs fp64 autograd: rvt_mlp_bwd_recompute_dgrad + rvt_mlp_bwd_recompute_wgrad
+    (the register-chained kernels of csrc/mlp_chain.hpp; what the stage driver calls)."""
     C = 64
     assert ops.mlp_bwd_fused_supported(dt, C)
     x = rnd((M, C), backend, dt, 1, 1.5)
@@ -540,8 +510,6 @@ def test_mlp_bwd_fused_everything_on_chip(backend, dt, M, route, monkeypatch):
     z = lambda *s: torch.zeros(*s, device=backend)
     dlw, dlb, dw1, db1, s2, cs2 = z(C), z(C), z(4 * C, C), z(4 * C), z(C, 4 * C), z(C)
     def run():
-        if route == 'fused':
-            return ops.mlp_bwd_fused(dy, x, lw, lb, w1, b1, w2g_t, w1_t, dlw, dlb, dw1, db1, s2, cs2, 1e-5)
         d = ops.mlp_bwd_recompute_dgrad(dy, x, lw, lb, w1, b1, w2g_t, w1_t, dlw, dlb, 1e-5)
         ops.mlp_bwd_recompute_wgrad(dy, x, lw, lb, w1, b1, w2g_t, dw1, db1, s2, cs2, 1e-5)
         return d
