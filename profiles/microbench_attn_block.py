@@ -9,6 +9,8 @@ dt = torch.bfloat16
 F_, H, W, C, dh, ph, pw, eps = 504, 96, 160, 64, 32, 6, 10, 1e-5
 if '--small' in sys.argv:
     F_ = 48
+if '--gen1' in sys.argv:      # RVT-Base on Gen1 (config/experiment/gen1/base.yaml): 64 x 80 tokens at stage 1, 8 x 10 = 80-token partitions
+    F_, H, W, ph, pw = 504, 64, 80, 8, 10
 
 
 def timeit(fn, n=5):

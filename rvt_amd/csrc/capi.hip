@@ -60,6 +60,9 @@ static inline int wgrad_ksplit(int out_rows, int out_cols, int tokens, int bn) {
     int want = imax(1, (split_override > 0 ? split_override : 512) / imax(1, tiles));
     static const int slice_tokens = getenv("RVT_WGRAD_SLICE_TOKENS") ? imax(64, atoi(getenv("RVT_WGRAD_SLICE_TOKENS"))) : 8192;   // (tests: small)
     int maxs = imax(1, tokens / slice_tokens);
+    // small problems (RVT-Tiny on Gen1: 13 440 / 53 760 tokens at stages 4 / 3): with 8192-token slices a launch is a dozen
+    // workgroups walking hundreds of K tiles each (0.24 ms for 5 GFLOP); 1024-token slices fill the chip
+    if (maxs < 8 && slice_tokens > 1024) maxs = imax(1, tokens / 1024);
     int ks = imin(want, maxs);
     if (ks >= 16) ks = ks / 8 * 8;             // multiple of 8 slices: tiles of one slice can share an XCD's L2
     return ks;
@@ -773,10 +776,11 @@ int rvt_attn_block_bwd(const void* x, const void* dxmid, void* dx, void* dqkv, v
     const int NB = (g.L + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
 #define RVT_AB_BWD(NBB, LNN) launch_ab_bwd<T, NBB, LNN>(x, dxmid, dx, dqkv, u_out, ln_w, ln_b, wqkv, bqkv, wpg_t, dln_w, dln_b, g, eps, st)
-    DISPATCH_DTYPE(dtype, {
-        if (NB == 2) { if (ln_w) RVT_AB_BWD(2, true); else RVT_AB_BWD(2, false); }
-        else { if (ln_w) RVT_AB_BWD(3, true); else RVT_AB_BWD(3, false); }
-    });
+    // Three 32-token blocks per partition (the 8 x 10 Gen1 partitions) exist for the forward only: the backward's per-wave
+    // state for three blocks needs more than 512 registers (584-868 bytes per lane of scratch, 1.8-2.7 ms against 1.2-1.5 ms for
+    // the op-by-op chain at RVT-Base / Gen1, profiles/r3/microbench_attn_block_gen1.txt) - training takes the chain there.
+    RVT_CHECK(NB == 2, "attn_block_bwd: partitions of %d tokens (more than two 32-token blocks) are forward-only", g.L);
+    DISPATCH_DTYPE(dtype, { if (ln_w) RVT_AB_BWD(2, true); else RVT_AB_BWD(2, false); });
 #undef RVT_AB_BWD
     return check_launch("attn_block_bwd");
 }

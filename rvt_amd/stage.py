@@ -47,10 +47,14 @@ def use_fused_mlp(dtype, C: int, what: str) -> bool:
     return C == 64 or (C == 128 and what.startswith('fwd'))
 
 
-def use_attn_block(dtype, C: int, dh: int, n_tok: int) -> bool:
+def use_attn_block(dtype, C: int, dh: int, n_tok: int, training: bool = False) -> bool:
     """Attention half of a block (norm1, qkv, partition attention, proj, LayerScale + residual) as ONE kernel per direction
     (csrc/attn_block.hpp, one wave per partition) instead of LayerNorm + linear + attention core + linear (+ their
     backward chain): where it is built (C = 64, dim_head 32, partitions of 33..96 tokens).  RVT_ATTN_BLOCK=0 disables."""
+    # partitions of more than 64 tokens (Gen1: 8 x 10) have a fused forward only; a forward that keeps activations for a
+    # backward therefore takes the op-by-op chain there
+    if training and n_tok > 64:
+        return False
     return os.environ.get('RVT_ATTN_BLOCK', '1') != '0' and ops.attn_block_supported(dtype, C, dh, n_tok)
 
 
@@ -159,7 +163,7 @@ def stage_seq_forward(sw: StageWeights, g: StageGeom, inp: Tensor, h0: Optional[
 
     for pair in sw.blocks:
         for bw, window in ((pair[0], True), (pair[1], False)):
-            if use_attn_block(dt, C, g.dim_head, g.ph * g.pw):
+            if use_attn_block(dt, C, g.dim_head, g.ph * g.pw, training=save):
                 # maxvit.py:268 in one launch; backward recomputes q / k / v / P from the block input (nothing but `a`,
                 # the operand of the proj weight gradient, is kept)
                 xmid, a = ops.attn_block_fwd(x, bw['n1_w'], bw['n1_b'], bw['qkv_w'], bw['qkv_b'], bw['proj_w'], bw['proj_b'],

@@ -311,6 +311,8 @@ def test_attn_block_fused(backend, dt, window, ln, case):
     close(xmid, xmid_r, dt, 'attn_block xmid')
     xmid_r.backward(f64(dxm))
 
+    if ph * pw > 64:               # three 32-token blocks per partition: forward only (training takes the op-by-op chain)
+        return
     dln_w = torch.zeros(C, dtype=torch.float32, device=backend) if ln else None
     dln_b = torch.zeros(C, dtype=torch.float32, device=backend) if ln else None
     dx, dqkv, u = ops.attn_block_bwd(x, dxm, ln_w, ln_b, wqkv, bqkv, wpg_t, dln_w, dln_b, Fr, H, W, C, dh, ph, pw, window, eps)
