@@ -72,6 +72,18 @@ for label, M, N, K in SHAPES:
     ms, best = timeit(lambda: ops.linear_scale_res_fwd(x, w, b, gam, res, out=y))
     report(f'{label} scale_res', ms, best, by + M * N * 2, fl,
            check('scale_res', y, lambda r: res[r].float() + gam * (ref(r) + b), rows))
+    # weight gradient dW[N][K] = dy[M][N]^T x[M][K] (+ bias column sums): csrc/ppgemm_tn.hpp vs the 128 x 128 split-K engine
+    if M >= 100000:
+        dyw, dw, csum = rnd(M, N, scale=0.5), torch.zeros(N, K, device=dev), torch.zeros(N, device=dev)
+        ms, best = timeit(lambda: ops.linear_wgrad(dyw, x, dw, colsum_out=csum))
+        dw.zero_(); csum.zero_()
+        ops.linear_wgrad(dyw, x, dw, colsum_out=csum)
+        wr = torch.randint(0, N, (64,), device=dev)
+        want = (dyw[:, wr].float().t() @ x.float())
+        err = (dw[wr] - want).abs().max().item() / max(want.abs().max().item(), 1e-6)
+        err2 = (csum - dyw.float().sum(0)).abs().max().item() / max(dyw.float().sum(0).abs().max().item(), 1e-6)
+        report(f'{label} wgrad +colsum', ms, best, (M * N + M * K) * 2, fl, max(err, err2))
+        del dyw, dw
     if N >= 4 * K:
         g = None
         def run():

@@ -8,6 +8,7 @@
 #include "common.hpp"
 #include "gemm.hpp"
 #include "ppgemm.hpp"
+#include "ppgemm_tn.hpp"
 #include "rowops.hpp"
 #include "attn.hpp"
 #include "attn_block.hpp"
@@ -127,6 +128,10 @@ static inline int pp_min_k(int k) {
     static const int all = getenv("RVT_PPGEMM_ALL") ? atoi(getenv("RVT_PPGEMM_ALL")) : 0;
     return all ? 0 : k;
 }
+static inline bool use_ppgemm_tn(int dtype, int M, int N, int K, int ldy, int ldx, int kcut) {
+    static const int enabled = getenv("RVT_PPGEMM") ? atoi(getenv("RVT_PPGEMM")) : 1;
+    return enabled && dtype == RVT_BF16 && ppgemm_tn_shape_ok(M, N, K, ldy, ldx, kcut);
+}
 static inline bool use_ppgemm(int dtype, int M, int N, int K, int ldx, int ldw, int kcut) {
     static const int enabled = getenv("RVT_PPGEMM") ? atoi(getenv("RVT_PPGEMM")) : 1;
     static const int min_m = getenv("RVT_PPGEMM_MIN_M") ? atoi(getenv("RVT_PPGEMM_MIN_M")) : 4096;
@@ -146,6 +151,9 @@ int rvt_is_emulator(void) {
 }
 
 size_t rvt_wgrad_workspace_floats(int dtype, int out_rows, int out_cols, int tokens, int want_colsum) {
+    size_t pp = 0;
+    if (use_ppgemm_tn(dtype, tokens, out_rows, out_cols, out_rows, out_cols, out_cols))
+        pp = ppgemm_tn_ws_floats(tokens, out_rows, out_cols, want_colsum);     // (an upper bound is all the callers need)
     int bn = wgrad_bn(out_cols);
     int bk = dtype == RVT_F32 ? TileGeom<float>::BK : TileGeom<bf16>::BK;
     size_t n = wgrad_ws_floats(out_rows, out_cols, tokens, bn, bk, want_colsum);
@@ -153,7 +161,7 @@ size_t rvt_wgrad_workspace_floats(int dtype, int out_rows, int out_cols, int tok
         size_t nt = wgrad_ws_floats(out_cols, out_rows, tokens, 64, bk, want_colsum);
         if (nt > n) n = nt;
     }
-    return n;
+    return n > pp ? n : pp;
 }
 
 int rvt_prepack_input(const void* src, int src_u8, void* dst, int dtype, int F, int Cin, int h, int w, int H, int W,
@@ -452,6 +460,10 @@ int rvt_linear_wgrad(const void* dy, const void* x, float* dw, float* dy_colsum,
                      int gelu_in, void* stream) {
     RVT_CHECK(N % 8 == 0 && K % 8 == 0, "linear_wgrad: N=%d K=%d must be multiples of 8", N, K);
     hipStream_t st = (hipStream_t)stream;
+    if (!gelu_in && ws != nullptr && use_ppgemm_tn(dtype, M, N, K, N, K, K)) {
+        launch_ppgemm_tn((const bf16*)dy, N, (const bf16*)x, (const bf16*)x, K, K, dw, dy_colsum, ws, M, N, K, st);
+        return check_launch("linear_wgrad");
+    }
     DISPATCH_DTYPE(dtype, {
         PlainSrc<T> a{(const T*)dy, N, M, N};
         PlainSrc<T> b{(const T*)x, K, M, K};
@@ -825,6 +837,10 @@ int rvt_lstm_wgrad(const void* dz, const void* x, const void* h_prev, float* dw,
                    int M, int C, void* stream) {
     RVT_CHECK(C % 8 == 0, "lstm_wgrad: C=%d must be a multiple of 8", C);
     hipStream_t st = (hipStream_t)stream;
+    if (ws != nullptr && use_ppgemm_tn(dtype, M, 4 * C, 2 * C, 4 * C, C, C)) {       // [x | h]: two [M][C] matrices side by side
+        launch_ppgemm_tn((const bf16*)dz, 4 * C, (const bf16*)x, (const bf16*)h_prev, C, C, dw, dz_colsum, ws, M, 4 * C, 2 * C, st);
+        return check_launch("lstm_wgrad");
+    }
     DISPATCH_DTYPE(dtype, {
         PlainSrc<T> a{(const T*)dz, 4 * C, M, 4 * C};
         ConcatSrc<T> b{(const T*)x, (const T*)h_prev, C, M, 2 * C};

@@ -19,6 +19,7 @@ os.environ.setdefault('RVT_STEM_GRID', '3')
 # 8-workgroup grid so that a workgroup walks several output tiles (load stream / accumulator flush across tile boundaries)
 os.environ.setdefault('RVT_PPGEMM_MIN_M', '256')
 os.environ.setdefault('RVT_PPGEMM_GRID', '8')
+os.environ.setdefault('RVT_PPGEMM_TN_ITEMS', '6')          # weight-gradient variant: a few token slices per output tile
 os.environ.setdefault('RVT_PPGEMM_ALL', '1')            # every epilogue flavour through it, whatever the contraction length
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

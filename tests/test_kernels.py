@@ -92,6 +92,29 @@ def test_ppgemm_routes(backend, M, N, K):
     close(ops.linear_dgrad(x, w, res), ref * p.grad, dt, "ppgemm linear_dgrad * gelu'")
 
 
+@pytest.mark.parametrize('M,N,K', [(1000, 256, 256), (700, 512, 256), (1500, 256, 768), (600, 1024, 512)])
+def test_ppgemm_tn_routes(backend, M, N, K):
+    """Weight-gradient variant of the LDS-DMA GEMM (csrc/ppgemm_tn.hpp) behind rvt_linear_wgrad / rvt_lstm_wgrad (bf16, output
+    dims multiples of 256): ragged last token slice, += semantics, bias column sums, the [x | h] two-matrix operand."""
+    dt = torch.bfloat16
+    dy, x = rnd((M, N), backend, dt, 1), rnd((M, K), backend, dt, 2)
+    dw = torch.full((N, K), 0.25, device=backend)
+    cs = torch.full((N,), -1.0, device=backend)
+    ops.linear_wgrad(dy, x, dw, colsum_out=cs)
+    close(dw - 0.25, f64(dy).t() @ f64(x), dt, 'ppgemm_tn dW')
+    close(cs + 1.0, f64(dy).sum(0), dt, 'ppgemm_tn colsum', mult=0.2)
+    dw2 = torch.zeros(N, K, device=backend)
+    ops.linear_wgrad(dy, x, dw2)
+    close(dw2, f64(dy).t() @ f64(x), dt, 'ppgemm_tn dW (no colsum)')
+    if N == 4 * (K // 2) and (K // 2) % 256 == 0:        # ConvLSTM shape: dz [M][4C], [x | h] two [M][C] operands
+        C = K // 2
+        xs, hs = x[:, :C].contiguous(), x[:, C:].contiguous()
+        dw3, db3 = torch.zeros(N, K, device=backend), torch.zeros(N, device=backend)
+        ops.lstm_wgrad(dy, xs, hs, dw3, db3)
+        close(dw3, f64(dy).t() @ f64(x), dt, 'ppgemm_tn lstm dW')
+        close(db3, f64(dy).sum(0), dt, 'ppgemm_tn lstm colsum', mult=0.2)
+
+
 @pytest.mark.parametrize('dt', DTYPES)
 def test_linear_gelu_and_mul(backend, dt):
     M, N, K = 150, 136, 40
