@@ -43,6 +43,14 @@ int rvt_prepack_input(const void* src, int src_u8, void* dst, int dtype, int F, 
  * (tap-major, cin fastest) -> out [F][Ho][Wo][Cout], Ho=(H+2*pad-k)/stride+1. */
 int rvt_conv_fwd(const void* in, const void* w, void* out, int dtype, int F, int H, int W, int Cin, int Cout,
                  int k, int stride, int pad, void* stream);
+/* Input gradient of the 3x3 / stride-2 / pad-1 down-sampling conv of stages 2-4 (reference maxvit.py:160-168, autograd) as ONE
+ * product over 2x2 blocks of input pixels (csrc/ppgemm.hpp, GATHER mode).  wd4: [4*Cin][4*Cout] weights in the block-sparse layout
+ * of PACK_CONV_DGRAD4 (csrc/pack.hpp); add (nullable): cotangent already attached to the input, same shape as din.
+ * rvt_conv_dgrad4_supported: bf16, k 3, stride 2, pad 1, even H and W, Cin and Cout multiples of 64, enough rows. */
+int rvt_conv_dgrad4_supported(int dtype, int H, int W, int Cin, int Cout, int k, int stride, int pad, int F);
+int rvt_conv_dgrad4(const void* dy, const void* wd4, const void* add, void* din, int dtype, int F, int H, int W, int Cin, int Cout,
+                    void* stream);
+
 /* Input gradient: din[F][H][W][Cin] = conv^T(dy) (+ add).  wd = class-packed transposed weights, see
  * rvt_conv_dgrad_weight_elems / rvt_amd.weights.pack_conv_dgrad: for each parity class (py,px) in
  * row-major order a [Cin][nky*nkx*Cout] matrix.  `add` (nullable) has din's shape. */

@@ -34,10 +34,10 @@ template <int ABL> static float run(const PPMat& X, const PPMat& W, bf16* Y, int
     int grid = 256; const int total = m_tiles * n_tiles;
     if (grid > ((total + 7) & ~7)) grid = (total + 7) & ~7;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; i++) hipLaunchKernelGGL((ppgemm_kernel<PP_STORE, ABL>), dim3(grid), dim3(512), 0, 0, X, W, ep, M, N, K, m_tiles, n_tiles);
+    for (int i = 0; i < 3; i++) hipLaunchKernelGGL((ppgemm_kernel<PP_STORE, ABL>), dim3(grid), dim3(512), 0, 0, X, W, ep, M, N, K, m_tiles, n_tiles, PPConv());
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
-    for (int i = 0; i < iters; i++) hipLaunchKernelGGL((ppgemm_kernel<PP_STORE, ABL>), dim3(grid), dim3(512), 0, 0, X, W, ep, M, N, K, m_tiles, n_tiles);
+    for (int i = 0; i < iters; i++) hipLaunchKernelGGL((ppgemm_kernel<PP_STORE, ABL>), dim3(grid), dim3(512), 0, 0, X, W, ep, M, N, K, m_tiles, n_tiles, PPConv());
     CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     return ms / iters;

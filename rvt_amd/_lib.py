@@ -26,6 +26,7 @@ _SIGS = {
     'rvt_stacked_histogram': [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     'rvt_prepack_input': [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     'rvt_conv_fwd': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    'rvt_conv_dgrad4': [_vp] * 4 + [_i] * 6 + [_vp],
     'rvt_conv_dgrad': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     'rvt_conv_wgrad': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     'rvt_stem_fwd': [_vp] * 6 + [_i] * 8 + [_f, _vp],
@@ -63,7 +64,7 @@ _SIGS = {
 EXPORTS = sorted(list(_SIGS) + ['rvt_last_error', 'rvt_is_emulator', 'rvt_wgrad_workspace_floats',
                                'rvt_mlp_fused_supported', 'rvt_lstm_scan_supported', 'rvt_mlp_bwd_fused_supported',
                                'rvt_mlp_bwd_fused_ws_floats', 'rvt_attn_block_supported', 'rvt_lstm_scan_bwd_ws_floats',
-                               'rvt_lstm_scan_saves_gates', 'rvt_stem_supported', 'rvt_stem_wgrad_ws_floats'])
+                               'rvt_lstm_scan_saves_gates', 'rvt_stem_supported', 'rvt_stem_wgrad_ws_floats', 'rvt_conv_dgrad4_supported'])
 
 
 def _bind(lib: ctypes.CDLL) -> ctypes.CDLL:
@@ -89,6 +90,8 @@ def _bind(lib: ctypes.CDLL) -> ctypes.CDLL:
     lib.rvt_attn_block_supported.argtypes = [_i, _i, _i, _i]
     lib.rvt_lstm_scan_supported.restype = ctypes.c_int
     lib.rvt_lstm_scan_supported.argtypes = [_i, _i]
+    lib.rvt_conv_dgrad4_supported.restype = ctypes.c_int
+    lib.rvt_conv_dgrad4_supported.argtypes = [_i] * 9
     lib.rvt_stem_supported.restype = ctypes.c_int
     lib.rvt_stem_supported.argtypes = [_i] * 8
     lib.rvt_stem_wgrad_ws_floats.restype = ctypes.c_size_t

@@ -301,6 +301,40 @@ int rvt_stem_wgrad(const void* src, const void* dy, float* dw, float* ws, int dt
     return stem_wgrad_launch(src, dy, nullptr, nullptr, nullptr, nullptr, dw, ws, dtype, F, Cin, cp, h, wd, H, W, 0.f, stream);
 }
 
+// The same input gradient for the 3 x 3 / stride 2 / pad 1 convs of stages 2-4 as ONE product over 2 x 2 input-pixel blocks
+// (ppgemm.hpp, GATHER): wd4 = [4 Cin][4 Cout] block-sparse weights (PACK_CONV_DGRAD4).  Measured against the four
+// parity-class launches above: profiles/r3/microbench_conv_dgrad4.txt.
+int rvt_conv_dgrad4_supported(int dtype, int H, int W, int Cin, int Cout, int k, int stride, int pad, int F) {
+    if (dtype != RVT_BF16 || k != 3 || stride != 2 || pad != 1 || (H & 1) || (W & 1)) return 0;
+    if (Cin % 64 != 0 || Cin > 512 || Cout % 64 != 0) return 0;
+    const long long M = (long long)F * (H / 2) * (W / 2);
+    if (M * Cout * 2 >= (1ll << 31) || (long long)F * H * W * Cin * 2 >= (1ll << 32)) return 0;
+    return use_ppgemm(dtype, (int)M, 4 * Cin, 4 * Cout, Cout, 4 * Cout, 4 * Cout) ? 1 : 0;
+}
+int rvt_conv_dgrad4(const void* dy, const void* wd4, const void* add, void* din, int dtype, int F, int H, int W, int Cin, int Cout,
+                    void* stream) {
+    RVT_CHECK(rvt_conv_dgrad4_supported(dtype, H, W, Cin, Cout, 3, 2, 1, F), "conv_dgrad4: unsupported shape H=%d W=%d Cin=%d Cout=%d", H, W, Cin, Cout);
+    hipStream_t st = (hipStream_t)stream;
+    PPConv cv;
+    cv.Ho = H / 2; cv.Wo = W / 2; cv.Cout = Cout; cv.H = H; cv.W = W; cv.Cin = Cin;
+    cv.dHoWo = FastDiv(cv.Ho * cv.Wo); cv.dWo = FastDiv(cv.Wo);
+    const int N = 4 * Cin, n_tiles = N / 256;
+    for (int nt = 0; nt < 4; nt++) {
+        int mask = 0;
+        if (nt < n_tiles)
+            for (int cls = (nt * 256) / Cin; cls <= (nt * 256 + 255) / Cin; cls++)
+                for (int da = 0; da <= (cls >> 1); da++)
+                    for (int db = 0; db <= (cls & 1); db++) mask |= 1 << (2 * da + db);
+        cv.taps[nt] = mask ? mask : 1;
+    }
+    const int M = F * cv.Ho * cv.Wo;
+    const PPMat xs{(const bf16*)dy, (const bf16*)dy, Cout, 1 << 30}, ws{(const bf16*)wd4, (const bf16*)wd4, 4 * Cout, 1 << 30};
+    const PPEpArgs ep{(bf16*)din, nullptr, (const bf16*)add, nullptr, nullptr, Cin};
+    if (add) launch_ppgemm<PP_ADD, 1>(xs, ws, ep, M, N, 4 * Cout, st, cv);
+    else launch_ppgemm<PP_STORE, 1>(xs, ws, ep, M, N, 4 * Cout, st, cv);
+    return check_launch("conv_dgrad4");
+}
+
 int rvt_conv_dgrad(const void* dy, const void* wd, const void* add, void* din, int dtype, int F, int H, int W, int Cin,
                    int Cout, int k, int stride, int pad, void* stream) {
     RVT_CHECK(Cin % 8 == 0 && Cout % 8 == 0, "conv_dgrad: channels must be multiples of 8");
@@ -405,7 +439,7 @@ int rvt_linear_scale_res_fwd(const void* x, const void* w, const float* bias, co
     RVT_CHECK(N % 8 == 0 && K % 8 == 0, "linear_scale_res_fwd: N=%d K=%d must be multiples of 8", N, K);
     RVT_CHECK(bias && gamma && res, "linear_scale_res_fwd: bias, gamma and res are required");
     hipStream_t st = (hipStream_t)stream;
-    if (!gelu_in && N <= PPGeom::MAX_CST / 2 && K >= pp_min_k(1024) && use_ppgemm(dtype, M, N, K, K, K, K)) {
+    if (!gelu_in && N <= PPGeom::MAX_CST / 2 && use_ppgemm(dtype, M, N, K, K, K, K)) {
         launch_ppgemm<PP_SCALE_RES>(PPMat{(const bf16*)x, (const bf16*)x, K, K}, PPMat{(const bf16*)w, (const bf16*)w, K, K},
                                     PPEpArgs{(bf16*)y, nullptr, (const bf16*)res, bias, gamma, N}, M, N, K, st);
         return check_launch("linear_scale_res_fwd");
@@ -428,9 +462,8 @@ int rvt_linear_dgrad(const void* dy, const void* wt, const void* gelu_pre, const
     RVT_CHECK((gelu_pre != nullptr) + (add != nullptr) + (mul != nullptr) <= 1,
               "linear_dgrad: gelu_pre, add and mul are mutually exclusive");
     hipStream_t st = (hipStream_t)stream;
-    // dx[M][K] = dy[M][N] . wt[K][N]^T: output width K, contraction N.  With a side input (add / mul) the epilogue's late loads
-    // drain the load stream once per flushed block: only worth it for long contractions (measured: N >= 1024)
-    if (!gelu_pre && (!(add || mul) || N >= pp_min_k(1024)) && use_ppgemm(dtype, M, K, N, N, N, N)) {
+    // dx[M][K] = dy[M][N] . wt[K][N]^T: output width K, contraction N
+    if (!gelu_pre && use_ppgemm(dtype, M, K, N, N, N, N)) {
         const PPMat xs{(const bf16*)dy, (const bf16*)dy, N, N}, ws{(const bf16*)wt, (const bf16*)wt, N, N};
         if (mul) launch_ppgemm<PP_MUL>(xs, ws, PPEpArgs{(bf16*)dx, nullptr, (const bf16*)mul, nullptr, nullptr, K}, M, K, N, st);
         else if (add) launch_ppgemm<PP_ADD>(xs, ws, PPEpArgs{(bf16*)dx, nullptr, (const bf16*)add, nullptr, nullptr, K}, M, K, N, st);

@@ -16,7 +16,9 @@ enum PackKind {
     PACK_CONV_FWD = 2,       // src [Cout][Cin][k][k] -> dst [Cout][k*k*cp] tap-major, cin fastest, zero padded (d0..d3 = Cout,Cin,k,cp)
     PACK_CONV_DGRAD = 3,     // src [Cout][Cin][k][k] -> dst [Cin][nky*nkx*Cout] of one stride-parity class (d0..d4 = Cout,Cin,k,nky,nkx)
     PACK_LSTM_ROWS = 4,      // src [4C][K] -> dst rows interleaved n' = (c/8)*32 + gate*8 + c%8            (d0 = C, d1 = K)
-    PACK_CONV_WGRAD_ACC = 5  // src [Cout][k*k*cp] (raw fp32 product) -> dst [Cout][Cin][k][k] += ...      (d0..d3 = Cout,Cin,k,cp)
+    PACK_CONV_WGRAD_ACC = 5, // src [Cout][k*k*cp] (raw fp32 product) -> dst [Cout][Cin][k][k] += ...      (d0..d3 = Cout,Cin,k,cp)
+    PACK_CONV_DGRAD4 = 6     // src [Cout][Cin][3][3] -> dst [(py,px,ci)][(da,db,co)] of the 2 x 2-block input gradient (ppgemm.hpp
+                             // GATHER; d0, d1 = Cout, Cin): w[co][ci][ky][kx], ky = 1 | 2, 0 for py = 0 | 1 and da = 0, 1; else 0
 };
 
 struct PackDesc {             // 96 bytes; mirrored by rvt_amd/weights.py (numpy structured dtype)
@@ -81,6 +83,16 @@ pack_table_kernel(const PackDesc* __restrict__ descs, int nd) {
             const int np = (int)(i / K), kc = (int)(i % K);
             const int c = (np / 32) * 8 + np % 8, gate = (np % 32) / 8;
             v = d.src[(size_t)(gate * C + c) * K + kc];
+            break;
+        }
+        case PACK_CONV_DGRAD4: {
+            const int Cout = d.d[0], Cin = d.d[1];
+            const int n = (int)(i / (4 * Cout)), kc = (int)(i % (4 * Cout));
+            const int cls = n / Cin, ci = n % Cin, tap = kc / Cout, co = kc % Cout;
+            const int py = cls >> 1, px = cls & 1, da = tap >> 1, db = tap & 1;
+            const bool on = (py == 1 || da == 0) && (px == 1 || db == 0);
+            const int ky = py == 0 ? 1 : (da == 0 ? 2 : 0), kx = px == 0 ? 1 : (db == 0 ? 2 : 0);
+            v = on ? d.src[(((size_t)co * Cin + ci) * 3 + ky) * 3 + kx] : 0.f;
             break;
         }
         case PACK_CONV_WGRAD_ACC: {

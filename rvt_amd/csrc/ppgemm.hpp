@@ -120,27 +120,44 @@ struct PPWork {
     }
 };
 
+// GATHER = 1: input gradient of the 3 x 3 / stride 2 / pad 1 down-sampling conv (reference maxvit.py:160-168, autograd) as ONE
+// product.  Row m = (frame, a, b) = the 2 x 2 block of input pixels (2a + py, 2b + px); its four pixels only see the four dY
+// pixels (a + da, b + db), da, db in {0, 1} (ky = 1 | 2, 0 for py = 0 | 1 and da = 0, 1; the same in x):
+//     [dIn(2a+py, 2b+px)]_{py,px}  =  [dY(a+da, b+db)]_{da,db}  .  Wd4^T,    Wd4[(py,px,ci)][(da,db,co)] = w[co][ci][ky][kx] or 0
+// The X operand is the dY tensor itself: the K tiles of tap (da, db) read row m + da Wo + db (one scalar offset per step; lanes
+// whose tap leaves the image or whose row is beyond M get an out-of-range address = zeros), the output row is scattered to its
+// four pixels (wave column -> (py, px, channel block)).  7 of the 16 (class, tap) blocks of Wd4 are zero: an N tile only walks the
+// taps one of its classes uses (taps[nt] bit mask): all 16 / 16 for Cin = 64, 12 / 16 for Cin = 128, 9 / 16 for Cin = 256.
+struct PPConv {
+    int Ho, Wo, Cout, H, W, Cin;          // dY [F][Ho][Wo][Cout], dIn [F][H][W][Cin]
+    FastDiv dHoWo, dWo;
+    int taps[4];                          // per N tile: bit (2 da + db)
+};
+
 // ABL: ablation bits for profiles/probes/ppgemm_probe.hip (0 in the library): 1 no LDS-DMA / vmcnt waits, 2 no fragment reads,
 // 4 no MFMAs, 8 no barriers, 16 no epilogue, 32 epilogue stores dropped (empty output buffer)
-template <int EP, int ABL = 0>
+template <int EP, int ABL = 0, int GATHER = 0>
 __global__ void __launch_bounds__(512, 2)
-ppgemm_kernel(PPMat X, PPMat W, PPEpArgs ep, int M, int N, int K, int m_tiles, int n_tiles) {
+ppgemm_kernel(PPMat X, PPMat W, PPEpArgs ep, int M, int N, int K, int m_tiles, int n_tiles, PPConv cv) {
     typedef PPGeom G;
     __shared__ __attribute__((aligned(16))) char smem[G::SMEM];
     float* const cst = reinterpret_cast<float*>(smem + G::OFF_CST);
-    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int tid = threadIdx.x, lane_ = tid & 63, lane = lane_, l31 = lane & 31, hi = lane >> 5;
     const int wave = wave_uniform(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
-    const int nk = K / G::BK;
+    const int cpt = GATHER ? cv.Cout / G::BK : 0;     // K tiles per tap
+    auto nk_of = [&](int nt) __attribute__((always_inline)) { return GATHER ? __builtin_popcount(cv.taps[nt & 3]) * cpt : K / G::BK; };
     constexpr bool SIDE = EP == PP_ADD || EP == PP_SCALE_RES || EP == PP_MUL;
-    // vector memory instructions of one flushed row block (32 rows x 64 columns per wave): 4 stores of 8 full rows each
-    // (twice for the second output of PP_GELU_DUAL), 4 side-input loads
-    constexpr int EPI_OPS = (EP == PP_GELU_DUAL ? 8 : 4) + (SIDE ? 4 : 0);
 
     PPWork work;
     work.init(blockIdx.x, gridDim.x, m_tiles, n_tiles);
     if (work.count == 0) return;
-    const int nsteps = work.count * nk;
+    int nsteps = 0;
+    if (GATHER) {
+        for (int u = 0; u < work.count; u++) { int mt_, nt_; work.tile(u, mt_, nt_); nsteps += nk_of(nt_); }
+    } else {
+        nsteps = work.count * nk_of(0);
+    }
 
     // per-column constants -> LDS (before the load stream starts: these are ordinary loads)
     const int c1off = EP == PP_SCALE_RES ? N : 0;
@@ -164,30 +181,66 @@ ppgemm_kernel(PPMat X, PPMat W, PPEpArgs ep, int M, int N, int K, int m_tiles, i
     const int waddr0 = G::OFF_W + wc * G::UNIT + l31 * 128 + ((hi ^ swz) << 4);  // + j * 32 rows
 
     // descriptors of the steps s+1 and s+2
-    struct Desc { pp_rsrc rx, rw; int sx, sw; };
+    struct Desc { pp_rsrc rx, rw; int sx, sw, da, db, mask; };
     int lu = 0, lkt = 0, lstep = 0;                  // load-side (item, K tile, step)
+    int gmask = 0;                                   // GATHER, current load-side tile: bit i: row of unit i is beyond M; 4 + i: a == Ho - 1; 8 + i: b == Wo - 1
     auto next_desc = [&]() -> Desc {
         Desc d;
+        d.da = 0; d.db = 0; d.mask = 0;
         if (lstep < nsteps) {
             int mt, nt;
             work.tile(lu, mt, nt);
-            const int k0 = lkt * G::BK;
-            const bool seg = k0 >= X.kcut;
-            const bf16* xb = (seg ? X.p1 : X.p0) + (size_t)mt * G::BM * X.ld;
-            const int rows = M - mt * G::BM;
-            d.rx = pp_make_rsrc(xb, (unsigned)((rows > G::BM ? G::BM : rows) * X.ld * 2));
-            d.sx = (seg ? k0 - X.kcut : k0) * 2;
-            d.rw = pp_make_rsrc(W.p0 + (size_t)nt * G::BN * W.ld, (unsigned)(G::BN * W.ld * 2));
-            d.sw = k0 * 2;
+            if (GATHER) {
+                if (lkt == 0) {                      // new tile on the load side: border / tail masks of this lane's four rows
+                    gmask = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int m = mt * G::BM + (lr >> 5) * 128 + i * 32 + (lr & 31);
+                        uint32_t f, rem, a, b;
+                        cv.dHoWo.divmod((uint32_t)(m < M ? m : 0), f, rem);
+                        cv.dWo.divmod(rem, a, b);
+                        gmask |= (m >= M ? 1 : 0) << i;
+                        gmask |= ((int)a == cv.Ho - 1 ? 1 : 0) << (4 + i);
+                        gmask |= ((int)b == cv.Wo - 1 ? 1 : 0) << (8 + i);
+                    }
+                }
+                const int tidx = lkt / cpt, coff = (lkt - tidx * cpt) * G::BK;
+                int tap = 0, cnt = 0;
+#pragma unroll
+                for (int t = 0; t < 4; t++) {        // the tidx-th tap of this N tile
+                    const int on = (cv.taps[nt & 3] >> t) & 1;
+                    if (on && cnt == tidx) tap = t;
+                    cnt += on;
+                }
+                d.da = tap >> 1; d.db = tap & 1; d.mask = gmask;
+                d.rx = pp_make_rsrc(X.p0, (unsigned)((size_t)M * X.ld * 2));
+                d.sx = (mt * G::BM * X.ld + (d.da * cv.Wo + d.db) * cv.Cout + coff) * 2;
+                d.rw = pp_make_rsrc(W.p0 + (size_t)nt * G::BN * W.ld, (unsigned)(G::BN * W.ld * 2));
+                d.sw = (tap * cv.Cout + coff) * 2;
+            } else {
+                const int k0 = lkt * G::BK;
+                const bool seg = k0 >= X.kcut;
+                const bf16* xb = (seg ? X.p1 : X.p0) + (size_t)mt * G::BM * X.ld;
+                const int rows = M - mt * G::BM;
+                d.rx = pp_make_rsrc(xb, (unsigned)((rows > G::BM ? G::BM : rows) * X.ld * 2));
+                d.sx = (seg ? k0 - X.kcut : k0) * 2;
+                d.rw = pp_make_rsrc(W.p0 + (size_t)nt * G::BN * W.ld, (unsigned)(G::BN * W.ld * 2));
+                d.sw = k0 * 2;
+            }
+            if (++lkt == nk_of(nt)) { lkt = 0; lu++; }
         } else {                                     // past the end: empty buffers (zeros to LDS, no memory traffic) keep the counts uniform
             d.rx = pp_make_rsrc(X.p0, 0u); d.rw = pp_make_rsrc(W.p0, 0u); d.sx = 0; d.sw = 0;
         }
         lstep++;
-        if (++lkt == nk) { lkt = 0; lu++; }
         return d;
     };
     auto issue_x = [&](const Desc& d, int stage, int i) __attribute__((always_inline)) {
-        if (!(ABL & 1)) pp_glds16(d.rx, smem, stage * G::STAGE + i * G::UNIT + lds0, vx0 + i * ldx64, d.sx);
+        int v = vx0 + i * ldx64;
+        if (GATHER) {
+            const bool kill = ((d.mask >> i) & 1) | (d.da & (d.mask >> (4 + i)) & 1) | (d.db & (d.mask >> (8 + i)) & 1);
+            v = kill ? 0x40000000 : v;               // out of range whatever the scalar offset: the DMA writes zeros
+        }
+        if (!(ABL & 1)) pp_glds16(d.rx, smem, stage * G::STAGE + i * G::UNIT + lds0, v, d.sx);
     };
     auto issue_w = [&](const Desc& d, int stage, int g) __attribute__((always_inline)) {
         if (!(ABL & 1)) pp_glds16(d.rw, smem, stage * G::STAGE + G::OFF_W + g * G::UNIT + lds0, vw0 + g * ldw128, d.sw);
@@ -197,12 +250,15 @@ ppgemm_kernel(PPMat X, PPMat W, PPEpArgs ep, int M, int N, int K, int m_tiles, i
     bf16x8 xf[4], wf[2][4];
 
     // Output descriptors of the tile being flushed (base = first row of the tile, extent = its valid rows)
-    struct OutDesc { pp_rsrc out, out2, side; int n0; };
+    struct OutDesc { pp_rsrc out, out2, side; int n0, m0; };
     auto out_desc = [&](int mt, int nt) -> OutDesc {
         OutDesc o;
         const int rows = M - mt * G::BM;
-        const unsigned bytes = (unsigned)((rows > G::BM ? G::BM : rows) * ep.ld * 2);
-        const size_t base = (size_t)mt * G::BM * ep.ld;
+        // (GATHER: the rows scatter over the whole dIn tensor: one descriptor for all of it, offsets from its start)
+        const unsigned bytes = GATHER ? (unsigned)((size_t)(M / (cv.Ho * cv.Wo)) * cv.H * cv.W * cv.Cin * 2)
+                                      : (unsigned)((rows > G::BM ? G::BM : rows) * ep.ld * 2);
+        const size_t base = GATHER ? 0 : (size_t)mt * G::BM * ep.ld;
+        o.m0 = mt * G::BM;
         o.out = pp_make_rsrc(ep.out + base, (ABL & 32) ? 0u : bytes);          // (ABL 32: stores issued but dropped)
         o.out2 = pp_make_rsrc(ep.out2 ? ep.out2 + base : ep.out, ep.out2 ? bytes : 0u);
         o.side = pp_make_rsrc(ep.side ? ep.side + base : ep.out, ep.side ? bytes : 0u);
@@ -214,13 +270,46 @@ ppgemm_kernel(PPMat X, PPMat W, PPEpArgs ep, int M, int N, int K, int m_tiles, i
     // pair's LDS scratch and come back as 16-byte pieces of FULL 128-byte rows: lane -> (row it * 8 + lane / 8, piece lane % 8),
     // so that a store instruction writes 8 complete rows.  Side inputs (residual / factor) are loaded and applied in that row form.
     char* const scr = smem + G::OFF_SCR + wc * G::SCR_BYTES;
-    auto flush_block = [&](int i, const OutDesc& od) __attribute__((always_inline)) {
+    // global offset of the 16-byte piece (row it * 8 + lane / 8 of block i, piece lane % 8) of the tile being flushed
+    auto row_voff = [&](int i, int it, const OutDesc& od, int lane) __attribute__((always_inline)) {
+        const int r = wr * 128 + i * 32 + it * 8 + (lane >> 3), pc = lane & 7, colb = od.n0 + wc * 64;
+        int voff = (r * ep.ld + colb + 8 * pc) * 2;
+        if (GATHER) {                                 // row (frame, a, b), wave column (py, px, channel block) -> pixel (2a + py, 2b + px)
+            const int m = od.m0 + r;
+            uint32_t f, rem, a, b;
+            cv.dHoWo.divmod((uint32_t)(m < M ? m : 0), f, rem);
+            cv.dWo.divmod(rem, a, b);
+            const int cls = colb / cv.Cin, cb = colb - cls * cv.Cin;
+            const int pix = ((int)f * cv.H + 2 * (int)a + (cls >> 1)) * cv.W + 2 * (int)b + (cls & 1);
+            voff = m < M ? (pix * cv.Cin + cb + 8 * pc) * 2 : (int)0xfffffff0u;
+        }
+        return voff;
+    };
+    // side rows (residual / factor / added cotangent) of block i, in the row form the stores use.  Issued ONE flushed block ahead
+    // (step_body): vmcnt retires in order, so a load issued right before its use would wait for every LDS-DMA piece in flight.
+    auto side_load = [&](int i, const OutDesc& od, u32x4 (&sd)[4]) __attribute__((always_inline)) {
+        if (!SIDE || (ABL & 16)) return;
+        int lane = lane_;
+#ifndef RVT_EMU
+        asm volatile("" : "+v"(lane));
+#endif
+#pragma unroll
+        for (int it = 0; it < 4; it++) sd[it] = pp_load16(od.side, row_voff(i, it, od, lane));
+    };
+    auto flush_block = [&](int i, const OutDesc& od, const u32x4 (&sd)[4]) __attribute__((always_inline)) {
         if (ABL & 16) {                               // keep the accumulators alive (or the MFMAs are dead code)
 #ifndef RVT_EMU
             asm volatile("" ::"v"(acc[i][0]), "v"(acc[i][1]));
 #endif
             return;
         }
+        // everything lane-derived below is recomputed per flush from an OPAQUE copy of the lane id: hoisted out of the step loop these
+        // per-lane addresses cost registers the main loop does not have (spills there = vmcnt(0) drains of the load stream)
+        int lane = lane_, l31, hi;
+#ifndef RVT_EMU
+        asm volatile("" : "+v"(lane));
+#endif
+        l31 = lane & 31; hi = lane >> 5;
         const int row0 = wr * 128 + i * 32;           // first tile row of the block
         const int colb = od.n0 + wc * 64;             // first column
         typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
@@ -262,13 +351,12 @@ ppgemm_kernel(PPMat X, PPMat W, PPEpArgs ep, int M, int N, int K, int m_tiles, i
 #pragma unroll
             for (int it = 0; it < 4; it++) {
                 const int r = it * 8 + (lane >> 3), pc = lane & 7;
-                const int voff = ((row0 + r) * ep.ld + colb + 8 * pc) * 2;
+                const int voff = row_voff(i, it, od, lane);
                 u32x4 t = *reinterpret_cast<const u32x4*>(scr + r * G::SCR_LD + pc * 16);
                 if (SIDE && apply_side) {
-                    const u32x4 sdv = pp_load16(od.side, voff);
                     bf16x8 a, b;
                     __builtin_memcpy(&a, &t, 16);
-                    __builtin_memcpy(&b, &sdv, 16);
+                    __builtin_memcpy(&b, &sd[it], 16);
                     float o[8];
 #pragma unroll
                     for (int e = 0; e < 8; e++) o[e] = EP == PP_MUL ? (float)a[e] * (float)b[e] : (float)a[e] + (float)b[e];
@@ -336,9 +424,16 @@ ppgemm_kernel(PPMat X, PPMat W, PPEpArgs ep, int M, int N, int K, int m_tiles, i
     auto step_body = [&](auto mode_c) __attribute__((always_inline)) {
         constexpr int MODE = decltype(mode_c)::value;
         constexpr bool FIRST = MODE == 1 || MODE == 3, FLUSH = MODE == 1;
-        constexpr int E = (ABL & 16) ? 0 : EPI_OPS + ((ABL & 64) ? 4 : 0);     // (ABL 64, timing probe only: counts too lax)
-        constexpr int W0 = 8 + (MODE == 2 ? 4 * E : 0), W1 = 9 + (MODE == 1 ? E : MODE == 2 ? 3 * E : 0),
-                      W2 = 10 + (MODE == 1 ? 2 * E : MODE == 2 ? 3 * E : 0), W3 = 7 + (MODE == 1 ? 3 * E : 0);
+        // vector memory instructions issued by the flush phases p0..p3 of a MODE 1 step: the block's stores, the side rows of the
+        // NEXT block (p0: of blocks 0 and 1)
+        constexpr int ST = (ABL & 16) ? 0 : (EP == PP_GELU_DUAL ? 8 : 4) + ((ABL & 64) ? 4 : 0);      // (ABL 64, timing probe only: counts too lax)
+        constexpr int SL = (SIDE && !(ABL & 16)) ? 4 : 0;
+        // (GATHER: the scatter addresses leave no registers for a second set of side rows: they are loaded right before their use)
+        constexpr bool PREF = !GATHER;
+        constexpr int E0 = ST + (PREF ? 2 * SL : SL), E1 = ST + SL, E2 = ST + SL, E3 = ST + (PREF ? 0 : SL);
+        constexpr int W0 = 8 + (MODE == 2 ? E0 + E1 + E2 + E3 : 0), W1 = 9 + (MODE == 1 ? E0 : MODE == 2 ? E1 + E2 + E3 : 0),
+                      W2 = 10 + (MODE == 1 ? E0 + E1 : MODE == 2 ? E1 + E2 + E3 : 0), W3 = 7 + (MODE == 1 ? E0 + E1 + E2 : 0);
+        u32x4 sda[4], sdb[4];
         int st = (s & 1) * G::STAGE;
 #ifndef RVT_EMU
         asm volatile("" : "+v"(st));                  // opaque: the fragment addresses are formed per step from two base registers (hoisted, they spill)
@@ -356,7 +451,7 @@ ppgemm_kernel(PPMat X, PPMat W, PPEpArgs ep, int M, int N, int K, int m_tiles, i
         // ---------------- phase 0 ----------------
         issue_x(d1, (s + 1) & 1, 0); issue_x(d1, (s + 1) & 1, 1);
         if (!(ABL & 1)) pp_wait_vm<W0>();
-        if (FLUSH) flush_block(0, od);
+        if (FLUSH) { side_load(0, od, sda); if (PREF) side_load(1, od, sdb); flush_block(0, od, sda); }
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) { wf[0][ks] = wfrag(st, 0, ks); xf[ks] = xfrag(st, 0, ks); wf[1][ks] = wfrag(st, 1, ks); }
         bar();
@@ -365,7 +460,7 @@ ppgemm_kernel(PPMat X, PPMat W, PPEpArgs ep, int M, int N, int K, int m_tiles, i
         // ---------------- phase 1 ----------------
         issue_x(d1, (s + 1) & 1, 2); issue_x(d1, (s + 1) & 1, 3);
         if (!(ABL & 1)) pp_wait_vm<W1>();
-        if (FLUSH) flush_block(1, od);
+        if (FLUSH) { if (PREF) { side_load(2, od, sda); flush_block(1, od, sdb); } else { side_load(1, od, sda); flush_block(1, od, sda); } }
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) xf[ks] = xfrag(st, 1, ks);
         bar();
@@ -374,7 +469,7 @@ ppgemm_kernel(PPMat X, PPMat W, PPEpArgs ep, int M, int N, int K, int m_tiles, i
         // ---------------- phase 2 ----------------
         issue_w(d2, s & 1, 0); issue_w(d2, s & 1, 1);
         if (!(ABL & 1)) pp_wait_vm<W2>();
-        if (FLUSH) flush_block(2, od);
+        if (FLUSH) { if (PREF) { side_load(3, od, sdb); flush_block(2, od, sda); } else { side_load(2, od, sda); flush_block(2, od, sda); } }
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) xf[ks] = xfrag(st, 2, ks);
         bar();
@@ -383,7 +478,7 @@ ppgemm_kernel(PPMat X, PPMat W, PPEpArgs ep, int M, int N, int K, int m_tiles, i
         // ---------------- phase 3 ----------------
         issue_w(d2, s & 1, 2); issue_w(d2, s & 1, 3);
         if (!(ABL & 1)) pp_wait_vm<W3>();
-        if (FLUSH) flush_block(3, od);
+        if (FLUSH) { if (PREF) flush_block(3, od, sdb); else { side_load(3, od, sda); flush_block(3, od, sda); } }
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) xf[ks] = xfrag(st, 3, ks);
         bar();
@@ -396,6 +491,7 @@ ppgemm_kernel(PPMat X, PPMat W, PPEpArgs ep, int M, int N, int K, int m_tiles, i
     for (int u = 0; u < work.count; u++) {
         int mt, nt;
         work.tile(u, mt, nt);
+        const int nk = nk_of(nt);
         if (u == 0) {
             step_body(std::integral_constant<int, 3>());
             for (int kt = 1; kt < nk; kt++) step_body(std::integral_constant<int, 0>());
@@ -411,12 +507,12 @@ ppgemm_kernel(PPMat X, PPMat W, PPEpArgs ep, int M, int N, int K, int m_tiles, i
     // last tile: the two waves of a pair share a scratch, so the groups flush one after the other
     if (wr == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) flush_block(i, od);
+        for (int i = 0; i < 4; i++) { u32x4 sd[4]; side_load(i, od, sd); flush_block(i, od, sd); }
     }
     pp_barrier();
     if (wr == 1) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) flush_block(i, od);
+        for (int i = 0; i < 4; i++) { u32x4 sd[4]; side_load(i, od, sd); flush_block(i, od, sd); }
     }
 }
 
@@ -427,15 +523,16 @@ inline bool ppgemm_shape_ok(int M, int N, int K, int ldx, int ldw, int kcut) {
            ldw % 8 == 0 && (size_t)256 * (size_t)ldmax * 2 < (1ull << 31);
 }
 
-template <int EP>
-inline void launch_ppgemm(const PPMat& X, const PPMat& W, const PPEpArgs& ep, int M, int N, int K, hipStream_t stream) {
+template <int EP, int GATHER = 0>
+inline void launch_ppgemm(const PPMat& X, const PPMat& W, const PPEpArgs& ep, int M, int N, int K, hipStream_t stream,
+                          const PPConv& cv = PPConv()) {
     const int m_tiles = (M + 255) / 256, n_tiles = N / 256;
     static const int grid_override = getenv("RVT_PPGEMM_GRID") ? atoi(getenv("RVT_PPGEMM_GRID")) : 0;      // (tests: small grids walk several tiles)
     const int total = m_tiles * n_tiles;
     int grid = grid_override > 0 ? grid_override : 256;
     if (grid > ((total + 7) & ~7)) grid = (total + 7) & ~7;
     grid = (grid + 7) & ~7;
-    hipLaunchKernelGGL((ppgemm_kernel<EP>), dim3(grid), dim3(512), 0, stream, X, W, ep, M, N, K, m_tiles, n_tiles);
+    hipLaunchKernelGGL((ppgemm_kernel<EP, 0, GATHER>), dim3(grid), dim3(512), 0, stream, X, W, ep, M, N, K, m_tiles, n_tiles, cv);
 }
 
 }  // namespace rvt

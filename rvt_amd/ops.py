@@ -96,6 +96,20 @@ def stem_wgrad(src: Tensor, dy: Tensor, dw: Tensor, H: int, W: int) -> None:
     L.call('rvt_stem_wgrad', L.ptr(src), L.ptr(dy), L.ptr(dw), L.ptr(ws), L.dtype_code(dy.dtype), F_, Cin, cp, h, wd, H, W, st)
 
 
+def conv_dgrad4_supported(dtype: torch.dtype, H: int, W: int, Cin: int, Cout: int, k: int, stride: int, pad: int, F_: int) -> bool:
+    return dtype in L._DT and bool(L.get_lib().rvt_conv_dgrad4_supported(L.dtype_code(dtype), H, W, Cin, Cout, k, stride, pad, F_))
+
+
+def conv_dgrad4(dy: Tensor, wd4: Tensor, add: Optional[Tensor], H: int, W: int, Cin: int) -> Tensor:
+    """Input gradient of the 3x3 / stride-2 / pad-1 conv in one launch (2x2 input-pixel blocks; wd4 = weights.pack PACK_CONV_DGRAD4)."""
+    F_, Ho, Wo, Cout = dy.shape
+    assert tuple(wd4.shape) == (4 * Cin, 4 * Cout) and H == 2 * Ho and W == 2 * Wo
+    din = torch.empty((F_, H, W, Cin), dtype=dy.dtype, device=dy.device)
+    L.call('rvt_conv_dgrad4', L.ptr(dy), L.ptr(wd4), L.ptr(add), L.ptr(din), L.dtype_code(dy.dtype), F_, H, W, Cin, Cout,
+           L.stream_of(dy))
+    return din
+
+
 def conv_dgrad(dy: Tensor, wd: Tensor, add: Optional[Tensor], H: int, W: int, Cin: int, k: int, stride: int, pad: int,
                out: Optional[Tensor] = None) -> Tensor:
     F_, Ho, Wo, Cout = dy.shape

@@ -413,6 +413,10 @@ def stage_seq_backward(sw: StageWeights, g: StageGeom, sv: StageSaved, dH: Optio
     side.run(conv_wgrad_fn, sv.inp, dy0)
     d_in = None
     if need_input_grad:
-        d_in = ops.conv_dgrad(dy0, sw.conv_wd, prev_cot, g.H_in, g.W_in, g.Cin, g.k, g.stride, g.pad)
+        if sw.conv_wd4 is not None and os.environ.get('RVT_CONV_DGRAD4', '1') != '0' and \
+                ops.conv_dgrad4_supported(dt, g.H_in, g.W_in, g.Cin, C, g.k, g.stride, g.pad, F_):
+            d_in = ops.conv_dgrad4(dy0, sw.conv_wd4, prev_cot, g.H_in, g.W_in, g.Cin)      # one launch (2 x 2 pixel blocks)
+        else:
+            d_in = ops.conv_dgrad(dy0, sw.conv_wd, prev_cot, g.H_in, g.W_in, g.Cin, g.k, g.stride, g.pad)
     side.join()             # every parameter gradient of this stage is final from here on (DDP hook, optimizer)
     return d_in, dh0, dc0

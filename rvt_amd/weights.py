@@ -24,7 +24,7 @@ from . import _lib as L
 
 Tensor = torch.Tensor
 
-PACK_COPY, PACK_TRANSPOSE, PACK_CONV_FWD, PACK_CONV_DGRAD, PACK_LSTM_ROWS, PACK_CONV_WGRAD_ACC = range(6)
+PACK_COPY, PACK_TRANSPOSE, PACK_CONV_FWD, PACK_CONV_DGRAD, PACK_LSTM_ROWS, PACK_CONV_WGRAD_ACC, PACK_CONV_DGRAD4 = range(7)
 PACK_DT = np.dtype([('src', '<u8'), ('dst', '<u8'), ('scale', '<u8'), ('n', '<i8'), ('kind', '<i4'), ('out_f32', '<i4'),
                     ('d', '<i4', (5,)), ('ky', '<i4', (4,)), ('kx', '<i4', (4,)), ('block0', '<u4')])
 LS_DT = np.dtype([('S', '<u8'), ('cs', '<u8'), ('W', '<u8'), ('b', '<u8'), ('gamma', '<u8'), ('dW', '<u8'), ('db', '<u8'),
@@ -169,6 +169,7 @@ class ModelWeights:
     # ---- packed weights ---------------------------------------------------------------------------------
     def _build_stage(self, tab: Optional[_Table], arT: _Arena, ar32: _Arena, p, pre: str, g, need_grad: bool) -> StageWeights:
         m = self.master
+        dtype_is_bf16 = self.dtype == torch.bfloat16
         sw = StageWeights()
         C, Cin, k, stride, pad = g.C, g.Cin, g.k, g.stride, g.pad
         sw.C, sw.Cin, sw.cin_pad = C, Cin, round8(Cin)
@@ -199,6 +200,11 @@ class ModelWeights:
                     _pack_entry(tab, m(wname), sw.conv_wd[off:off + cnt], PACK_CONV_DGRAD, (C, Cin, k, len(ky), len(kx)),
                                 None, ky, kx, n=cnt)
                 off += cnt
+        # ... and the block-sparse [4 Cin][4 Cout] layout of the one-launch input gradient (rvt_conv_dgrad4; 3x3 / 2 / 1 convs)
+        sw.conv_wd4 = None
+        if need_grad and k == 3 and stride == 2 and pad == 1 and Cin % 64 == 0 and C % 64 == 0 and dtype_is_bf16:
+            sw.conv_wd4 = arT.take(4 * Cin, 4 * C)
+            emit(wname, sw.conv_wd4, PACK_CONV_DGRAD4, (C, Cin))
         sw.ln_w, sw.ln_b = (m(pre + 'downsample_cf2cl.norm.weight'), m(pre + 'downsample_cf2cl.norm.bias')) if tab is not None else (None, None)
         sw.blocks = []
         for bi in range(g.num_blocks):
@@ -337,3 +343,20 @@ def lstm_gate_perm(C: int, device) -> Tensor:
     c = (n // 32) * 8 + n % 8
     gate = (n % 32) // 8
     return gate * C + c
+
+
+def pack_conv_dgrad4(w: Tensor, dtype: torch.dtype) -> Tensor:
+    """[4*Cin][4*Cout] block-sparse weights of the one-launch input gradient (rvt_conv_dgrad4; 3x3 / stride 2 / pad 1):
+    row (py, px, ci), column (da, db, co) = w[co][ci][ky][kx] with ky = 1 | 2, 0 for py = 0 | 1 and da = 0, 1 (kx likewise), else 0.
+    Host-side restatement of PACK_CONV_DGRAD4 (csrc/pack.hpp) for the kernel tests."""
+    Cout, Cin, k, _ = w.shape
+    assert k == 3
+    out = torch.zeros(4, Cin, 4, Cout, dtype=torch.float32, device=w.device)
+    for py in range(2):
+        for px in range(2):
+            for da in range(py + 1):
+                for db in range(px + 1):
+                    ky = 1 if py == 0 else (2 if da == 0 else 0)
+                    kx = 1 if px == 0 else (2 if db == 0 else 0)
+                    out[2 * py + px, :, 2 * da + db, :] = w[:, :, ky, kx].t()
+    return out.reshape(4 * Cin, 4 * Cout).to(dtype).contiguous()

@@ -477,6 +477,27 @@ def test_stem(backend, case):
     assert float(pad_cols.abs().max()) == 0.0 if cp > Cin else True
 
 
+@pytest.mark.parametrize('case', [(3, 16, 24, 64, 128), (5, 24, 16, 128, 64), (9, 8, 16, 256, 128)])      # F, H, W, Cin, Cout
+def test_conv_dgrad4(backend, case):
+    """Input gradient of the 3x3 / 2 / 1 conv as one product over 2x2 pixel blocks (csrc/ppgemm.hpp GATHER) vs fp64 autograd and vs
+    the four parity-class launches: image borders, ragged last row tile, with and without an added cotangent, the per-tile tap lists
+    (Cin = 64: one N tile with all taps; 128: two tiles, 2 + 4 taps; 256: four tiles, 1 + 2 + 2 + 4 taps)."""
+    Fr, H, W, Cin, Cout = case
+    dt = torch.bfloat16
+    assert ops.conv_dgrad4_supported(dt, H, W, Cin, Cout, 3, 2, 1, Fr)
+    w = rnd((Cout, Cin, 3, 3), backend, torch.float32, 2, 0.2).to(dt)
+    dy = rnd((Fr, H // 2, W // 2, Cout), backend, dt, 3)
+    add = rnd((Fr, H, W, Cin), backend, dt, 4)
+    xr = torch.zeros(Fr, Cin, H, W, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xr, f64(w), None, 2, 1).backward(f64(dy).permute(0, 3, 1, 2))
+    want = xr.grad.permute(0, 2, 3, 1)
+    wd4 = weights.pack_conv_dgrad4(w.float(), dt)
+    close(ops.conv_dgrad4(dy, wd4, None, H, W, Cin), want, dt, 'conv_dgrad4')
+    close(ops.conv_dgrad4(dy, wd4, add, H, W, Cin), want + f64(add), dt, 'conv_dgrad4 + add')
+    old = ops.conv_dgrad(dy, weights.pack_conv_dgrad(w.float(), 2, 1, dt), add, H, W, Cin, 3, 2, 1)
+    close(ops.conv_dgrad4(dy, wd4, add, H, W, Cin), f64(old), dt, 'conv_dgrad4 vs parity-class route', mult=0.5)
+
+
 @pytest.mark.parametrize('dt', DTYPES)
 @pytest.mark.parametrize('N,H,W,C', [(2, 5, 7, 16), (1, 6, 4, 48), (3, 3, 3, 8)])
 def test_dwconv(backend, dt, N, H, W, C):
