@@ -61,9 +61,10 @@ static inline int wgrad_ksplit(int out_rows, int out_cols, int tokens, int bn) {
     int want = imax(1, (split_override > 0 ? split_override : 512) / imax(1, tiles));
     static const int slice_tokens = getenv("RVT_WGRAD_SLICE_TOKENS") ? imax(64, atoi(getenv("RVT_WGRAD_SLICE_TOKENS"))) : 8192;   // (tests: small)
     int maxs = imax(1, tokens / slice_tokens);
-    // small problems (RVT-Tiny on Gen1: 13 440 / 53 760 tokens at stages 4 / 3): with 8192-token slices a launch is a dozen
-    // workgroups walking hundreds of K tiles each (0.24 ms for 5 GFLOP); 1024-token slices fill the chip
-    if (maxs < 8 && slice_tokens > 1024) maxs = imax(1, tokens / 1024);
+    // problems whose 8192-token slices do not fill the chip once (RVT-Tiny on Gen1: 104 workgroups at stage 1, 24 at stage 2,
+    // each walking hundreds of K tiles - 1.4 TB/s): slices down to 1024 tokens until one workgroup per CU is reached (the
+    // partial tiles of such launches are a few MB against >= 100 MB of operands)
+    if (maxs * tiles < 256 && slice_tokens > 1024) maxs = imax(maxs, imin(imax(1, tokens / 1024), (256 + tiles - 1) / tiles));
     int ks = imin(want, maxs);
     if (ks >= 16) ks = ks / 8 * 8;             // multiple of 8 slices: tiles of one slice can share an XCD's L2
     return ks;

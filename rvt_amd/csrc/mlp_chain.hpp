@@ -99,13 +99,13 @@ mlpc_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, const float* _
                 const float* __restrict__ gamma, int M, float eps) {
     typedef McSmem<T, C> S;
     constexpr int KS = C / 16, NCB = C / 32, HID = 4 * C, NJC = HID / 32;
-    __shared__ __attribute__((aligned(16))) char smem[S::W_1 + S::W_2 + S::NCONST * 4 + GELU_LUT_BYTES];
+    __shared__ __attribute__((aligned(16))) char smem[S::W_1 + S::W_2 + S::NCONST * 4 + GeluTab<T>::BYTES];
     char* const W1_l = smem;
     char* const W2_l = smem + S::W_1;
     float* const kst = reinterpret_cast<float*>(smem + S::W_1 + S::W_2);
     float* const lut = kst + S::NCONST;
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, half = lane >> 5, wave = tid >> 6;
-    gelu_lut_fill<false>(lut, tid, 64 * WPB);
+    GeluTab<T>::template fill<false>(lut, tid, 64 * WPB);
     chain_stage_weights<T, C, false>(W1_l, W1, HID, tid, 64 * WPB);
     chain_stage_weights<T, HID, true>(W2_l, W2, C, tid, 64 * WPB);
     for (int i = tid; i < C; i += 64 * WPB) {
@@ -115,11 +115,23 @@ mlpc_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, const float* _
     __syncthreads();
 
     const int n_tiles = (M + 31) / 32;
+    // the next tile's rows are fetched while this one is computed: with two waves per SIMD nothing else covers the HBM
+    // round trip at the top of a tile (sixteen registers; stores of this tile retire behind the prefetch, in order)
+    frag_t<T> xn[KS];
+    {
+        const int t0 = blockIdx.x * WPB + wave;
+        mc_load_row<T, C>(xn, xmid, t0 * 32 + li, t0 < n_tiles && t0 * 32 + li < M, half);
+    }
     for (int tile = blockIdx.x * WPB + wave; tile < n_tiles; tile += gridDim.x * WPB) {
         const int row = tile * 32 + li;
         const bool valid = row < M;
         frag_t<T> xf[KS], uf[KS];
-        mc_load_row<T, C>(xf, xmid, row, valid, half);
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) xf[ks] = xn[ks];
+        {
+            const int tn = tile + gridDim.x * WPB;
+            mc_load_row<T, C>(xn, xmid, tn * 32 + li, tn < n_tiles && tn * 32 + li < M, half);
+        }
         float mean, rstd;
         mc_layernorm<T, C>(xf, uf, kst + S::K_LNW, kst + S::K_LNB, valid, half, eps, mean, rstd);
         f32x16 oacc[NCB];
@@ -132,9 +144,9 @@ mlpc_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, const float* _
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) mma32(h, opm_load_frag<T>(W1_l, HID, 32 * jc + li, 2 * ks + half), uf[ks]);
             float g[16];
-            gelu_lut_eval16(lut, h, g);
+            GeluTab<T>::eval16(lut, h, g);
 #pragma unroll
-            for (int r = 0; r < 16; r++) g[r] *= h[r];
+            for (int r = 0; r < 16; r++) g[r] = mul_nopack(g[r], h[r], r);
             frag_t<T> gf[2];
             gf[0] = arr_slot_frag<T>(g, 0);
             gf[1] = arr_slot_frag<T>(g, 1);
@@ -176,13 +188,13 @@ mlpc_bwd_dgrad_kernel(const T* __restrict__ dxout, const T* __restrict__ xmid, T
                       float* __restrict__ dln_b, int M, float eps) {
     typedef McSmem<T, C> S;
     constexpr int KS = C / 16, NCB = C / 32, HID = 4 * C, NJC = HID / 32;
-    __shared__ __attribute__((aligned(16))) char smem[2 * S::W_1 + S::NCONST * 4 + GELU_LUT_BYTES];
+    __shared__ __attribute__((aligned(16))) char smem[2 * S::W_1 + S::NCONST * 4 + GeluTab<T>::BYTES];
     char* const W1_l = smem;
     char* const W2_l = smem + S::W_1;                                // (W2 gamma)^T: [4C rows][C]
     float* const kst = reinterpret_cast<float*>(smem + 2 * S::W_1);
     float* const lut = kst + S::NCONST;
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, half = lane >> 5, wave = tid >> 6;
-    gelu_lut_fill<true>(lut, tid, 64 * WPB);
+    GeluTab<T>::template fill<true>(lut, tid, 64 * WPB);
     chain_stage_weights<T, C, false>(W1_l, W1, HID, tid, 64 * WPB);
     chain_stage_weights<T, C, false>(W2_l, W2gT, HID, tid, 64 * WPB);
     for (int i = tid; i < C; i += 64 * WPB) { kst[S::K_LNW + i] = ln_w[i]; kst[S::K_LNB + i] = ln_b[i]; }
@@ -224,9 +236,9 @@ mlpc_bwd_dgrad_kernel(const T* __restrict__ dxout, const T* __restrict__ xmid, T
                 mma32(dg, opm_load_frag<T>(W2_l, HID, 32 * jc + li, 2 * ks + half), df[ks]);
             }
             float dh[16];
-            gelu_lut_eval16(lut, h, dh);
+            GeluTab<T>::eval16(lut, h, dh);
 #pragma unroll
-            for (int r = 0; r < 16; r++) dh[r] *= dg[r];
+            for (int r = 0; r < 16; r++) dh[r] = mul_nopack(dh[r], dg[r], r);
             frag_t<T> dhf[2];
             dhf[0] = arr_slot_frag<T>(dh, 0);
             dhf[1] = arr_slot_frag<T>(dh, 1);
@@ -311,7 +323,7 @@ mlpc_bwd_dgrad_kernel(const T* __restrict__ dxout, const T* __restrict__ xmid, T
 //            registers = the tile's tokens in accumulator order;
 //   dW1, S2  contract over the TOKENS: one operand is g / dh straight from those accumulator registers, the other is
 //            v2^T / dxout^T = ds_read_b64_tr_b16 on the row-major tiles, addressed in the same (accumulator) token order.
-// No identity-MFMA transposes, no copies of the hidden activations anywhere; GELU and GELU' come from one 16-byte table gather.
+// No identity-MFMA transposes, no copies of the hidden activations anywhere; GELU and GELU' come from one 8-byte nearest-entry table gather.
 // Partial results per workgroup in `ws`, laid out as mlp_fold_partials expects:
 // [dW1: grid x 4C x C][S2: grid x C x 4C][db1: 2 grid x 4C][cs2: grid x C].
 constexpr int MCW_ROWB = 144;              // LDS row pitch of the [32 tokens][64 channels] bf16 tiles (bank spread for the transposing reads)
@@ -321,12 +333,12 @@ mlpc_bwd_wgrad_kernel(const bf16* __restrict__ dxout, const bf16* __restrict__ x
                       const bf16* __restrict__ W2gT, float* __restrict__ ws, int M, float eps) {
     typedef bf16 T;
     constexpr int C = 64, KS = C / 16, NCB = C / 32, HID = 4 * C, TILE = 32 * MCW_ROWB;
-    __shared__ __attribute__((aligned(16))) char smem[4 * TILE + GELU_LUT4_BYTES];
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE + GELU_NLUT2_BYTES];
     char* const V2 = smem;
     char* const DX = smem + 2 * TILE;
     float* const lut = reinterpret_cast<float*>(smem + 4 * TILE);
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, half = lane >> 5, wave = tid >> 6;
-    gelu_lut4_fill(lut, tid, 512);
+    gelu_nlut2_fill(lut, tid, 512);
     // this wave's weight rows j = 32 wave + li, as B operands (k-step ks: channels 16 ks + 8 half ..)
     frag_t<T> w1f[KS], w2f[KS];
 #pragma unroll
@@ -397,10 +409,10 @@ mlpc_bwd_wgrad_kernel(const bf16* __restrict__ dxout, const bf16* __restrict__ x
             float x8[8], g8[8], p8[8];
 #pragma unroll
             for (int e = 0; e < 8; e++) x8[e] = h[8 * q + e];
-            gelu_both_lut4_8(lut, x8, g8, p8);
+            gelu_both_nlut2_8(lut, x8, g8, p8);
 #pragma unroll
             for (int e = 0; e < 8; e++) {
-                const float d = dg[8 * q + e] * p8[e];
+                const float d = mul_nopack(dg[8 * q + e], p8[e], e);
                 db1 += d;
                 gf[q][e] = (T)g8[e];
                 dhf[q][e] = (T)d;
