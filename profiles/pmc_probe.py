@@ -128,6 +128,29 @@ elif op in ('lstm_scan_fwd', 'lstm_scan_bwd'):         # stage-1 ConvLSTM scans:
         dw, db = torch.zeros(4 * Cc, 2 * Cc, device=dev), torch.zeros(4 * Cc, device=dev)
         wt = w.t().contiguous()
         fn = lambda: ops.lstm_scan_bwd(xa, Hall, Cs, None, dH, None, w, wt, b, dxa, None, dh0, dc0, dw=dw, db=db)
+elif op in ('pp_fwd_s4', 'pp_dgrad_s4', 'pp_scale_res_s4', 'pp_wgrad_s4', 'pp_fwd_s3', 'pp_wgrad_s3'):
+    # round 3: the 256 x 256 LDS-DMA GEMMs (csrc/ppgemm.hpp, ppgemm_tn.hpp) at the stage-4 / stage-3 MLP shapes
+    Ms, Cs_ = (120960, 512) if op.endswith('s4') else (483840, 256)
+    xs, hs = rnd(Ms, Cs_), rnd(Ms, 4 * Cs_)
+    if op.startswith('pp_fwd'):
+        w, b, y = rnd(4 * Cs_, Cs_) * 0.05, torch.zeros(4 * Cs_, device=dev), torch.empty(Ms, 4 * Cs_, device=dev, dtype=dt)
+        fn = lambda: ops.linear_fwd(xs, w, b, out=y)
+    elif op.startswith('pp_dgrad'):
+        wt, dx = rnd(Cs_, 4 * Cs_) * 0.05, torch.empty(Ms, Cs_, device=dev, dtype=dt)
+        fn = lambda: ops.linear_dgrad(hs, wt, out=dx)
+    elif op.startswith('pp_scale_res'):
+        w, b, gam = rnd(Cs_, 4 * Cs_) * 0.05, torch.zeros(Cs_, device=dev), torch.ones(Cs_, device=dev)
+        y = torch.empty(Ms, Cs_, device=dev, dtype=dt)
+        fn = lambda: ops.linear_scale_res_fwd(hs, w, b, gam, xs, out=y)
+    else:
+        dw, cs = torch.zeros(4 * Cs_, Cs_, device=dev), torch.zeros(4 * Cs_, device=dev)
+        fn = lambda: ops.linear_wgrad(hs, xs, dw, colsum_out=cs)
+elif op == 'conv_dgrad4_s3':   # stage-3 conv input gradient as one gather GEMM: 504 frames, 48 x 80 x 128 <- 24 x 40 x 256
+    from rvt_amd import weights as Wt
+    F_, H, W, Cin, Co = 504, 48, 80, 128, 256
+    dyc = rnd(F_, H // 2, W // 2, Co)
+    wd4 = Wt.pack_conv_dgrad4(torch.randn(Co, Cin, 3, 3, device=dev) * 0.05, dt)
+    fn = lambda: ops.conv_dgrad4(dyc, wd4, None, H, W, Cin)
 for _ in range(3):
     fn()
 torch.cuda.synchronize()

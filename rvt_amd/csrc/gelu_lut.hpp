@@ -91,11 +91,7 @@ __device__ __forceinline__ int gelu_nlut_index(float x) {
     const float s = (float)GELU_NLUT_N / (2.0f * GELU_LUT_X), magic = 8388608.0f;       // 2^23 = 0x4B000000
     float t = fmaf(x, s, GELU_LUT_X * s + magic);
     t = fminf(fmaxf(t, magic), magic + (float)GELU_NLUT_N);
-#if defined(RVT_EXP_NOGATHER)
-    return (int)(threadIdx.x & 31) + (((int)(__builtin_bit_cast(unsigned int, t) - 0x4B000000u)) & 0x1fe0);   // timing experiment: conflict-free
-#else
     return (int)(__builtin_bit_cast(unsigned int, t) - 0x4B000000u);
-#endif
 }
 // a product hipcc's SLP vectoriser will not pack: left to itself it pairs the products of REGISTERS 2i+1, 2i+2 into
 // v_pk_mul_f32 (the first gather is waited for on its own), which costs a v_mov per value to line the pairs up and a
