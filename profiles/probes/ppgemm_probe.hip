@@ -32,7 +32,7 @@ template <int ABL> static float run(const PPMat& X, const PPMat& W, bf16* Y, int
     PPEpArgs ep{Y, nullptr, nullptr, nullptr, nullptr, N};
     const int m_tiles = (M + 255) / 256, n_tiles = N / 256;
     int grid = 256; const int total = m_tiles * n_tiles;
-    if (grid > ((total + 7) & ~7)) grid = (total + 7) & ~7;
+    { const int per_xcd = ((m_tiles + 7) / 8) * n_tiles; if (grid > 8 * per_xcd) grid = 8 * per_xcd; }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int i = 0; i < 3; i++) hipLaunchKernelGGL((ppgemm_kernel<PP_STORE, ABL>), dim3(grid), dim3(512), 0, 0, X, W, ep, M, N, K, m_tiles, n_tiles, PPConv());
     CK(hipDeviceSynchronize());

@@ -528,9 +528,12 @@ inline void launch_ppgemm(const PPMat& X, const PPMat& W, const PPEpArgs& ep, in
                           const PPConv& cv = PPConv()) {
     const int m_tiles = (M + 255) / 256, n_tiles = N / 256;
     static const int grid_override = getenv("RVT_PPGEMM_GRID") ? atoi(getenv("RVT_PPGEMM_GRID")) : 0;      // (tests: small grids walk several tiles)
-    const int total = m_tiles * n_tiles;
+    // panels are dealt to XCDs (PPWork): XCD 0 owns the most tiles, ceil(m_tiles / 8) * n_tiles; a grid cut to the TOTAL tile
+    // count gives every XCD total / 8 workgroups and the fullest XCD's first workgroups a second tile - twice the critical path
+    // on a one-round launch (5760 x 2048 x 1024: 184 tiles, 56 us at 184 workgroups).  Size the per-XCD share by the fullest XCD.
+    const int per_xcd = ((m_tiles + 7) / 8) * n_tiles;
     int grid = grid_override > 0 ? grid_override : 256;
-    if (grid > ((total + 7) & ~7)) grid = (total + 7) & ~7;
+    if (grid > 8 * per_xcd) grid = 8 * per_xcd;
     grid = (grid + 7) & ~7;
     hipLaunchKernelGGL((ppgemm_kernel<EP, 0, GATHER>), dim3(grid), dim3(512), 0, stream, X, W, ep, M, N, K, m_tiles, n_tiles, cv);
 }

@@ -11,7 +11,8 @@ from tests.harness import compare, load_golden, oracle_run
 def test_oracle_matches_reference_golden(name):
     torch.set_num_threads(max(1, torch.get_num_threads()))
     want = load_golden(name)
-    got = oracle_run(name, torch.float32)
+    # (T = 21 cases: the carried-state second batch is covered by the short cases; skipping it keeps the CPU suite in minutes)
+    got = oracle_run(name, torch.float32, with_batch2=not name.endswith('_t21'))
     # fp32 vs fp32, different op order (im2col einsum vs oneDNN conv, gather vs permute): 2e-4 is ample
     compare(got, want, rtol=2e-4, what=f'oracle vs reference [{name}]', grad_rtol=5e-4)
 
