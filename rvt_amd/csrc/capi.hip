@@ -95,10 +95,10 @@ static void launch_wgrad(const ASrc& a, const BSrc& b, const BXf& bxf, float* ou
     float* ws_cs = colsum_out ? ws + (size_t)ns * tile_elems : nullptr;
     EpPartialStore ep{ws, Ng, tile_elems, 0};
     launch_gemm<T, BN, true>(a, XfNone(), b, bxf, ep, Mg, Ng, tokens, ks, st, ws_cs);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for(tile_elems, 1024)), dim3(256), 0, st, (const float*)ws, out, ns,
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(reduce_grid(tile_elems)), dim3(256), 0, st, (const float*)ws, out, ns,
                        tile_elems, transpose_out ? Ng : 0);
     if (colsum_out)
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for((size_t)Mg, 64)), dim3(256), 0, st, (const float*)ws_cs,
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(reduce_grid((size_t)Mg)), dim3(256), 0, st, (const float*)ws_cs,
                            colsum_out, ns, (size_t)Mg, 0);
 }
 
@@ -629,13 +629,13 @@ template <class T, int MODE> static int mlp_bwd_fused_grid(int M) {
 static void mlp_fold_partials(const float* ws, int grid, int C, float* dw1, float* db1, float* s2, float* cs2, hipStream_t st) {
     const size_t wc = (size_t)4 * C * C;
     const float* p = ws;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for(wc, 1024)), dim3(256), 0, st, p, dw1, grid, wc, 0);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(reduce_grid(wc)), dim3(256), 0, st, p, dw1, grid, wc, 0);
     p += (size_t)grid * wc;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for(wc, 1024)), dim3(256), 0, st, p, s2, grid, wc, 0);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(reduce_grid(wc)), dim3(256), 0, st, p, s2, grid, wc, 0);
     p += (size_t)grid * wc;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for((size_t)4 * C, 64)), dim3(256), 0, st, p, db1, 2 * grid, (size_t)4 * C, 0);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(reduce_grid((size_t)4 * C)), dim3(256), 0, st, p, db1, 2 * grid, (size_t)4 * C, 0);
     p += (size_t)2 * grid * 4 * C;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for((size_t)C, 64)), dim3(256), 0, st, p, cs2, grid, (size_t)C, 0);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(reduce_grid((size_t)C)), dim3(256), 0, st, p, cs2, grid, (size_t)C, 0);
 }
 extern "C" {
 size_t rvt_mlp_bwd_fused_ws_floats(int dtype, int C, int M) {
@@ -929,10 +929,10 @@ static void launch_lstm_scan_bwd(const void* x_all, const void* Hall, const void
         // fold the per-workgroup partial records: the [4C][2C] weight block and the NWM bias rows are column sums over records
         constexpr int NWM = NW / (C / 32);
         const size_t rec = (size_t)4 * C * 2 * C + (size_t)NWM * 4 * C;
-        hipLaunchKernelGGL(strided_reduce_kernel, dim3(grid_for((size_t)4 * C * 2 * C, 1024)), dim3(256), 0, st, (const float*)ws, dw,
+        hipLaunchKernelGGL(strided_reduce_kernel, dim3(reduce_grid((size_t)4 * C * 2 * C)), dim3(256), 0, st, (const float*)ws, dw,
                            grid, rec, (size_t)4 * C * 2 * C);
         for (int m = 0; m < NWM; m++)
-            hipLaunchKernelGGL(strided_reduce_kernel, dim3(grid_for((size_t)4 * C, 64)), dim3(256), 0, st,
+            hipLaunchKernelGGL(strided_reduce_kernel, dim3(reduce_grid((size_t)4 * C)), dim3(256), 0, st,
                                (const float*)(ws + (size_t)4 * C * 2 * C + (size_t)m * 4 * C), db, grid, rec, (size_t)4 * C);
     }
 }

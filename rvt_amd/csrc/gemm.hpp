@@ -540,37 +540,51 @@ struct EpPartialStore {
     }
 };
 
+// Split-K folds.  A workgroup owns 32 consecutive outputs x 8 slice lanes: thread (e, g) sums slices g, g + 8, ... of output e
+// (four independent chains), the eight partial sums meet in LDS in a fixed order (deterministic).  The one-thread-per-output
+// form walked all slices in one thread: nsplit / 8 dependent round trips - 10-20 us for the 256-512 slices of the small
+// weight gradients, 1.2 ms per Base step over 73 launches.  Grid: reduce_grid(count) workgroups (any grid is correct).
+inline int reduce_grid(size_t count) {
+    size_t g = (count + 31) / 32;
+    return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+template <class Addr>
+__device__ __forceinline__ void reduce_rows_32x8(const float* __restrict__ ws, int nrec, size_t count, const Addr& addr,
+                                                  float* __restrict__ out, int t_cols) {
+    __shared__ float red[8][33];
+    const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
+    for (size_t i0 = (size_t)blockIdx.x * 32; i0 < count; i0 += (size_t)gridDim.x * 32) {
+        const size_t i = i0 + e;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        if (i < count) {
+            int s = g;
+            for (; s + 24 < nrec; s += 32) {
+                a0 += ws[addr(s) + i]; a1 += ws[addr(s + 8) + i]; a2 += ws[addr(s + 16) + i]; a3 += ws[addr(s + 24) + i];
+            }
+            for (; s < nrec; s += 8) a0 += ws[addr(s) + i];
+        }
+        red[g][e] = (a0 + a1) + (a2 + a3);
+        __syncthreads();
+        if (g == 0 && i < count) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; k++) t += red[k][e];
+            size_t o = i;
+            if (t_cols > 0) { const size_t r = i / t_cols, c = i % t_cols; o = c * (count / t_cols) + r; }
+            out[o] += t;
+        }
+        __syncthreads();
+    }
+}
 // out[i] += sum_s ws[s][i]; with t_cols > 0 the partial tiles are [count / t_cols][t_cols] and `out` is their transpose
 __global__ void __launch_bounds__(256)
 splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int nsplit, size_t count, int t_cols) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
-        // eight independent partial sums: the slice loop is a chain of dependent loads otherwise (nsplit x memory latency)
-        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        int s = 0;
-        for (; s + 8 <= nsplit; s += 8) {
-#pragma unroll
-            for (int u = 0; u < 8; u++) a[u] += ws[(size_t)(s + u) * count + i];
-        }
-        for (; s < nsplit; s++) a[0] += ws[(size_t)s * count + i];
-        size_t o = i;
-        if (t_cols > 0) { const size_t r = i / t_cols, c = i % t_cols; o = c * (count / t_cols) + r; }
-        out[o] += ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-    }
+    reduce_rows_32x8(ws, nsplit, count, [count](int s) { return (size_t)s * count; }, out, t_cols);
 }
-
 // out[i] += sum_s ws[s * stride + i], i < count  (per-workgroup partial RECORDS of `stride` floats each)
 __global__ void __launch_bounds__(256)
 strided_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int nrec, size_t stride, size_t count) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
-        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        int s = 0;
-        for (; s + 8 <= nrec; s += 8) {
-#pragma unroll
-            for (int u = 0; u < 8; u++) a[u] += ws[(size_t)(s + u) * stride + i];
-        }
-        for (; s < nrec; s++) a[0] += ws[(size_t)s * stride + i];
-        out[i] += ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-    }
+    reduce_rows_32x8(ws, nrec, count, [stride](int s) { return (size_t)s * stride; }, out, 0);
 }
 
 // conv input-gradient of one parity class: row m = (frame, yy, xx) -> pixel (s*yy+py, s*xx+px); out = v + add

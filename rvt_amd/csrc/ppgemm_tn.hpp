@@ -279,11 +279,9 @@ inline void launch_ppgemm_tn(const bf16* dY, int ldy, const bf16* X, const bf16*
     hipLaunchKernelGGL((ppgemm_tn_kernel<0>), dim3(8 * n_tiles * k_tiles * ((ns_eff + 7) / 8)), dim3(512), 0, st, dY, ldy, X, X2, kcut, ldx, ws, ws_cs, M, N,
                        K, n_tiles, k_tiles, tps);
     const size_t elems = (size_t)N * K;
-    const int g1 = (int)((elems + 255) / 256 > 1024 ? 1024 : (elems + 255) / 256);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g1), dim3(256), 0, st, (const float*)ws, out, ns_eff, elems, N);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(reduce_grid(elems)), dim3(256), 0, st, (const float*)ws, out, ns_eff, elems, N);
     if (colsum_out) {
-        const int g2 = (N + 255) / 256;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g2), dim3(256), 0, st, (const float*)ws_cs, colsum_out, ns_eff * 8, (size_t)N, 0);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(reduce_grid((size_t)N)), dim3(256), 0, st, (const float*)ws_cs, colsum_out, ns_eff * 8, (size_t)N, 0);
     }
 }
 
