@@ -95,6 +95,15 @@ int rvt_linear_scale_res_fwd(const void* x, const void* w, const float* bias, co
  * (all nullable). */
 int rvt_linear_dgrad(const void* dy, const void* wt, const void* gelu_pre, const void* add, const void* mul, void* dx,
                      int dtype, int M, int N, int K, void* stream);
+/* Input gradient of a linear layer whose input is a LayerNorm output, with the LayerNorm backward (+ residual cotangent) in
+ * the epilogue (reference maxvit.py:229,347 norm1 -> qkv and :241,100-118 norm2 -> fc1, autograd; csrc/dgrad_ln.hpp):
+ *   dx[M][C] = add + LN'(dy[M][K] w[K][C]; x[M][C]),  dln_w[C] += sum_tok (dy w) * xhat,  dln_b[C] += sum_tok (dy w).
+ * w = the forward weight in its natural [K][C] layout (compute dtype), add nullable.
+ * rvt_linear_dgrad_ln_supported: bf16, C in {64, 128}, K = 3C or 4C. */
+int rvt_linear_dgrad_ln_supported(int dtype, int C, int K);
+int rvt_linear_dgrad_ln(const void* dy, const void* w, const void* x, const void* add, void* dx, const float* ln_w,
+                        float* dln_w, float* dln_b, int dtype, int M, int C, int K, float eps, void* stream);
+
 /* dw[N][K] (float32) += dy[M][N]^T f(x)[M][K];  if dy_colsum != NULL also dy_colsum[N] += column sums of dy
  * (the bias gradient), computed from the tiles the kernel streams anyway. */
 int rvt_linear_wgrad(const void* dy, const void* x, float* dw, float* dy_colsum, float* ws, int dtype, int M, int N,

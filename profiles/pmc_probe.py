@@ -151,6 +151,12 @@ elif op == 'conv_dgrad4_s3':   # stage-3 conv input gradient as one gather GEMM:
     dyc = rnd(F_, H // 2, W // 2, Co)
     wd4 = Wt.pack_conv_dgrad4(torch.randn(Co, Cin, 3, 3, device=dev) * 0.05, dt)
     fn = lambda: ops.conv_dgrad4(dyc, wd4, None, H, W, Cin)
+elif op in ('dgrad_ln_k512', 'dgrad_ln_k384'):    # stage-2 fc1 / qkv input gradient with the LayerNorm backward in the epilogue (csrc/dgrad_ln.hpp)
+    Ms, Cs_, Ks = 1935360, 128, 512 if op.endswith('512') else 384
+    xs, dys, dres = rnd(Ms, Cs_), rnd(Ms, Ks), rnd(Ms, Cs_)
+    w, lw = rnd(Ks, Cs_) * 0.1, torch.rand(Cs_, device=dev) + 0.5
+    dw, db, out = torch.zeros(Cs_, device=dev), torch.zeros(Cs_, device=dev), torch.empty(Ms, Cs_, device=dev, dtype=dt)
+    fn = lambda: ops.linear_dgrad_ln(dys, w, xs, dres, lw, dw, db, 1e-5, out=out)
 for _ in range(3):
     fn()
 torch.cuda.synchronize()

@@ -9,6 +9,7 @@
 #include "gemm.hpp"
 #include "ppgemm.hpp"
 #include "ppgemm_tn.hpp"
+#include "dgrad_ln.hpp"
 #include "rowops.hpp"
 #include "attn.hpp"
 #include "attn_block.hpp"
@@ -564,6 +565,29 @@ template <class K> static int mc_grid(K kernel, int threads, int M, int wpb) {
     return imax(1, imin(want, resident_override > 0 ? resident_override : 256 * per_cu));
 }
 extern "C" {
+
+// dx = add + LN'(dy W; x) in one launch (csrc/dgrad_ln.hpp): bf16, C in {64, 128}, K = 3C or 4C.  RVT_DGRAD_LN=0 disables.
+int rvt_linear_dgrad_ln_supported(int dtype, int C, int K) {
+    static const int on = getenv("RVT_DGRAD_LN") ? atoi(getenv("RVT_DGRAD_LN")) : 1;
+    return on && dtype == RVT_BF16 && (C == 64 || C == 128) && (K == 3 * C || K == 4 * C);
+}
+int rvt_linear_dgrad_ln(const void* dy, const void* w, const void* x, const void* add, void* dx, const float* ln_w,
+                        float* dln_w, float* dln_b, int dtype, int M, int C, int K, float eps, void* stream) {
+    RVT_CHECK(rvt_linear_dgrad_ln_supported(dtype, C, K), "linear_dgrad_ln: not built for dtype=%d C=%d K=%d", dtype, C, K);
+    RVT_CHECK(M >= 1 && ln_w != nullptr && dln_w != nullptr && dln_b != nullptr, "linear_dgrad_ln: LayerNorm weight and gradient buffers required");
+    hipStream_t st = (hipStream_t)stream;
+#define RVT_DGL(CC, AH)                                                                                                    \
+    do {                                                                                                                   \
+        auto k = dgrad_ln_kernel<bf16, CC, 8, AH>;                                                                         \
+        hipLaunchKernelGGL(k, dim3(mc_grid(k, 512, M, 8)), dim3(512), 0, st, (const bf16*)dy, (const bf16*)w, (const bf16*)x, \
+                           (const bf16*)add, (bf16*)dx, ln_w, dln_w, dln_b, M, K, eps);                                    \
+    } while (0)
+    const bool four = (K / 32) % 4 == 0;
+    if (C == 128) RVT_DGL(128, 4);          // (K = 384 / 512: both whole groups of four chunks)
+    else { if (four) RVT_DGL(64, 4); else RVT_DGL(64, 2); }
+#undef RVT_DGL
+    return check_launch("linear_dgrad_ln");
+}
 
 int rvt_mlp_fwd(const void* xmid, void* xout, void* g_out, void* gp_out, void* v2_out, const float* ln_w, const float* ln_b,
                 const void* w1, const float* b1, const void* w2, const float* b2, const float* gamma, int dtype, int M,

@@ -228,6 +228,14 @@ template <class T> struct TrFeat {
     }
 };
 
+// A value the optimiser has to treat as freshly produced here: everything derived from it stays inside the loop it is used in
+// (hipcc hoists per-lane address tables out of loops and spills them; see ppgemm.hpp / dgrad_ln.hpp).
+__device__ __forceinline__ void opaque_vgpr(int& v) {
+#ifndef RVT_EMU
+    asm volatile("" : "+v"(v));
+#endif
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also fences global memory: hipcc emits
 // `s_waitcnt vmcnt(0)` in front of the barrier, i.e. every wave waits until its outstanding global STORES are
 // acknowledged (CDNA counts stores on vmcnt).  In these kernels barriers only protect LDS tiles / staging buffers —

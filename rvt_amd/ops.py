@@ -147,6 +147,24 @@ def layernorm_bwd(x: Tensor, w: Tensor, dy: Tensor, dres: Optional[Tensor], dw: 
     return dx
 
 
+def linear_dgrad_ln_supported(dtype: torch.dtype, C: int, K: int) -> bool:
+    return dtype in L._DT and bool(L.get_lib().rvt_linear_dgrad_ln_supported(L.dtype_code(dtype), C, K))
+
+
+def linear_dgrad_ln(dy: Tensor, w: Tensor, x: Tensor, dres: Optional[Tensor], ln_w: Tensor, dw: Tensor, db: Tensor,
+                    eps: float, out: Optional[Tensor] = None) -> Tensor:
+    """dx = dres + LN'(dy @ w; x) with dw += sum (dy @ w) * xhat, db += sum (dy @ w): the input gradient of a linear layer fed by
+    a LayerNorm and that LayerNorm's backward in one launch (csrc/dgrad_ln.hpp).  w: the forward weight [K][C]."""
+    C = x.shape[-1]
+    K = dy.shape[-1]
+    rows = x.numel() // C
+    assert tuple(w.shape) == (K, C) and w.dtype == x.dtype == dy.dtype and dy.numel() // K == rows
+    dx = _out(x, x.shape, out=out)
+    L.call('rvt_linear_dgrad_ln', L.ptr(dy), L.ptr(w), L.ptr(x), L.ptr(dres), L.ptr(dx), L.ptr(ln_w), L.ptr(dw), L.ptr(db),
+           L.dtype_code(x.dtype), rows, C, K, float(eps), L.stream_of(x))
+    return dx
+
+
 def linear_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor], gelu_in: bool = False, out: Optional[Tensor] = None) -> Tensor:
     K = x.shape[-1]
     M = x.numel() // K

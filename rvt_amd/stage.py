@@ -363,9 +363,12 @@ def stage_seq_backward(sw: StageWeights, g: StageGeom, sv: StageSaved, dH: Optio
                     ops.linear_wgrad(dhd, v2, G(bp + 'mlp.net.0.0.weight'), colsum_out=G(bp + 'mlp.net.0.0.bias'))
                 side.run(fc1_wgrad_fn, dhd, s['xmid'])
                 if not fused:
-                    dv2 = ops.linear_dgrad(dhd, bw['fc1_wt'])
-                    dxmid = ops.layernorm_bwd(s['xmid'], bw['n2_w'], dv2, dx, dn2w, dn2b, g.eps)
-                    del dv2
+                    if ops.linear_dgrad_ln_supported(dt, C, 4 * C):     # fc1 input gradient + norm2 backward + residual: one launch
+                        dxmid = ops.linear_dgrad_ln(dhd, bw['fc1_w'], s['xmid'], dx, bw['n2_w'], dn2w, dn2b, g.eps)
+                    else:
+                        dv2 = ops.linear_dgrad(dhd, bw['fc1_wt'])
+                        dxmid = ops.layernorm_bwd(s['xmid'], bw['n2_w'], dv2, dx, dn2w, dn2b, g.eps)
+                        del dv2
                 del dhd
             # attention branch: xmid = xin + g1 * (a Wp^T + bp)
             def proj_wgrad_fn(dxmid=dxmid, s=s, bp=bp):
@@ -392,6 +395,9 @@ def stage_seq_backward(sw: StageWeights, g: StageGeom, sv: StageSaved, dH: Optio
             side.run(qkv_wgrad_fn, dqkv, s['xin'])
             if bw['n1_w'] is None:
                 dx = ops.linear_dgrad(dqkv, bw['qkv_wt'], add=dxmid)
+            elif ops.linear_dgrad_ln_supported(dt, C, 3 * C):           # qkv input gradient + norm1 backward + residual: one launch
+                dx = ops.linear_dgrad_ln(dqkv, bw['qkv_w'], s['xin'], dxmid, bw['n1_w'], G(bp + 'norm1.weight'),
+                                         G(bp + 'norm1.bias'), g.eps)
             else:
                 du = ops.linear_dgrad(dqkv, bw['qkv_wt'])
                 dx = ops.layernorm_bwd(s['xin'], bw['n1_w'], du, dxmid, G(bp + 'norm1.weight'), G(bp + 'norm1.bias'), g.eps)

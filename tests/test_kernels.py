@@ -245,6 +245,36 @@ def test_layernorm(backend, dt, rows, C):
     close(db, br.grad, dt, 'ln_bwd db')
 
 
+@pytest.mark.parametrize('C,K', [(64, 192), (64, 256), (128, 384), (128, 512)])
+@pytest.mark.parametrize('M', [45, 300, 1000])
+def test_linear_dgrad_ln(backend, C, K, M):
+    """dx = dres + LN'(dy W; x) in one launch (csrc/dgrad_ln.hpp) vs fp64 autograd and vs the two-launch chain it replaces."""
+    dt = torch.bfloat16
+    assert ops.linear_dgrad_ln_supported(dt, C, K) and not ops.linear_dgrad_ln_supported(torch.float32, C, K)
+    x = rnd((M, C), backend, dt, 1, 2.0)
+    lw = rnd((C,), backend, torch.float32, 2) * 0.3 + 1.0
+    w = rnd((K, C), backend, dt, 3, 0.2)
+    dy, dres = rnd((M, K), backend, dt, 4), rnd((M, C), backend, dt, 5)
+    dw, db = torch.zeros(C, device=backend), torch.zeros(C, device=backend)
+    dx = ops.linear_dgrad_ln(dy, w, x, dres, lw, dw, db, 1e-5)
+    xr, lwr, lbr = f64(x).requires_grad_(True), f64(lw).requires_grad_(True), torch.zeros(C, dtype=torch.float64, requires_grad=True)
+    u = F.layer_norm(xr, (C,), lwr, lbr, 1e-5)
+    (u @ f64(w).t()).backward(f64(dy))
+    close(dx, xr.grad + f64(dres), dt, 'dgrad_ln dx')
+    close(dw, lwr.grad, dt, 'dgrad_ln dln_w')
+    close(db, lbr.grad, dt, 'dgrad_ln dln_b')
+    # the chain: du (rounded to bf16) then the LayerNorm backward
+    dw2, db2 = torch.zeros(C, device=backend), torch.zeros(C, device=backend)
+    du = ops.linear_dgrad(dy, w.t().contiguous())
+    dx2 = ops.layernorm_bwd(x, lw, du, dres, dw2, db2, 1e-5)
+    close(dx, dx2.double(), dt, 'dgrad_ln vs chain dx')
+    close(dw, dw2.double(), dt, 'dgrad_ln vs chain dln_w')
+    # accumulation into existing parameter gradients, no residual
+    dx3 = ops.linear_dgrad_ln(dy, w, x, None, lw, dw, db, 1e-5)
+    close(dw, 2 * lwr.grad, dt, 'dgrad_ln dln_w accumulates')
+    close(dx3, xr.grad, dt, 'dgrad_ln dx, no residual')
+
+
 def ref_attention(qkv, Fr, H, W, C, dh, ph, pw, window):
     """plain restatement of maxvit.py:273-304,343-354 on (F,H,W,3C) -> (F,H,W,C)"""
     heads = C // dh
