@@ -15,5 +15,6 @@ cp $G/bench_tiny_gen1.json profiles/bench_${TAG}_tiny_gen1_n1.json.log
 cp $G/bench_stream_latency.json profiles/bench_${TAG}_stream_latency.json.log
 cp $G/op_breakdown.txt profiles/r3/op_breakdown_$TAG.txt
 cp $G/pytest.log profiles/r3/pytest_gpu_$TAG.log
-for f in microbench_ppgemm microbench_gemm128 microbench_conv_dgrad microbench_mlp_chain pmc_round3_kernels; do cp $G/$f.txt profiles/r3/${f}_$TAG.txt; done
+for f in microbench_ppgemm microbench_gemm128 microbench_conv_dgrad microbench_mlp_chain microbench_dgrad_ln pmc_round3_kernels; do cp $G/$f.txt profiles/r3/${f}_$TAG.txt; done
+python profiles/pmc_summary.py pp_fwd_s4 pp_dgrad_s4 pp_scale_res_s4 pp_wgrad_s4 pp_fwd_s3 pp_wgrad_s3 conv_dgrad4_s3 mlpc_fwd mlpc_dgrad mlpc_wgrad dgrad_ln_k512 dgrad_ln_k384 > profiles/r3/pmc_round3_table_$TAG.txt
 ls -la profiles/${TAG}_rocprofv3 profiles/r3 | tail -30

@@ -19,6 +19,7 @@ RVT_PPGEMM=1 timeout 600 python profiles/microbench_ppgemm.py > $OUT/microbench_
 RVT_PPGEMM=0 timeout 600 python profiles/microbench_ppgemm.py > $OUT/microbench_gemm128.txt 2>&1
 timeout 300 python profiles/microbench_conv_dgrad.py > $OUT/microbench_conv_dgrad.txt 2>&1
 timeout 300 python profiles/microbench_mlp_chain.py > $OUT/microbench_mlp_chain.txt 2>&1
-tail -2 $OUT/microbench_ppgemm.txt $OUT/microbench_conv_dgrad.txt $OUT/microbench_mlp_chain.txt
-bash profiles/pmc_probe.sh pp_fwd_s4 pp_dgrad_s4 pp_scale_res_s4 pp_wgrad_s4 pp_fwd_s3 pp_wgrad_s3 conv_dgrad4_s3 mlpc_fwd mlpc_dgrad mlpc_wgrad > $OUT/pmc_round3_kernels.txt 2>&1
+timeout 300 python profiles/microbench_dgrad_ln.py > $OUT/microbench_dgrad_ln.txt 2>&1
+tail -n 2 $OUT/microbench_ppgemm.txt $OUT/microbench_conv_dgrad.txt $OUT/microbench_mlp_chain.txt $OUT/microbench_dgrad_ln.txt
+bash profiles/pmc_probe.sh pp_fwd_s4 pp_dgrad_s4 pp_scale_res_s4 pp_wgrad_s4 pp_fwd_s3 pp_wgrad_s3 conv_dgrad4_s3 mlpc_fwd mlpc_dgrad mlpc_wgrad dgrad_ln_k512 dgrad_ln_k384 > $OUT/pmc_round3_kernels.txt 2>&1
 grep -c "==" $OUT/pmc_round3_kernels.txt
