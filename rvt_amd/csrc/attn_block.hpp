@@ -209,11 +209,18 @@ attn_block_fwd_kernel(const T* __restrict__ x, T* __restrict__ xmid, T* __restri
                       float eps) {
     typedef AbSmem<T, C> S;
     constexpr int KS = C / 16, HEADS = C / 32, NCB = C / 32;
-    __shared__ __attribute__((aligned(16))) char smem[S::OFF_S];
+    // LN: the raw rows are needed again for the residual.  They used to be re-read from L2 in the epilogue - but vmcnt retires loads
+    // and stores in issue order, so that load waited for the acknowledgement of every attention-output row stored before it (the
+    // stores cost 27 % of the kernel in a timing variant without them).  bf16: the rows are stashed in lane-private LDS slots
+    // (piece (b, ks) of lane l at ((b KS + ks) 64 + l) 16: no conflicts, no synchronisation) and come back over lgkmcnt.
+    constexpr bool STASH = LN && sizeof(T) == 2;
+    constexpr int STASH_B = STASH ? NB * KS * 64 * 16 : 0;
+    __shared__ __attribute__((aligned(16))) char smem[S::OFF_S + WPB * STASH_B];
     char* const Wq_l = smem;
     char* const Wp_l = smem + S::OFF_P;
     float* const kst = reinterpret_cast<float*>(smem + S::OFF_K);
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, half = lane >> 5, wave = tid >> 6;
+    char* const stash = smem + S::OFF_S + wave * STASH_B + lane * 16;
 
     ab_stage_weights<T, C, false>(Wq_l, Wqkv, 3 * C, tid, 64 * WPB);
     ab_stage_weights<T, C, true>(Wp_l, Wp, C, tid, 64 * WPB);
@@ -235,6 +242,12 @@ attn_block_fwd_kernel(const T* __restrict__ x, T* __restrict__ xmid, T* __restri
         ab_partition<NB>(pt, g, pidx, li);
         frag_t<T> uf[NB][KS];
         ab_load_rows<T, C, NB>(uf, x, pt.tok, pt.valid, half);
+        if (STASH) {
+#pragma unroll
+            for (int b = 0; b < NB; b++)
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) *reinterpret_cast<frag_t<T>*>(stash + (b * KS + ks) * 1024) = uf[b][ks];
+        }
         if (LN) {
             float mean[NB], rstd[NB];
             ab_layernorm<T, C, NB>(uf, uf, kst + S::K_LNW, kst + S::K_LNB, pt.valid, half, eps, mean, rstd);
@@ -318,7 +331,8 @@ attn_block_fwd_kernel(const T* __restrict__ x, T* __restrict__ xmid, T* __restri
                     float res[8], gam[8], bpv[8], o[8];
                     const size_t off = (size_t)pt.tok[bi] * C + (2 * ks + half) * 8;
                     if (LN) {
-                        const frag_t<T> xr = frag_load<T>(x + off);          // (L2: this wave read the row a moment ago)
+                        const frag_t<T> xr = STASH ? *reinterpret_cast<const frag_t<T>*>(stash + (bi * KS + ks) * 1024)
+                                                   : frag_load<T>(x + off);          // (fp32: L2 - this wave read the row a moment ago)
                         frag_to_float<T>(xr, res);
                     } else {
                         frag_to_float<T>(uf[bi][ks], res);
@@ -388,12 +402,16 @@ attn_block_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dxmid, T* _
     constexpr int KS = C / 16, HEADS = C / 32, NCB = C / 32, LP = 32 * NB;
     // per wave: P / dS scratch
     constexpr int DLN = 0;
-    __shared__ __attribute__((aligned(16))) char smem[S::OFF_S + WPB * (SC::BYTES + DLN) + (LN ? WPB * 2 * C * 4 : 0)];
+    constexpr bool STASH = LN && sizeof(T) == 2;                       // raw rows for the LayerNorm backward: lane-private LDS slots (see the forward)
+    constexpr int STASH_B = STASH ? NB * KS * 64 * 16 : 0;
+    constexpr int OFF_STASH = S::OFF_S + WPB * (SC::BYTES + DLN) + (LN ? WPB * 2 * C * 4 : 0);
+    __shared__ __attribute__((aligned(16))) char smem[OFF_STASH + WPB * STASH_B];
     char* const Wq_l = smem;
     char* const Wp_l = smem + S::OFF_P;
     float* const kst = reinterpret_cast<float*>(smem + S::OFF_K);
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, half = lane >> 5, wave = tid >> 6;
     char* const Pl = smem + S::OFF_S + wave * (SC::BYTES + DLN);
+    char* const stash = smem + OFF_STASH + wave * STASH_B + lane * 16;
     char* const dSl = Pl + SC::ONE;
     // LayerNorm parameter gradients = column sums over tokens of du * xhat and du: the row pieces hold tokens in the LANES; an
     // MFMA against an identity operand turns a piece block into "col = channel, registers = tokens" (exact), where the column
@@ -427,7 +445,13 @@ attn_block_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dxmid, T* _
         float mean[NB], rstd[NB];
         ab_load_rows<T, C, NB>(uf, x, pt.tok, pt.valid, half);
         ab_load_rows<T, C, NB>(df, dxmid, pt.tok, pt.valid, half);
-        if (LN) {       // the raw rows are re-read (L2) for the LayerNorm backward at the end: 32 registers less across the heads
+        if (STASH) {
+#pragma unroll
+            for (int b = 0; b < NB; b++)
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) *reinterpret_cast<frag_t<T>*>(stash + (b * KS + ks) * 1024) = uf[b][ks];
+        }
+        if (LN) {       // the raw rows come back from the LDS stash (fp32: L2) for the LayerNorm backward at the end: 32 registers less across the heads
             ab_layernorm<T, C, NB>(uf, uf, kst + S::K_LNW, kst + S::K_LNB, pt.valid, half, eps, mean, rstd);
             if (u_out != nullptr) {
 #pragma unroll
@@ -581,7 +605,8 @@ attn_block_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dxmid, T* _
                 for (int ks = 0; ks < KS; ks++) {
                     float w[8];
                     load_cols<8>(kst + S::K_LNW, 16 * ks + 8 * half, w);
-                    const frag_t<T> xr = frag_load<T>(x + (size_t)pt.tok[b] * C + (2 * ks + half) * 8);
+                    const frag_t<T> xr = STASH ? *reinterpret_cast<const frag_t<T>*>(stash + (b * KS + ks) * 1024)
+                                               : frag_load<T>(x + (size_t)pt.tok[b] * C + (2 * ks + half) * 8);
 #pragma unroll
                     for (int e = 0; e < 8; e++) {
                         xh[ks][e] = pt.valid[b] ? ((float)xr[e] - mean[b]) * rstd[b] : 0.f;

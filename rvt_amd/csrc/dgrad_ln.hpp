@@ -22,7 +22,9 @@ template <class T, int C> struct DglSmem {
     static constexpr int MAXK = 4 * C;
     static constexpr int W_BYTES = KT * MAXK * 128;                 // [K rows][C] operand image
     static constexpr int NCONST = C;                                // ln_w
-    static constexpr int BYTES = W_BYTES + NCONST * 4;
+    static constexpr int SCR_PITCH = 80, SCR_WAVE = 32 * SCR_PITCH;  // per wave: [32 rows][64 B + pad], the store bounce of pass 2
+    static constexpr int OFF_SCR = W_BYTES + NCONST * 4;
+    static constexpr int BYTES_FOR(int wpb) { return OFF_SCR + wpb * SCR_WAVE; }
 };
 
 template <class T, int C, int WPB, int AHEAD>
@@ -32,9 +34,10 @@ dgrad_ln_kernel(const T* __restrict__ dy, const T* __restrict__ W, const T* __re
                 int M, int K, float eps) {
     typedef DglSmem<T, C> S;
     constexpr int KS = C / 16, NCB = C / 32;
-    __shared__ __attribute__((aligned(16))) char smem[S::BYTES];
+    __shared__ __attribute__((aligned(16))) char smem[S::BYTES_FOR(WPB)];
     char* const W_l = smem;
     float* const kst = reinterpret_cast<float*>(smem + S::W_BYTES);
+    char* const scr = smem + S::OFF_SCR + (threadIdx.x >> 6) * S::SCR_WAVE;
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, half = lane >> 5, wave = tid >> 6;
     chain_stage_weights<T, C, false>(W_l, W, K, tid, 64 * WPB);
     for (int i = tid; i < C; i += 64 * WPB) kst[i] = ln_w[i];
@@ -59,7 +62,7 @@ dgrad_ln_kernel(const T* __restrict__ dy, const T* __restrict__ W, const T* __re
     // the first AHEAD chunks of a tile's dy rows are requested while the PREVIOUS tile runs its LayerNorm epilogue (1.5 k VALU
     // instructions with nothing else in flight)
     frag_t<T> df[AHEAD][2];
-    constexpr int EARLY = AHEAD / 2;                                 // (the whole ring alive across the epilogue spills at C = 128)
+    constexpr int EARLY = 1;                                         // (more of the ring alive across the epilogue spills at C = 128)
     auto prime = [&](int t) __attribute__((always_inline)) {
         const int r = t * 32 + li;
         const T* const p = dy + (size_t)(r < M ? r : M - 1) * K + 8 * half;
@@ -86,10 +89,11 @@ dgrad_ln_kernel(const T* __restrict__ dy, const T* __restrict__ W, const T* __re
 #pragma unroll
             for (int q = 0; q < 2; q++) df[a][q] = frag_load<T>(dyr + 32 * a + 16 * q);
         f32x16 dacc[NCB];
-#pragma unroll
-        for (int cb = 0; cb < NCB; cb++) acc_zero(dacc[cb]);
-        // du^T[c][tok] = sum_j W[j][c] dy[tok][j]: hidden chunks of 32, AHEAD chunks of dy fragments in flight (K / 32 % AHEAD = 0)
-        for (int jc0 = 0; jc0 < NJC; jc0 += AHEAD) {
+        // du^T[c][tok] = sum_j W[j][c] dy[tok][j]: hidden chunks of 32, AHEAD chunks of dy fragments in flight (K / 32 % AHEAD = 0).
+        // The first group is peeled: its first products take C = 0 from the instruction (no zero fill of 16 NCB registers), and the
+        // accumulators are defined before the loop, so that its exit needs no copies between register sets.
+        auto group = [&](int jc0, auto first) __attribute__((always_inline)) {
+            constexpr bool FIRST = decltype(first)::value;
             // the image is entered at an OPAQUE byte offset per group of AHEAD chunks, so that the fragment addresses are formed
             // here (one xor each) instead of being hoisted out of the loop as a table (it spills at C = 128)
             int jb = jc0 * 32 * 128;
@@ -112,10 +116,13 @@ dgrad_ln_kernel(const T* __restrict__ dy, const T* __restrict__ W, const T* __re
                         const int off = (cb >> 1) * sub1 + (32 * a + 16 * q) * 128;
                         const frag_t<T> wf = frag_from_tr<T>(reinterpret_cast<const bf16*>(W_l + ((t_lo ^ xk) + off)),
                                                              reinterpret_cast<const bf16*>(W_l + ((t_hi ^ xk) + off)));
-                        mma32(dacc[cb], wf, cur[q]);
+                        if (FIRST && a == 0 && q == 0) mma32_zero(dacc[cb], wf, cur[q]);
+                        else mma32(dacc[cb], wf, cur[q]);
                     }
             }
-        }
+        };
+        group(0, std::true_type());
+        for (int jc0 = AHEAD; jc0 < NJC; jc0 += AHEAD) group(jc0, std::false_type());
         if (tile + (int)(gridDim.x * WPB) < n_tiles) prime(tile + gridDim.x * WPB);
         sched_fence();
         // row statistics of x (lane = row: in-lane sums + one exchange)
@@ -168,20 +175,39 @@ dgrad_ln_kernel(const T* __restrict__ dy, const T* __restrict__ W, const T* __re
         // m1 = mean_c(g w), m2 = mean_c(g w xhat) = rstd (S2 - mean S1) / C;  dx = add + rstd (g w - m1 - xhat m2) = add + (rstd w) g + A + B x
         const float m1 = s1 / (float)C, m2 = rstd * (s2 - mean * s1) / (float)C;
         const float Bc = -rstd * rstd * m2, Ac = -rstd * m1 - mean * Bc;
-        // pass 2
+        // pass 2.  The rows leave through a wave-private LDS bounce, two 16-channel pieces (64 bytes of every row) at a time: in
+        // operand form a store instruction would write 32 bytes of each of 32 rows, and those stores - a seventh of the kernel's
+        // bytes - cost a quarter of its time (0.95 -> 0.73 ms with the stores dropped); from the bounce a store instruction writes
+        // 64 contiguous bytes of 16 rows.  (DS operations of one wave execute in order: no barrier.)
         const T* const addr = add != nullptr ? add + (size_t)rowc * C + half * 8 : nullptr;
+        // (vmcnt retires loads and stores in issue order: a residual piece requested AFTER the stores of the previous pair would
+        // wait for their acknowledgement - the next pair's pieces are requested before this pair's rows are stored)
+        frag_t<T> af[2] = {frag_zero<T>(), frag_zero<T>()}, afn[2] = {frag_zero<T>(), frag_zero<T>()};
+        if (addr != nullptr) { af[0] = frag_load<T>(addr); af[1] = frag_load<T>(addr + 16); }
 #pragma unroll
-        for (int ks = 0; ks < KS; ks++) {
-            float w[8], o[8], av[8], dv[8];
-            load_cols<8>(kw, 16 * ks + 8 * half, w);
-            frag_t<T> af = frag_zero<T>();
-            if (addr != nullptr) af = frag_load<T>(addr + 16 * ks);
-            frag_to_float<T>(af, av);
-            frag_to_float<T>(rf[ks], dv);
+        for (int kp = 0; kp < KS / 2; kp++) {
+            if (addr != nullptr && kp + 1 < KS / 2) { afn[0] = frag_load<T>(addr + 16 * (2 * kp + 2)); afn[1] = frag_load<T>(addr + 16 * (2 * kp + 3)); }
 #pragma unroll
-            for (int e = 0; e < 8; e++) o[e] = av[e] + fmaf((float)xf[ks][e], Bc, fmaf(dv[e], rstd * w[e], Ac));
-            if (valid) frag_store<T>(dx + (size_t)row * C + (2 * ks + half) * 8, frag_from_float<T>(o));
-            if ((ks & 1) == 1) sched_fence();
+            for (int m = 0; m < 2; m++) {
+                const int ks = 2 * kp + m;
+                float w[8], o[8], av[8], dv[8];
+                load_cols<8>(kw, 16 * ks + 8 * half, w);
+                frag_to_float<T>(af[m], av);
+                frag_to_float<T>(rf[ks], dv);
+#pragma unroll
+                for (int e = 0; e < 8; e++) o[e] = av[e] + fmaf((float)xf[ks][e], Bc, fmaf(dv[e], rstd * w[e], Ac));
+                *reinterpret_cast<frag_t<T>*>(scr + li * S::SCR_PITCH + (2 * m + half) * 16) = frag_from_float<T>(o);
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int rr = 16 * j + (lane >> 2), orow = tile * 32 + rr;
+                const frag_t<T> v = *reinterpret_cast<const frag_t<T>*>(scr + rr * S::SCR_PITCH + (lane & 3) * 16);
+                if (orow < M) frag_store<T>(dx + (size_t)orow * C + kp * 32 + (lane & 3) * 8, v);
+            }
+            wave_lds_sync();
+            af[0] = afn[0]; af[1] = afn[1];
+            sched_fence();
         }
         // pass 3: LayerNorm parameter gradients = column sums over the 32 tokens of du xhat and du.  The row pieces hold tokens in
         // the LANES; an MFMA against an identity operand turns a piece into "col = channel, registers = tokens" (exact), where the
@@ -194,8 +220,6 @@ dgrad_ln_kernel(const T* __restrict__ dy, const T* __restrict__ W, const T* __re
 #pragma unroll
         for (int cb = 0; cb < NCB; cb++) {
             f32x16 tw, tb;
-            acc_zero(tw);
-            acc_zero(tb);
 #pragma unroll
             for (int m = 0; m < 2; m++) {
                 const int ks = 2 * cb + m;
@@ -203,8 +227,8 @@ dgrad_ln_kernel(const T* __restrict__ dy, const T* __restrict__ W, const T* __re
                 frag_to_float<T>(rf[ks], dv);
 #pragma unroll
                 for (int e = 0; e < 8; e++) pw[e] = dv[e] * fmaf((float)xf[ks][e], rstd, -mr);
-                mma32(tw, frag_from_float<T>(pw), idf[m]);
-                mma32(tb, rf[ks], idf[m]);
+                if (m == 0) { mma32_zero(tw, frag_from_float<T>(pw), idf[m]); mma32_zero(tb, rf[ks], idf[m]); }
+                else { mma32(tw, frag_from_float<T>(pw), idf[m]); mma32(tb, rf[ks], idf[m]); }
             }
 #pragma unroll
             for (int r = 0; r < 16; r++) { aw[cb] += tw[r]; ab[cb] += tb[r]; }
