@@ -210,8 +210,8 @@ attn_block_fwd_kernel(const T* __restrict__ x, T* __restrict__ xmid, T* __restri
     typedef AbSmem<T, C> S;
     constexpr int KS = C / 16, HEADS = C / 32, NCB = C / 32;
     // LN: the raw rows are needed again for the residual.  They used to be re-read from L2 in the epilogue - but vmcnt retires loads
-    // and stores in issue order, so that load waited for the acknowledgement of every attention-output row stored before it (the
-    // stores cost 27 % of the kernel in a timing variant without them).  bf16: the rows are stashed in lane-private LDS slots
+    // and stores in issue order, so that load waited for the acknowledgement of every attention-output row stored before it
+    // (1.13 -> 1.00 ms per block with the stash).  bf16: the rows are stashed in lane-private LDS slots
     // (piece (b, ks) of lane l at ((b KS + ks) 64 + l) 16: no conflicts, no synchronisation) and come back over lgkmcnt.
     constexpr bool STASH = LN && sizeof(T) == 2;
     constexpr int STASH_B = STASH ? NB * KS * 64 * 16 : 0;

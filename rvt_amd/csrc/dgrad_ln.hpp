@@ -176,9 +176,8 @@ dgrad_ln_kernel(const T* __restrict__ dy, const T* __restrict__ W, const T* __re
         const float m1 = s1 / (float)C, m2 = rstd * (s2 - mean * s1) / (float)C;
         const float Bc = -rstd * rstd * m2, Ac = -rstd * m1 - mean * Bc;
         // pass 2.  The rows leave through a wave-private LDS bounce, two 16-channel pieces (64 bytes of every row) at a time: in
-        // operand form a store instruction would write 32 bytes of each of 32 rows, and those stores - a seventh of the kernel's
-        // bytes - cost a quarter of its time (0.95 -> 0.73 ms with the stores dropped); from the bounce a store instruction writes
-        // 64 contiguous bytes of 16 rows.  (DS operations of one wave execute in order: no barrier.)
+        // operand form a store instruction would write 32 bytes of each of 32 rows (0.95 ms; 0.85 with the bounce, 0.82 with the
+        // residual pieces requested ahead of the stores); from the bounce a store instruction writes 64 contiguous bytes of 16 rows.  (DS operations of one wave execute in order: no barrier.)
         const T* const addr = add != nullptr ? add + (size_t)rowc * C + half * 8 : nullptr;
         // (vmcnt retires loads and stores in issue order: a residual piece requested AFTER the stores of the previous pair would
         // wait for their acknowledgement - the next pair's pieces are requested before this pair's rows are stored)
