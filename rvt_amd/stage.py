@@ -197,9 +197,13 @@ def stage_seq_forward(sw: StageWeights, g: StageGeom, inp: Tensor, h0: Optional[
 
     Hall = torch.empty((T + 1, B, H, W, C), dtype=dt, device=dev)
     dws = sw.dws
+    # a no-grad forward on the per-step route reads the incoming states where they are (streaming inference, T = 1: the two
+    # state copies per stage were 5 % of the step); BPTT and the scan kernel want them in slot 0
+    direct0 = (not save) and h0 is not None and not use_lstm_scan(dt, C, dws) and h0.dtype == dt and h0.is_contiguous() \
+        and c0 is not None and c0.dtype == torch.float32 and c0.is_contiguous()
     if h0 is None:
         Hall[0].zero_()                                                           # rnn.py:43-47
-    else:
+    elif not direct0:
         Hall[0].copy_(h0)
     if use_lstm_scan(dt, C, dws):
         # all T steps in ONE launch: h / c stay on chip, BPTT keeps only a T-typed copy of the cell states
@@ -219,7 +223,7 @@ def stage_seq_forward(sw: StageWeights, g: StageGeom, inp: Tensor, h0: Optional[
     Call = torch.empty((nc, B, H, W, C), dtype=torch.float32, device=dev)
     if h0 is None:
         Call[0].zero_()
-    else:
+    elif not direct0:
         Call[0].copy_(c0)
     gates = torch.empty((T, B, H, W, 4 * C), dtype=dt, device=dev) if save else None
     # DWS-ConvLSTM (rnn.py:50-54): depth-wise 3x3 on h_{t-1} only, or on cat(x, h_{t-1}) (the x half batched over T)
@@ -231,12 +235,14 @@ def stage_seq_forward(sw: StageWeights, g: StageGeom, inp: Tensor, h0: Optional[
             x_lstm = ops.dwconv(x, dws['w'][:C], dws['b'][:C], dws['k'])
     xt = x_lstm.view(T, B, H, W, C)
     for t in range(T):                                                            # rnn.py:52-67, one launch per step
-        h_in = Hall[t]
+        h_prev = h0.view(B, H, W, C) if (direct0 and t == 0) else Hall[t]
+        c_prev = c0.view(B, H, W, C) if (direct0 and t == 0) else Call[t % nc]
+        h_in = h_prev
         if dws is not None:
             wh = dws['w'] if dws['only_hidden'] else dws['w'][C:]
             bh = dws['b'] if dws['only_hidden'] else dws['b'][C:]
-            h_in = ops.dwconv(Hall[t], wh, bh, dws['k'], out=hconv[t if save else 0])
-        ops.lstm_fwd(xt[t], h_in, Call[t % nc], sw.lstm_w, sw.lstm_b, Hall[t + 1], Call[(t + 1) % nc],
+            h_in = ops.dwconv(h_prev, wh, bh, dws['k'], out=hconv[t if save else 0])
+        ops.lstm_fwd(xt[t], h_in, c_prev, sw.lstm_w, sw.lstm_b, Hall[t + 1], Call[(t + 1) % nc],
                      gates[t] if save else None)
     # the final cell state is handed to the caller (RNNStates keeps it across steps): a buffer of its own when the
     # T+1-slot array is what BPTT holds on to
