@@ -27,6 +27,49 @@ const char* rvt_last_error(void);
 /* 1 if this library is the CPU SIMT emulator build used by the unit tests, 0 for the gfx950 build */
 int rvt_is_emulator(void);
 
+/* Launch geometry and kernel routing, ONE explicit record instead of environment variables (round 4).  The defaults are
+ * the production route: what bench.py times and what a deployment runs; nothing in the library reads the environment.
+ * The unit tests install a "test geometry" (tiny persistent grids, every kernel family forced on at test-size problems;
+ * rvt_amd/tuning.py: TEST_GEOMETRY) through the same call and say so, and the production-route parity tests run on the
+ * defaults.  The record is process-wide (not per stream / per thread): set it between launches, not concurrently with them.
+ * 0 in a geometry field means "sized by the library" (occupancy query x 256 CUs). */
+typedef struct RvtTuning {
+    int struct_bytes;         /* sizeof(RvtTuning) of the caller; set / get reject a mismatch */
+    /* ---- launch geometry ---- */
+    int gemm_resident;        /* persistent workgroups of the 128-row GEMM engine, fused MLP (mlp.hpp) and ConvLSTM scan kernels */
+    int gemm_xcd_panels;      /* 1: panels of long NT tile walks are dealt per XCD (gemm.hpp tile_of mode 3) */
+    int wgrad_bn;             /* output-tile width of the split-K weight-gradient kernel: 0 = by shape, 64, 128 */
+    int wgrad_blocks;         /* target workgroups of a split-K weight-gradient launch (512 = two per CU) */
+    int wgrad_slice_tokens;   /* minimum tokens per K slice (8192; >= 64) */
+    int ppgemm;               /* 1: bf16 products whose shape fits take the 256x256 LDS-DMA kernels (ppgemm.hpp, ppgemm_tn.hpp) */
+    int ppgemm_min_m;         /* ... from this many token rows (4096) */
+    int ppgemm_all;           /* 1: every epilogue flavour takes ppgemm whatever the contraction length (production: GELU-dual from K >= 512) */
+    int ppgemm_grid;          /* workgroups of a ppgemm launch (0 = one per CU, sized by the fullest XCD) */
+    int ppgemm_tn_items;      /* token slices per output tile of ppgemm_tn (0 = fill the chip) */
+    int one_per_cu_grid;      /* grid cap of the one-workgroup-per-CU kernels: stem forward / weight gradient, chain-MLP weight gradient (0 = 256) */
+    int stem;                 /* 1: uint8 planes take the stem kernels (stem.hpp) */
+    int stem_depth;           /* software-pipeline depth of the stem forward's plane loads: 4 or 5 */
+    int mlp_tm;               /* token-tile height of the LDS-staged fused MLP at bf16 C = 64: 0 / 64, or 128 */
+    int mlp_chain;            /* 1: C = 64 MLP halves take the register-chained kernels (mlp_chain.hpp) */
+    int mlp_chain_wgrad;      /* 1: ... including the weight-gradient half */
+    int chain_resident;       /* persistent workgroups of the chain-MLP / dgrad_ln kernels */
+    int attn_block_resident;  /* persistent workgroups of the fused attention half (attn_block.hpp) */
+    int dgrad_ln;             /* 1: rvt_linear_dgrad_ln_supported may say yes */
+    /* ---- routes taken by the host-side stage driver (rvt_amd/stage.py reads them back through rvt_get_tuning) ---- */
+    int route_fused_mlp;      /* -1: by measurement (C = 64 all halves, C = 128 forward); 0: op-by-op; 1: every supported half */
+    int route_mlp_bwd_fused;  /* 1: MLP backward recomputed on chip from (dxout, xmid) where built */
+    int route_attn_block;     /* 1: fused attention half where built (C = 64) */
+    int route_lstm_scan;      /* -1: time loop in the kernel where the weights stay on chip; 0: one launch per step; 1: every built width */
+    int route_lstm_scan_wgrad;/* 1: ConvLSTM weight gradients inside the reverse scan where built */
+    int route_conv_dgrad4;    /* 1: 3x3 / stride-2 conv input gradient as one gather GEMM */
+    int route_wgrad_stream;   /* 1: weight-gradient launches on a second HIP stream */
+    int reserved[12];         /* zero */
+} RvtTuning;
+#define RVT_TUNING_DEFAULTS {(int)sizeof(RvtTuning), 0, 1, 0, 512, 8192, 1, 4096, 0, 0, 0, 0, 1, 4, 0, 1, 1, 0, 0, 1, -1, 1, 1, -1, 1, 1, 0, {0}}
+void rvt_tuning_defaults(RvtTuning* t);        /* fills *t with the production defaults */
+int rvt_get_tuning(RvtTuning* t);              /* t->struct_bytes must be set by the caller */
+int rvt_set_tuning(const RvtTuning* t);
+
 /* Weight-gradient GEMMs (rvt_*_wgrad) cut the token contraction into K slices.  `ws` is their scratch for the
  * two-stage reduction: rvt_wgrad_workspace_floats(dtype, out_rows, out_cols, tokens, want_colsum) float32 elements
  * (out = dw's [rows][cols]; conv: [Cout][k*k*Cin]; lstm: [4C][2C]).  ws == NULL selects direct float atomics, which

@@ -66,7 +66,7 @@ EXPORTS = sorted(list(_SIGS) + ['rvt_last_error', 'rvt_is_emulator', 'rvt_wgrad_
                                'rvt_mlp_fused_supported', 'rvt_lstm_scan_supported', 'rvt_mlp_bwd_fused_supported',
                                'rvt_mlp_bwd_fused_ws_floats', 'rvt_attn_block_supported', 'rvt_lstm_scan_bwd_ws_floats',
                                'rvt_lstm_scan_saves_gates', 'rvt_stem_supported', 'rvt_stem_wgrad_ws_floats', 'rvt_conv_dgrad4_supported',
-                               'rvt_linear_dgrad_ln_supported'])
+                               'rvt_linear_dgrad_ln_supported', 'rvt_tuning_defaults', 'rvt_get_tuning', 'rvt_set_tuning'])
 
 
 def _bind(lib: ctypes.CDLL) -> ctypes.CDLL:
@@ -102,6 +102,12 @@ def _bind(lib: ctypes.CDLL) -> ctypes.CDLL:
     lib.rvt_stem_wgrad_ws_floats.argtypes = [_i] * 4
     lib.rvt_wgrad_workspace_floats.restype = ctypes.c_size_t
     lib.rvt_wgrad_workspace_floats.argtypes = [_i, _i, _i, _i, _i]
+    lib.rvt_tuning_defaults.restype = None
+    lib.rvt_tuning_defaults.argtypes = [_vp]
+    lib.rvt_get_tuning.restype = ctypes.c_int
+    lib.rvt_get_tuning.argtypes = [_vp]
+    lib.rvt_set_tuning.restype = ctypes.c_int
+    lib.rvt_set_tuning.argtypes = [_vp]
     return lib
 
 
@@ -121,6 +127,8 @@ def get_lib() -> ctypes.CDLL:
             raise RuntimeError('rvt_amd needs an AMD GPU (gfx950): torch.cuda.is_available() is False '
                                'and there is no CPU fallback.')
         _lib = lib
+        from . import tuning
+        tuning.push(lib)        # the caller's overrides (none = the production route) into the freshly loaded library
     return _lib
 
 
@@ -129,6 +137,9 @@ def _install_test_library(lib: Optional[ctypes.CDLL]) -> None:
     global _lib, _is_emu
     _lib = lib
     _is_emu = bool(lib is not None and lib.rvt_is_emulator())
+    if lib is not None:
+        from . import tuning
+        tuning.push(lib)
 
 
 def is_emulator() -> bool:

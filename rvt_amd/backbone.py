@@ -342,7 +342,12 @@ class _BackboneSeqFn(torch.autograd.Function):
                                                 finalize=lambda si=si: mw.finalize_stage_grads(si))
             d_from_above = d_in
             if hook is not None:          # e.g. rvt_amd.dist.StageGradReducer: start this stage's all-reduce now
-                hook(si, mw.grads[si].param_region, accumulated=accumulate[si])
+                try:
+                    hook(si, mw.grads[si].param_region, accumulated=accumulate[si])
+                except TypeError as e:      # a user-installed two-argument hook (the pre-round-3 signature)
+                    if 'accumulated' not in str(e):
+                        raise
+                    hook(si, mw.grads[si].param_region)
             if ctx.needs_input_grad[4 + 2 * si]:
                 state_grads[2 * si] = dh0.permute(0, 3, 1, 2)
                 state_grads[2 * si + 1] = dc0.permute(0, 3, 1, 2)

@@ -1,8 +1,7 @@
 #!/bin/bash
-# Build librvt_hip.so (gfx950 code object + host launchers) in-tree.  hipcc cross-compiles without a GPU.
+# Build librvt_hip.so (gfx950 code objects + host launchers) in-tree: `make -j` over the eight capi_*.hip parts.
 set -e
 cd "$(dirname "$0")"
-OUT=../librvt_hip.so
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-result \
-    -ffp-contract=off -fno-honor-nans capi.hip -o "$OUT" "$@"
-echo "built $(realpath $OUT)"
+make -j"$(nproc)" "$@" 2>&1 | grep -v "^$" || true
+test -f ../librvt_hip.so
+echo "built $(realpath ../librvt_hip.so)"

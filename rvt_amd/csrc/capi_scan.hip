@@ -1,0 +1,125 @@
+// extern "C" entry points, part 8 of 8: ConvLSTM with the time loop inside the kernel (lstm_scan.hpp).
+#include "host.hpp"
+#include "gemm.hpp"
+#include "lstm_scan.hpp"
+
+using namespace rvt;
+
+extern "C" {
+// configurations built (waves per workgroup, weights resident in LDS or streamed from L2):
+//   bf16: C = 32 (4 waves, LDS), 64 (8 fwd / 4 bwd waves, LDS), 128 (weights from L2);  f32 (parity): C = 32, 64, 128 from L2
+int rvt_lstm_scan_supported(int dtype, int C) {
+    if (dtype != RVT_BF16 && dtype != RVT_F32) return 0;
+    return C == 32 || C == 64 || C == 128;
+}
+}  // extern "C"
+template <class K> static int scan_grid(K kernel, int threads, int M, int tm) {
+    const int resident_override = tuning().gemm_resident;
+    const int n_tiles = (M + tm - 1) / tm;
+    const int per_cu = resident_per_cu(kernel, threads, 1);
+    return imax(1, imin(n_tiles, resident_override > 0 ? resident_override : 256 * per_cu));
+}
+template <class T, int C, int NW, int RB, bool W_LDS, bool W_REG = false>
+static void launch_lstm_scan_fwd(const void* x_all, void* Hall, const float* c0, float* c_last, void* Csave, const void* W,
+                                 const float* bias, void* gates_out, int M, int Tn, hipStream_t st) {
+    constexpr int TM = (NW / (C / 32)) * RB * 32;
+    auto k = lstm_scan_fwd_kernel<T, C, NW, RB, W_LDS, W_REG>;
+    hipLaunchKernelGGL(k, dim3(scan_grid(k, 64 * NW, M, TM)), dim3(64 * NW), 0, st, (const T*)x_all, (T*)Hall, c0, c_last,
+                       (T*)Csave, (const T*)W, bias, (T*)gates_out, M, Tn);
+}
+// C = 128 in bf16: weights resident in the register file (forward) / gates saved for a reverse scan that keeps W^T in registers
+static bool scan_regw_built(int dtype, int C) { return dtype == RVT_BF16 && C == 128; }
+// in-kernel weight gradients of the reverse scan: where the weights are LDS-resident (bf16, C <= 64)
+static bool scan_wgrad_built(int dtype, int C) { return dtype == RVT_BF16 && (C == 32 || C == 64); }
+template <class T, int C, int NW, bool W_LDS, bool WGRAD>
+static int lstm_scan_bwd_grid(int M) {
+    constexpr int TM = (NW / (C / 32)) * 32;
+    auto k = lstm_scan_bwd_kernel<T, C, NW, W_LDS, WGRAD>;
+    return scan_grid(k, 64 * NW, M, TM);
+}
+template <class T, int C, int NW, bool W_LDS, bool WGRAD>
+static void launch_lstm_scan_bwd(const void* x_all, const void* Hall, const void* Csave, const float* c0, const void* dH,
+                                 const float* dc_last, const void* W, const void* Wt, const float* bias, void* dx_all,
+                                 void* dz_all, void* dh0, float* dc0, float* dw, float* db, float* ws, int M, int Tn,
+                                 hipStream_t st) {
+    auto k = lstm_scan_bwd_kernel<T, C, NW, W_LDS, WGRAD>;
+    const int grid = lstm_scan_bwd_grid<T, C, NW, W_LDS, WGRAD>(M);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * NW), 0, st, (const T*)x_all, (const T*)Hall,
+                       (const T*)Csave, c0, (const T*)dH, dc_last, (const T*)W, (const T*)Wt, bias, (T*)dx_all, (T*)dz_all,
+                       (T*)dh0, dc0, ws, (const T*)nullptr, M, Tn);
+    if (WGRAD) {
+        // fold the per-workgroup partial records: the [4C][2C] weight block and the NWM bias rows are column sums over records
+        constexpr int NWM = NW / (C / 32);
+        const size_t rec = (size_t)4 * C * 2 * C + (size_t)NWM * 4 * C;
+        hipLaunchKernelGGL(strided_reduce_kernel, dim3(reduce_grid((size_t)4 * C * 2 * C)), dim3(256), 0, st, (const float*)ws, dw,
+                           grid, rec, (size_t)4 * C * 2 * C);
+        for (int m = 0; m < NWM; m++)
+            hipLaunchKernelGGL(strided_reduce_kernel, dim3(reduce_grid((size_t)4 * C)), dim3(256), 0, st,
+                               (const float*)(ws + (size_t)4 * C * 2 * C + (size_t)m * 4 * C), db, grid, rec, (size_t)4 * C);
+    }
+}
+extern "C" {
+size_t rvt_lstm_scan_bwd_ws_floats(int dtype, int C, int M) {
+    if (!scan_wgrad_built(dtype, C)) return 0;
+    const int grid = C == 32 ? lstm_scan_bwd_grid<bf16, 32, 4, true, true>(M) : lstm_scan_bwd_grid<bf16, 64, 4, true, true>(M);
+    const int NWM = 4 / (C / 32);
+    return (size_t)grid * ((size_t)4 * C * 2 * C + (size_t)NWM * 4 * C);
+}
+
+int rvt_lstm_scan_saves_gates(int dtype, int C) { return scan_regw_built(dtype, C) ? 1 : 0; }
+int rvt_lstm_scan_fwd(const void* x_all, void* Hall, const float* c0, float* c_last, void* Csave, const void* w,
+                      const float* bias, void* gates_out, int dtype, int M, int C, int T_steps, void* stream) {
+    RVT_CHECK(rvt_lstm_scan_supported(dtype, C), "lstm_scan_fwd: not built for dtype=%d C=%d", dtype, C);
+    RVT_CHECK(M >= 1 && T_steps >= 1, "lstm_scan_fwd: empty problem");
+    hipStream_t st = (hipStream_t)stream;
+    RVT_CHECK(gates_out == nullptr || scan_regw_built(dtype, C), "lstm_scan_fwd: gates are only saved by the bf16 C = 128 variant");
+#define RVT_SCAN_FWD(TT, CC, NWW, RBB, LDS) launch_lstm_scan_fwd<TT, CC, NWW, RBB, LDS>(x_all, Hall, c0, c_last, Csave, w, bias, nullptr, M, T_steps, st)
+    if (dtype == RVT_BF16) {
+        if (C == 32) RVT_SCAN_FWD(bf16, 32, 4, 1, true);
+        else if (C == 64) RVT_SCAN_FWD(bf16, 64, 8, 1, true);
+        else launch_lstm_scan_fwd<bf16, 128, 4, 1, false, true>(x_all, Hall, c0, c_last, Csave, w, bias, gates_out, M, T_steps, st);     // (64-token tiles spill: 2.3 ms against 1.65)
+    } else {             // (four waves: the f32 variants need more than the 256 registers an 8-wave workgroup leaves)
+        if (C == 32) RVT_SCAN_FWD(float, 32, 4, 1, false);
+        else if (C == 64) RVT_SCAN_FWD(float, 64, 4, 1, false);
+        else RVT_SCAN_FWD(float, 128, 4, 1, false);
+    }
+#undef RVT_SCAN_FWD
+    return check_launch("lstm_scan_fwd");
+}
+
+int rvt_lstm_scan_bwd(const void* x_all, const void* Hall, const void* Csave, const float* c0, const void* dH,
+                      const float* dc_last, const void* w, const void* wt, const float* bias, void* dx_all, void* dz_all,
+                      void* dh0, float* dc0, float* dw, float* db, float* ws, const void* gates, int dtype, int M, int C,
+                      int T_steps, void* stream) {
+    RVT_CHECK(rvt_lstm_scan_supported(dtype, C), "lstm_scan_bwd: not built for dtype=%d C=%d", dtype, C);
+    RVT_CHECK(M >= 1 && T_steps >= 1 && Csave != nullptr, "lstm_scan_bwd: empty problem / missing saved cell states");
+    hipStream_t st = (hipStream_t)stream;
+    if (gates != nullptr) {       // reverse scan on the saved gates, W^T in registers (bf16, C = 128)
+        RVT_CHECK(scan_regw_built(dtype, C) && dw == nullptr && dz_all != nullptr && M >= 1 && T_steps >= 1 && Csave != nullptr,
+                  "lstm_scan_bwd: the saved-gates variant is bf16 C = 128, writes dz_all and has no in-kernel weight gradient");
+        hipStream_t st = (hipStream_t)stream;
+        auto k = lstm_scan_bwd_kernel<bf16, 128, 4, false, false, true>;
+        hipLaunchKernelGGL(k, dim3(scan_grid(k, 256, M, 32)), dim3(256), 0, st, (const bf16*)x_all, (const bf16*)Hall,
+                           (const bf16*)Csave, c0, (const bf16*)dH, dc_last, (const bf16*)w, (const bf16*)wt, bias, (bf16*)dx_all,
+                           (bf16*)dz_all, (bf16*)dh0, dc0, (float*)nullptr, (const bf16*)gates, M, T_steps);
+        return check_launch("lstm_scan_bwd(gates)");
+    }
+    const bool wgrad = dw != nullptr;
+    RVT_CHECK(!wgrad || (scan_wgrad_built(dtype, C) && db != nullptr && ws != nullptr),
+              "lstm_scan_bwd: in-kernel weight gradients need dtype bf16, C in {32, 64}, db and a workspace");
+    RVT_CHECK(wgrad || dz_all != nullptr, "lstm_scan_bwd: dz_all required without in-kernel weight gradients");
+#define RVT_SCAN_BWD(TT, CC, NWW, LDS, WG) launch_lstm_scan_bwd<TT, CC, NWW, LDS, WG>(x_all, Hall, Csave, c0, dH, dc_last, w, wt, bias, dx_all, dz_all, dh0, dc0, dw, db, ws, M, T_steps, st)
+    if (dtype == RVT_BF16) {
+        if (C == 32) { if (wgrad) RVT_SCAN_BWD(bf16, 32, 4, true, true); else RVT_SCAN_BWD(bf16, 32, 4, true, false); }
+        else if (C == 64) { if (wgrad) RVT_SCAN_BWD(bf16, 64, 4, true, true); else RVT_SCAN_BWD(bf16, 64, 4, true, false); }
+        else RVT_SCAN_BWD(bf16, 128, 4, false, false);
+    } else {
+        if (C == 32) RVT_SCAN_BWD(float, 32, 4, false, false);
+        else if (C == 64) RVT_SCAN_BWD(float, 64, 4, false, false);
+        else RVT_SCAN_BWD(float, 128, 4, false, false);
+    }
+#undef RVT_SCAN_BWD
+    return check_launch("lstm_scan_bwd");
+}
+
+}  // extern "C"

@@ -16,6 +16,7 @@
 #endif
 #include <stdint.h>
 #include <stddef.h>
+#include "../../include/rvt_hip.h"
 
 namespace rvt {
 
@@ -417,6 +418,9 @@ __device__ __forceinline__ float sigmoid_zb(float z, float nb) { return fast_rcp
 __device__ __forceinline__ float tanh_zb(float z, float tb) {
     return fmaf(-2.0f, fast_rcp(1.0f + fast_exp2(fmaf(z, 2.8853900817779268f, tb))), 1.0f);
 }
+
+// ---- the process-wide tuning / routing record (include/rvt_hip.h; defined in capi_core.hip)
+extern ::RvtTuning g_tuning;
 
 // ---- error plumbing for the C ABI ------------------------------------------------------------------
 void set_last_error(const char* fmt, ...);

@@ -577,12 +577,13 @@ __device__ __forceinline__ void reduce_rows_32x8(const float* __restrict__ ws, i
     }
 }
 // out[i] += sum_s ws[s][i]; with t_cols > 0 the partial tiles are [count / t_cols][t_cols] and `out` is their transpose
-__global__ void __launch_bounds__(256)
+// (static: gemm.hpp is included by several translation units of the gfx950 build)
+static __global__ void __launch_bounds__(256)
 splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int nsplit, size_t count, int t_cols) {
     reduce_rows_32x8(ws, nsplit, count, [count](int s) { return (size_t)s * count; }, out, t_cols);
 }
 // out[i] += sum_s ws[s * stride + i], i < count  (per-workgroup partial RECORDS of `stride` floats each)
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 strided_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int nrec, size_t stride, size_t count) {
     reduce_rows_32x8(ws, nrec, count, [stride](int s) { return (size_t)s * stride; }, out, 0);
 }
@@ -982,7 +983,7 @@ inline void launch_gemm(const ASrc& as, const AXf& axf, const BSrc& bs, const BX
     int gx = total, panel_major = 0;
     const bool one_k = !TN && K <= BK;
     if (!TN) {                                   // persistent: exactly one resident wave of workgroups striding over the tiles
-        static const int resident_override = getenv("RVT_GEMM_RESIDENT") ? atoi(getenv("RVT_GEMM_RESIDENT")) : 0;
+        const int resident_override = g_tuning.gemm_resident;
         // workgroups per CU as the hardware will actually schedule them (registers and LDS of THIS instantiation): more
         // would queue behind the resident ones and run as a half-empty second wave
         static int per_cu_one = 0, per_cu_multi = 0;
@@ -1002,7 +1003,7 @@ inline void launch_gemm(const ASrc& as, const AXf& axf, const BSrc& bs, const BX
         if (total > resident) gx = resident;
         panel_major = (n_tiles > 1 && m_tiles >= 4 * gx) ? 1 : 0;
         if (ASrc::SPATIAL_REUSE && total > gx && (gx & 7) == 0) panel_major = 2;
-        static const int xcd_panels = getenv("RVT_GEMM_XCD_PANELS") ? atoi(getenv("RVT_GEMM_XCD_PANELS")) : 1;    // (A/B knob)
+        const int xcd_panels = g_tuning.gemm_xcd_panels;    // (A/B knob)
         if (panel_major == 0 && n_tiles > 1 && xcd_panels && total >= 8 * gx) {
             // XCD-grouped panels (tile_of, mode 3).  Only for long tile walks: the per-XCD lists differ by up to one panel, which
             // on a one- or two-round launch (the per-step ConvLSTM GEMMs: measured +16 % on rvt_lstm_dgrad) is a whole extra round.

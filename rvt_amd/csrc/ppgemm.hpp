@@ -131,7 +131,7 @@ struct PPWork {
 struct PPConv {
     int Ho, Wo, Cout, H, W, Cin;          // dY [F][Ho][Wo][Cout], dIn [F][H][W][Cin]
     FastDiv dHoWo, dWo;
-    int taps[4];                          // per N tile: bit (2 da + db)
+    int taps[8];                          // per N tile (N = 4 Cin <= 2048: up to 8 tiles): bit (2 da + db)
 };
 
 // ABL: ablation bits for profiles/probes/ppgemm_probe.hip (0 in the library): 1 no LDS-DMA / vmcnt waits, 2 no fragment reads,
@@ -146,7 +146,7 @@ ppgemm_kernel(PPMat X, PPMat W, PPEpArgs ep, int M, int N, int K, int m_tiles, i
     const int wave = wave_uniform(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int cpt = GATHER ? cv.Cout / G::BK : 0;     // K tiles per tap
-    auto nk_of = [&](int nt) __attribute__((always_inline)) { return GATHER ? __builtin_popcount(cv.taps[nt & 3]) * cpt : K / G::BK; };
+    auto nk_of = [&](int nt) __attribute__((always_inline)) { return GATHER ? __builtin_popcount(cv.taps[nt & 7]) * cpt : K / G::BK; };
     constexpr bool SIDE = EP == PP_ADD || EP == PP_SCALE_RES || EP == PP_MUL;
 
     PPWork work;
@@ -208,7 +208,7 @@ ppgemm_kernel(PPMat X, PPMat W, PPEpArgs ep, int M, int N, int K, int m_tiles, i
                 int tap = 0, cnt = 0;
 #pragma unroll
                 for (int t = 0; t < 4; t++) {        // the tidx-th tap of this N tile
-                    const int on = (cv.taps[nt & 3] >> t) & 1;
+                    const int on = (cv.taps[nt & 7] >> t) & 1;
                     if (on && cnt == tidx) tap = t;
                     cnt += on;
                 }
@@ -238,7 +238,7 @@ ppgemm_kernel(PPMat X, PPMat W, PPEpArgs ep, int M, int N, int K, int m_tiles, i
         int v = vx0 + i * ldx64;
         if (GATHER) {
             const bool kill = ((d.mask >> i) & 1) | (d.da & (d.mask >> (4 + i)) & 1) | (d.db & (d.mask >> (8 + i)) & 1);
-            v = kill ? 0x40000000 : v;               // out of range whatever the scalar offset: the DMA writes zeros
+            v = kill ? (int)0x80000000u : v;         // beyond any permitted extent (the descriptor spans < 2^31 bytes), whatever the scalar offset: the DMA writes zeros
         }
         if (!(ABL & 1)) pp_glds16(d.rx, smem, stage * G::STAGE + i * G::UNIT + lds0, v, d.sx);
     };
@@ -527,7 +527,7 @@ template <int EP, int GATHER = 0>
 inline void launch_ppgemm(const PPMat& X, const PPMat& W, const PPEpArgs& ep, int M, int N, int K, hipStream_t stream,
                           const PPConv& cv = PPConv()) {
     const int m_tiles = (M + 255) / 256, n_tiles = N / 256;
-    static const int grid_override = getenv("RVT_PPGEMM_GRID") ? atoi(getenv("RVT_PPGEMM_GRID")) : 0;      // (tests: small grids walk several tiles)
+    const int grid_override = g_tuning.ppgemm_grid;      // (tests: small grids walk several tiles)
     // panels are dealt to XCDs (PPWork): XCD 0 owns the most tiles, ceil(m_tiles / 8) * n_tiles; a grid cut to the TOTAL tile
     // count gives every XCD total / 8 workgroups and the fullest XCD's first workgroups a second tile - twice the critical path
     // on a one-round launch (5760 x 2048 x 1024: 184 tiles, 56 us at 184 workgroups).  Size the per-XCD share by the fullest XCD.

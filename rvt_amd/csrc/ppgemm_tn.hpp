@@ -249,13 +249,13 @@ ppgemm_tn_kernel(const bf16* __restrict__ dY, int ldy, const bf16* __restrict__ 
 
 // host side ------------------------------------------------------------------------------------------------------------
 inline bool ppgemm_tn_shape_ok(int M, int N, int K, int ldy, int ldx, int kcut) {
-    static const int min_m = getenv("RVT_PPGEMM_MIN_M") ? atoi(getenv("RVT_PPGEMM_MIN_M")) : 4096;
+    const int min_m = g_tuning.ppgemm_min_m;
     return N % 256 == 0 && K % 256 == 0 && kcut % 256 == 0 && ldy % 8 == 0 && ldx % 8 == 0 && M >= min_m &&
            (size_t)64 * (size_t)(ldy > ldx ? ldy : ldx) * 2 + 512 < (1ull << 31);
 }
 // token slices: as many as fill the chip once (one item per CU), at least 4 steps of 64 tokens each
 inline int ppgemm_tn_slices(int M, int N, int K) {
-    static const int items_override = getenv("RVT_PPGEMM_TN_ITEMS") ? atoi(getenv("RVT_PPGEMM_TN_ITEMS")) : 0;     // (tests: small)
+    const int items_override = g_tuning.ppgemm_tn_items;     // (tests: small)
     const int tiles = (N / 256) * (K / 256);
     // slice s runs on XCD s % 8 (32 CUs each): a multiple of 8 slices with no more than 32 items per XCD, or the surplus
     // items of the fuller XCDs run as a second round (measured on dW[1536][512]: 21 slices = 0.38 ms, 16 slices = see profiles/r3)

@@ -26,8 +26,12 @@ class GraphedStep:
         # models whose kernel-side weight copies the captured step re-packs: a replay updates the parameters without bumping
         # their version counters on the host, so the next inference forward must not trust its cache
         self.models = tuple(models)
+        # SIDE EFFECT: the captured step needs stable gradient addresses, so the models switch to zero-copy gradient hand-off
+        # (rvt_amd/backbone.py: .grad = persistent bucket views, torch.autograd.grad sees no backbone gradients); close()
+        # restores the flags for later eager use of the same modules
+        self._saved_flags = [getattr(m, 'zero_copy_grads', False) for m in self.models]
         for m in self.models:
-            m.zero_copy_grads = True             # stable gradient addresses inside the captured step
+            m.zero_copy_grads = True
         dev = torch.device('cuda', torch.cuda.current_device()) if device is None else device
         for _ in range(max(1, warmup)):          # eager warm-up: sizes every grow-only workspace, the occupancy caches and
             fn()                                 # the optimizer state before anything is recorded
@@ -38,6 +42,15 @@ class GraphedStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             fn()
+
+    def close(self) -> None:
+        """Drop the graph and give the models their gradient hand-off mode back (eager use after a captured phase)."""
+        self.graph = None
+        for m, f in zip(self.models, self._saved_flags):
+            m.zero_copy_grads = f
+            for p in m.parameters():
+                p.grad = None            # bucket views would be overwritten by the next eager backward
+            m.invalidate_weight_cache()
 
     def __call__(self) -> None:
         self.graph.replay()

@@ -16,11 +16,9 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
 
-import os
-
 import torch
 
-from . import ops
+from . import ops, tuning
 from .weights import StageGrads, StageWeights
 
 
@@ -35,14 +33,14 @@ def use_fused_mlp(dtype, C: int, what: str) -> bool:
           C=64 : training forward 3.00 / 3.72, inference forward 2.03 / 3.72, backward dgrad chain 2.31 / 3.51 -> fused
           C=128: training forward 1.75 / 2.11, inference forward 1.53 / 2.11                                    -> fused
                  backward dgrad chain 2.19 / 1.89 (one workgroup per CU: registers)                            -> chain
-    RVT_FUSED_MLP=1 forces every supported case (used by the parity tests), =0 disables all; RVT_MLP_BWD_FUSED=0 disables
-    only the everything-on-chip backward."""
-    mode = os.environ.get('RVT_FUSED_MLP', 'auto')
+    tuning.route_fused_mlp = 1 forces every supported case (used by the parity tests), 0 disables all;
+    tuning.route_mlp_bwd_fused = 0 disables only the everything-on-chip backward."""
+    mode = tuning.get('route_fused_mlp')
     if what == 'bwd_fused':
-        return mode != '0' and os.environ.get('RVT_MLP_BWD_FUSED', '1') != '0' and ops.mlp_bwd_fused_supported(dtype, C)
-    if mode == '0' or not ops.mlp_fused_supported(dtype, C):
+        return mode != 0 and tuning.get('route_mlp_bwd_fused') != 0 and ops.mlp_bwd_fused_supported(dtype, C)
+    if mode == 0 or not ops.mlp_fused_supported(dtype, C):
         return False
-    if mode == '1':
+    if mode == 1:
         return True
     return C == 64 or (C == 128 and what.startswith('fwd'))
 
@@ -50,22 +48,22 @@ def use_fused_mlp(dtype, C: int, what: str) -> bool:
 def use_attn_block(dtype, C: int, dh: int, n_tok: int, training: bool = False) -> bool:
     """Attention half of a block (norm1, qkv, partition attention, proj, LayerScale + residual) as ONE kernel per direction
     (csrc/attn_block.hpp, one wave per partition) instead of LayerNorm + linear + attention core + linear (+ their
-    backward chain): where it is built (C = 64, dim_head 32, partitions of 33..96 tokens).  RVT_ATTN_BLOCK=0 disables."""
+    backward chain): where it is built (C = 64, dim_head 32, partitions of 33..96 tokens).  tuning.route_attn_block = 0 disables."""
     # partitions of more than 64 tokens (Gen1: 8 x 10) have a fused forward only; a forward that keeps activations for a
     # backward therefore takes the op-by-op chain there
     if training and n_tok > 64:
         return False
-    return os.environ.get('RVT_ATTN_BLOCK', '1') != '0' and ops.attn_block_supported(dtype, C, dh, n_tok)
+    return tuning.get('route_attn_block') != 0 and ops.attn_block_supported(dtype, C, dh, n_tok)
 
 
 def use_lstm_scan(dtype, C: int, dws) -> bool:
     """ConvLSTM with the time loop inside the kernel (csrc/lstm_scan.hpp) instead of one launch per step: only the 1x1-conv
     cell (dws_conv False — every shipped config); by default where the weights stay resident in LDS (C <= 64), C = 128
-    (weights streamed from L2) with RVT_LSTM_SCAN=1 (all supported widths; the parity tests) ; =0 disables."""
-    mode = os.environ.get('RVT_LSTM_SCAN', 'auto')
-    if mode == '0' or dws is not None or not ops.lstm_scan_supported(dtype, C):
+    (weights streamed from L2) with tuning.route_lstm_scan = 1 (all supported widths; the parity tests); 0 disables."""
+    mode = tuning.get('route_lstm_scan')
+    if mode == 0 or dws is not None or not ops.lstm_scan_supported(dtype, C):
         return False
-    return True if mode == '1' else (C <= 64 or ops.lstm_scan_saves_gates(dtype, C))
+    return True if mode == 1 else (C <= 64 or ops.lstm_scan_saves_gates(dtype, C))
 
 
 class SideStream:
@@ -81,8 +79,8 @@ class SideStream:
     def __init__(self, like: Tensor):
         # off by default since round 2: with the fused stage-1 kernels the step on ONE stream costs exactly the sum of its
         # kernels' isolated times (98.6 ms, profiles/r2/op_breakdown_serial_r2i.txt) and the second stream only adds
-        # contention (100.7 ms); RVT_WGRAD_STREAM=1 re-enables it
-        self.enabled = like.is_cuda and os.environ.get('RVT_WGRAD_STREAM', '0') == '1'
+        # contention (100.7 ms); tuning.route_wgrad_stream = 1 re-enables it
+        self.enabled = like.is_cuda and tuning.get('route_wgrad_stream') == 1
         self._keep = []
         if self.enabled:
             key = like.device.index
@@ -278,7 +276,7 @@ def stage_seq_backward(sw: StageWeights, g: StageGeom, sv: StageSaved, dH: Optio
         # (bf16, C <= 64) the weight gradients are accumulated in the same kernel and dz never exists in HBM
         dh_rec = torch.empty((B, H, W, C), dtype=dt, device=dev)
         dc_rec = torch.empty((B, H, W, C), dtype=f32, device=dev)
-        lstm_wgrad_done = sv.gates is None and os.environ.get('RVT_LSTM_SCAN_WGRAD', '1') != '0' and \
+        lstm_wgrad_done = sv.gates is None and tuning.get('route_lstm_scan_wgrad') != 0 and \
             ops.lstm_scan_wgrad_supported(dt, C, B * H * W)
         if not lstm_wgrad_done:
             dz = torch.empty((T, B, H, W, 4 * C), dtype=dt, device=dev)
@@ -425,7 +423,7 @@ def stage_seq_backward(sw: StageWeights, g: StageGeom, sv: StageSaved, dH: Optio
     side.run(conv_wgrad_fn, sv.inp, dy0)
     d_in = None
     if need_input_grad:
-        if sw.conv_wd4 is not None and os.environ.get('RVT_CONV_DGRAD4', '1') != '0' and \
+        if sw.conv_wd4 is not None and tuning.get('route_conv_dgrad4') != 0 and \
                 ops.conv_dgrad4_supported(dt, g.H_in, g.W_in, g.Cin, C, g.k, g.stride, g.pad, F_):
             d_in = ops.conv_dgrad4(dy0, sw.conv_wd4, prev_cot, g.H_in, g.W_in, g.Cin)      # one launch (2 x 2 pixel blocks)
         else:

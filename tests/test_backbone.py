@@ -82,14 +82,14 @@ def test_backbone_fp32_vs_reference_golden_emu(name):
 
 
 @pytest.mark.parametrize('dtype,rtol,grtol', [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 3e-2, 5e-2)])
-def test_backbone_fused_mlp_path_emu(monkeypatch, dtype, rtol, grtol):
-    """Opt-in fused-MLP route (RVT_FUSED_MLP=1; stages with C in {64,128}) against the reference golden."""
-    from rvt_amd import _lib
+def test_backbone_fused_mlp_path_emu(dtype, rtol, grtol):
+    """Opt-in fused-MLP route (tuning.route_fused_mlp = 1; stages with C in {64,128}) against the reference golden."""
+    from rvt_amd import _lib, tuning
     from tests.backends import emu_library
-    monkeypatch.setenv('RVT_FUSED_MLP', '1')
     _lib._install_test_library(emu_library())
     try:
-        got = run_hip_case('micro', torch.device('cpu'), dtype, with_batch2=False)
+        with tuning.override(route_fused_mlp=1):
+            got = run_hip_case('micro', torch.device('cpu'), dtype, with_batch2=False)
     finally:
         _lib._install_test_library(None)
     compare(got, load_golden('micro'), rtol=rtol, what='fused-MLP route vs reference [micro]', grad_rtol=grtol)
@@ -97,9 +97,10 @@ def test_backbone_fused_mlp_path_emu(monkeypatch, dtype, rtol, grtol):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('dtype,rtol,grtol', [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 3e-2, 5e-2)])
-def test_backbone_fused_mlp_path_gpu(monkeypatch, dtype, rtol, grtol):
-    monkeypatch.setenv('RVT_FUSED_MLP', '1')
-    got = run_hip_case('micro', torch.device('cuda', 0), dtype, with_batch2=False)
+def test_backbone_fused_mlp_path_gpu(dtype, rtol, grtol):
+    from rvt_amd import tuning
+    with tuning.override(route_fused_mlp=1):
+        got = run_hip_case('micro', torch.device('cuda', 0), dtype, with_batch2=False)
     compare(got, load_golden('micro'), rtol=rtol, what='fused-MLP route vs reference [micro]', grad_rtol=grtol)
 
 

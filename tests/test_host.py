@@ -30,7 +30,7 @@ def test_hip_library_loads_and_exports_every_symbol():
     """The gfx950 build must dlopen on a GPU-less host and export everything include/rvt_hip.h declares
     (no compute call is made)."""
     csrc = os.path.join(ROOT, 'rvt_amd', 'csrc')
-    srcs = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [os.path.join(ROOT, 'include', 'rvt_hip.h')]
+    srcs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(('.hip', '.hpp'))] + [os.path.join(ROOT, 'include', 'rvt_hip.h')]
     if not os.path.exists(_lib.LIB_PATH) or any(os.path.getmtime(f) > os.path.getmtime(_lib.LIB_PATH) for f in srcs):
         subprocess.run(['bash', os.path.join(csrc, 'build.sh')], check=True, capture_output=True)
     lib = _lib.load_library()
@@ -138,8 +138,8 @@ DDP_BACKBONE_WORKER = r'''
 import os, sys, torch, torch.distributed as dist
 root = sys.argv[1]
 sys.path.insert(0, root)
-os.environ.setdefault('RVT_GEMM_RESIDENT', '3')
-from rvt_amd import _lib
+from rvt_amd import _lib, tuning
+tuning.use(**dict(tuning.TEST_GEOMETRY, gemm_resident=3))
 from rvt_amd.dist import StageGradReducer
 from tests.backends import emu_library
 from tests.test_backbone import build_model

@@ -507,11 +507,14 @@ def test_stem(backend, case):
     assert float(pad_cols.abs().max()) == 0.0 if cp > Cin else True
 
 
-@pytest.mark.parametrize('case', [(3, 16, 24, 64, 128), (5, 24, 16, 128, 64), (9, 8, 16, 256, 128)])      # F, H, W, Cin, Cout
+@pytest.mark.parametrize('case', [(3, 16, 24, 64, 128), (5, 24, 16, 128, 128), (9, 8, 16, 256, 128), (9, 8, 16, 384, 128),
+                                  (9, 8, 16, 512, 128)])      # F, H, W, Cin, Cout
 def test_conv_dgrad4(backend, case):
     """Input gradient of the 3x3 / 2 / 1 conv as one product over 2x2 pixel blocks (csrc/ppgemm.hpp GATHER) vs fp64 autograd and vs
     the four parity-class launches: image borders, ragged last row tile, with and without an added cotangent, the per-tile tap lists
-    (Cin = 64: one N tile with all taps; 128: two tiles, 2 + 4 taps; 256: four tiles, 1 + 2 + 2 + 4 taps)."""
+    (Cin = 64: one N tile with all taps; 128: two tiles, 2 + 4 taps; 256: four tiles, 1 + 2 + 2 + 4 taps; 384 / 512: six / eight
+    tiles - ADVICE r3: the tap table had four entries).  Cout < 128 is rejected (a single-tap tile needs two K tiles)."""
+    assert not ops.conv_dgrad4_supported(torch.bfloat16, 16, 16, 128, 64, 3, 2, 1, 8)
     Fr, H, W, Cin, Cout = case
     dt = torch.bfloat16
     assert ops.conv_dgrad4_supported(dt, H, W, Cin, Cout, 3, 2, 1, Fr)

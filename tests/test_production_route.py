@@ -1,0 +1,192 @@
+"""Parity on the route bench.py times.
+
+Every other GPU test runs on the unit tests' TEST_GEOMETRY (tests/conftest.py: 8-workgroup grids, 128-token split-K
+slices, every kernel family forced on) because test-size problems would otherwise never walk more than one tile.  The tests
+here switch to `tuning.production()` — the library defaults: occupancy-sized persistent grids over 256 CUs, >= 8192-token
+split-K slices, XCD-dealt ppgemm_tn slices, the production choice of per-step vs in-kernel ConvLSTM scan — and check
+
+  (a) the reference goldens of the BASELINE GPU configurations (T = 21, recorded from the unmodified reference at B = 1 / 2)
+      in fp32 (<= 1e-3, the north_star bar) and bf16 (stated bound), on the production route;
+  (b) the BENCH-SIZE step (RVT-Base 1 Mpx, T = 21, B = 24, bf16 — BASELINE configs[2]) through two size-independent
+      properties that tie it to (a): the backbone has no cross-sample op, so sample b of the batch must reproduce the B = 1
+      run of that sample, and the parameter gradient of the batch must be the SUM of the per-sample gradients;
+  (c) every linear-family entry point at the bench's own GEMM shapes (M = 7 741 440 / 1 935 360 / 483 840 / 120 960 token
+      rows) against an fp32 product on sampled rows / the full fp32 weight gradient;
+  (d) the streaming-inference route (T = 1 calls with carried ConvLSTM state, BASELINE configs[4]) against forward_sequence.
+"""
+import numpy as np
+import pytest
+import torch
+
+from rvt_amd import RNNDetector, backbone_config, ops, tuning
+from tests.harness import compare, load_golden
+from tests.test_backbone import run_hip_case
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device('cuda', 0)
+
+
+def test_production_route_is_the_library_default(production_route):
+    cur = tuning.current()
+    assert tuning.overrides() == {}
+    assert cur['gemm_resident'] == 0 and cur['ppgemm_grid'] == 0 and cur['ppgemm_min_m'] == 4096
+    assert cur['wgrad_slice_tokens'] == 8192 and cur['ppgemm_all'] == 0 and cur['route_lstm_scan'] == -1
+    assert cur['one_per_cu_grid'] == 0 and cur['route_fused_mlp'] == -1
+
+
+@pytest.mark.parametrize('name', ['base_1mpx_t21', 'tiny_gen1_t21', 'base_1mpx', 'base_gen1'])
+def test_production_route_fp32_vs_reference_golden(production_route, name):
+    """north_star bar (<= 1e-3 rel on features, states, every parameter gradient) on the production launch geometry."""
+    got = run_hip_case(name, DEV, torch.float32)
+    worst = compare(got, load_golden(name), rtol=1e-3, what=f'production route fp32 vs reference [{name}]', grad_rtol=1e-3)
+    print(f'{name}: worst err/tol = {worst:.3e}')
+
+
+@pytest.mark.parametrize('name', ['base_1mpx_t21', 'tiny_gen1_t21'])
+def test_production_route_bf16_vs_reference_golden(production_route, name):
+    """bf16 (the dtype bench.py times) against the fp32 reference over T = 21: 4e-2 of the tensor scale on features / cell
+    states, 5e-2 on gradient norms / samples (same stated bound as tests/test_backbone.py on the test geometry)."""
+    got = run_hip_case(name, DEV, torch.bfloat16, with_batch2=False)
+    worst = compare(got, load_golden(name), rtol=4e-2, what=f'production route bf16 vs reference [{name}]', grad_rtol=5e-2)
+    print(f'{name}: worst err/tol = {worst:.3e}')
+
+
+def _bench_model(dtype, size='base', dataset='gen4'):
+    torch.manual_seed(0)
+    m = RNNDetector(backbone_config(size, dataset), compute_dtype=dtype).to(DEV)
+    g = torch.Generator().manual_seed(2)
+    with torch.no_grad():                 # LayerScale 1e-5 hides the attention / MLP branches (tests/test_properties.py): U(0.5, 1.5)
+        for n, p in m.named_parameters():
+            if n.endswith('.gamma'):
+                p.copy_((0.5 + torch.rand(p.shape, generator=g)).to(DEV))
+    return m
+
+
+def _run(m, xs, cots):
+    for p in m.parameters():
+        p.grad = None
+    feats, states = m.forward_sequence(xs, None)
+    torch.autograd.backward([feats[s] for s in (2, 3, 4)], cots)
+    return feats, states, {n: p.grad.detach().float().clone() for n, p in m.named_parameters()}
+
+
+@pytest.mark.parametrize('B,T', [(24, 21)])
+def test_bench_size_step_batch_independence_and_gradient_additivity(production_route, B, T):
+    """BASELINE configs[2] at its full size on the route bench.py times.  No op of the backbone mixes samples, hence
+    feats(batch)[b] == feats(sample b alone) and grad(batch) == sum_b grad(sample b alone); the B = 1 route is pinned to
+    the reference by test_production_route_*_golden[base_1mpx_t21] above.  bf16: 2e-2 of the tensor scale on features
+    (both sides are bf16 runs of the same arithmetic; they differ in tile walks and split-K summation order only),
+    3e-2 on gradients relative to the gradient's max."""
+    m = _bench_model(torch.bfloat16)
+    geoms = m.stage_geoms(*m.in_res_hw)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    xs = torch.randint(0, 11, (T, B, 20, 360, 640), generator=g, dtype=torch.uint8, device=DEV)
+    cots = [torch.randn((T, B, geoms[s].H, geoms[s].W, geoms[s].C), generator=g, device=DEV,
+                        dtype=torch.bfloat16).permute(0, 1, 4, 2, 3) for s in (1, 2, 3)]
+    feats, states, grads = _run(m, xs, cots)
+    feats = {s: feats[s].detach().float() for s in (1, 2, 3, 4)}
+    cells = [c.detach().float() for _, c in states]
+    gsum = {n: torch.zeros_like(v) for n, v in grads.items()}
+    worst_f = 0.0
+    for b in range(B):
+        f1, s1, g1 = _run(m, xs[:, b:b + 1].contiguous(), [c[:, b:b + 1].contiguous() for c in cots])
+        for n in gsum:
+            gsum[n] += g1[n]
+        if b in (0, 7, B - 1):
+            for s in (1, 2, 3, 4):
+                want = f1[s].detach().float()[:, 0]
+                err = (feats[s][:, b] - want).abs().max().item() / want.abs().max().item()
+                worst_f = max(worst_f, err)
+                assert err < 2e-2, f'stage {s} features of sample {b}: batch vs alone rel err {err:.3e}'
+            for s in range(4):
+                want = s1[s][1].detach().float()[0]
+                err = (cells[s][b] - want).abs().max().item() / max(want.abs().max().item(), 1e-6)
+                assert err < 2e-2, f'stage {s + 1} cell state of sample {b}: rel err {err:.3e}'
+    worst_g = 0.0
+    for n, v in grads.items():
+        scale = max(gsum[n].abs().max().item(), 1e-12)
+        err = (v - gsum[n]).abs().max().item() / scale
+        worst_g = max(worst_g, err)
+        assert err < 3e-2, f'grad {n}: batch vs sum of samples rel err {err:.3e}'
+    print(f'bench-size step: worst feature err {worst_f:.3e}, worst gradient err {worst_g:.3e}')
+
+
+# the linear products of one RVT-Base 1Mpx step (T = 21, B = 24): (stage, token rows, C)
+BENCH_STAGES = [(1, 7741440, 64), (2, 1935360, 128), (3, 483840, 256), (4, 120960, 512)]
+
+
+def _rnd(*shape, scale=1.0, gen=None):
+    return (torch.randn(*shape, device=DEV, generator=gen) * scale).to(torch.bfloat16)
+
+
+@pytest.mark.parametrize('stage,M,C', BENCH_STAGES)
+def test_bench_shape_linear_family_vs_fp32(production_route, stage, M, C):
+    """rvt_linear_fwd / _gelu_fwd / _scale_res_fwd / _dgrad (plain, + add, * mul) / _wgrad at the bench's own shapes
+    (qkv, proj, fc1, fc2 of the stage) on the production route, against fp32 torch products.  Row-wise entry points: 768
+    sampled rows incl. the first and last, 2e-2 of the reference max (bf16 output rounding is 4e-3; the margin covers the
+    GELU / GELU' tables).  Weight gradients: the whole fp32 [N][K] result and the bias column sums against an fp64-accumulated
+    product over all M rows, 2e-3 of the reference max."""
+    gen = torch.Generator(device=DEV).manual_seed(100 + stage)
+    rows = torch.randint(0, M, (768,), device=DEV, generator=gen)
+    rows[0], rows[-1] = 0, M - 1
+    for label, N, K in (('qkv', 3 * C, C), ('proj', C, C), ('fc1', 4 * C, C), ('fc2', C, 4 * C)):
+        x, w = _rnd(M, K, gen=gen), _rnd(N, K, scale=K ** -0.5, gen=gen)
+        b, gam = torch.randn(N, device=DEV, generator=gen), 0.5 + torch.rand(N, device=DEV, generator=gen)
+        res = _rnd(M, N, gen=gen)
+        ref = x[rows].float() @ w.float().t()
+
+        def check(what, got, want, tol=2e-2):
+            err = (got[rows].float() - want).abs().max().item() / max(want.abs().max().item(), 1e-6)
+            assert err < tol, f'stage {stage} {label} {what} (M={M} N={N} K={K}): rel err {err:.3e}'
+
+        check('linear_fwd', ops.linear_fwd(x, w, b), ref + b)
+        check('linear_scale_res_fwd', ops.linear_scale_res_fwd(x, w, b, gam, res), res[rows].float() + gam * (ref + b))
+        check('linear_dgrad', ops.linear_dgrad(x, w), ref)
+        check('linear_dgrad+add', ops.linear_dgrad(x, w, add=res), ref + res[rows].float())
+        check('linear_dgrad*mul', ops.linear_dgrad(x, w, mul=res), ref * res[rows].float())
+        if label == 'fc1':
+            hg, hgp = ops.linear_gelu_fwd(x, w, b, want_grad=True)
+            h = (ref + b).double()
+            phi = 0.5 * (1 + torch.erf(h / 2 ** 0.5))
+            check('linear_gelu_fwd g', hg, (h * phi).float())
+            check('linear_gelu_fwd gp', hgp, (phi + h * torch.exp(-0.5 * h * h) / (2 * np.pi) ** 0.5).float())
+            del hg, hgp
+        # weight gradient dW[N][K] = dy[M][N]^T x[M][K] (+ column sums of dy), fp32 out
+        dy = res
+        dw, cs = torch.zeros(N, K, device=DEV), torch.zeros(N, device=DEV)
+        ops.linear_wgrad(dy, x, dw, colsum_out=cs)
+        want = torch.zeros(N, K, device=DEV, dtype=torch.float64)
+        wcs = torch.zeros(N, device=DEV, dtype=torch.float64)
+        step = 1 << 19
+        for r0 in range(0, M, step):
+            a = dy[r0:r0 + step].float()
+            want += (a.t() @ x[r0:r0 + step].float()).double()
+            wcs += a.double().sum(0)
+        err = (dw.double() - want).abs().max().item() / want.abs().max().item()
+        assert err < 2e-3, f'stage {stage} {label} linear_wgrad (M={M} N={N} K={K}): rel err {err:.3e}'
+        err = (cs.double() - wcs).abs().max().item() / wcs.abs().max().item()
+        assert err < 2e-3, f'stage {stage} {label} linear_wgrad column sums: rel err {err:.3e}'
+        del x, w, res, dy, dw, want
+
+
+@pytest.mark.parametrize('dtype,B,tol', [(torch.bfloat16, 64, 2e-2), (torch.float32, 4, 1e-4)])
+def test_streaming_route_matches_forward_sequence(production_route, dtype, B, tol):
+    """BASELINE configs[4]: T = 1 forward calls with the ConvLSTM state carried between them (modules/detection.py:231-255),
+    3 steps, against ONE forward_sequence over the same 3 frames.  Same arithmetic on different kernels (per-step cell
+    launches reading the carried state in place vs the in-kernel scan): fp32 <= 1e-4, bf16 <= 2e-2 of the tensor scale."""
+    m = _bench_model(dtype)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    xs = torch.randint(0, 11, (3, B, 20, 360, 640), generator=g, dtype=torch.uint8, device=DEV)
+    with torch.no_grad():
+        feats_seq, states_seq = m.forward_sequence(xs, None)
+        states = None
+        for t in range(3):
+            out, states = m(xs[t], states)
+            for s in (1, 2, 3, 4):
+                want = feats_seq[s][t].float()
+                err = (out[s].float() - want).abs().max().item() / want.abs().max().item()
+                assert err < tol, f'step {t} stage {s}: streaming vs sequence rel err {err:.3e}'
+        for s in range(4):
+            for a, b in zip(states[s], states_seq[s]):
+                err = (a.float() - b.float()).abs().max().item() / max(b.float().abs().max().item(), 1e-6)
+                assert err < tol, f'final state of stage {s + 1}: rel err {err:.3e}'
