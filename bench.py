@@ -27,6 +27,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+import opmodel  # noqa: E402  (algorithmic FLOP / byte model of every C-ABI entry point)
+
 # ALGORITHMIC matmul FLOPs per event-tensor (SURVEY.md §8d / BASELINE.md §2; 2*MAC of conv+linear+attention,
 # fwd+bwd = 3*fwd - stem dgrad)
 WORKLOADS = {
@@ -35,16 +37,13 @@ WORKLOADS = {
     'tiny_gen1': dict(size='tiny', dataset='gen1', hw=(240, 304), T=21, B=8, f_fwd=2.001e9, f_fwdbwd=5.683e9,
                       label='RVT-Tiny, Gen1 20x240x304 (padded 256x320), T=21, B=8/GPU'),
 }
-PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}     # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
-
-
-def linear_flops(M, N, K):
-    return 2.0 * M * N * K
+PEAK_TFLOPS = opmodel.PEAK_TFLOPS                 # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = opmodel.HBM_PEAK_GBS               # MI355X HBM3E (MI355X_MICROARCH.md)
 
 
 class OpTimer:
     """HIP-event timing of individual C-ABI launches on torch's current stream (the stream the kernels are
-    launched on).  Used for the `roofline` object: per-launch duration of the dominant kernel family."""
+    launched on).  Used for the `roofline` objects: per-launch duration of every entry point."""
 
     def __init__(self):
         self.records = {}
@@ -79,54 +78,90 @@ class OpTimer:
         return out
 
 
-def gemm_flops_of_call(name, args):
-    """Algorithmic FLOPs of one launch of a GEMM-family entry point, from its own (trailing) arguments:
-    every signature ends  ..., dtype, M, N, K[, gelu_in], stream  (LSTM: ..., dtype, M, C, stream)."""
-    if name in ('rvt_linear_fwd', 'rvt_linear_scale_res_fwd', 'rvt_linear_wgrad'):
-        M, N, K = args[-5], args[-4], args[-3]
-        return linear_flops(M, N, K)
-    if name in ('rvt_linear_dgrad', 'rvt_linear_gelu_fwd'):
-        M, N, K = args[-4], args[-3], args[-2]
-        return linear_flops(M, N, K)
-    if name in ('rvt_lstm_fwd', 'rvt_lstm_dgrad', 'rvt_lstm_wgrad'):
-        M, C = args[-3], args[-2]
-        return linear_flops(M, 4 * C, 2 * C)
-    return None
+def shape_key(args):
+    """The integer (non-pointer-sized) arguments of a launch: dtype and the problem sizes - what tells two kernels of one
+    entry point apart (pointers are > 2^31 or None)."""
+    return tuple(x for x in args if isinstance(x, int) and not isinstance(x, bool) and 0 <= x < (1 << 31))[-8:]
 
 
-def gemm_bytes_of_call(name, args, elt):
-    """Algorithmic HBM bytes of one launch: every operand and result crosses HBM exactly once.
-    Linear-family launches move the token-major activations ([M][N] and [M][K], `elt` bytes per element); the
-    weight / weight-gradient panel (N*K) is read or written once."""
-    if name in ('rvt_linear_fwd', 'rvt_linear_scale_res_fwd', 'rvt_linear_wgrad'):
-        M, N, K = args[-5], args[-4], args[-3]
-    elif name in ('rvt_linear_dgrad', 'rvt_linear_gelu_fwd'):
-        M, N, K = args[-4], args[-3], args[-2]
-    elif name in ('rvt_lstm_fwd', 'rvt_lstm_dgrad', 'rvt_lstm_wgrad'):
-        M, N, K = args[-3], 4 * args[-2], 2 * args[-2]
-    else:
+def kernel_groups(records):
+    """(entry point, shape key) -> [launch records]: one group = one kernel at one problem shape."""
+    groups = {}
+    for n, recs in records.items():
+        for r in recs:
+            groups.setdefault((n, shape_key(r[2])), []).append(r)
+    return groups
+
+
+def group_roofline(key, recs, dtype_name, mfma_peak=None):
+    n, shp = key
+    ms = sum(a.elapsed_time(b) for a, b, _ in recs)
+    fb = [opmodel.model(n, r[2]) for r in recs]
+    if any(x is None for x in fb):
         return None
-    act = M * (N + K) * elt
-    if name == 'rvt_linear_scale_res_fwd':
-        act += M * N * elt                        # residual read
-    if name == 'rvt_linear_gelu_fwd':
-        act += M * N * elt                        # second output (GELU')
-    wbytes = N * K * (4 if name.endswith('wgrad') else elt)
-    return act + wbytes
+    rec = opmodel.roofline_entry(n, sum(x[0] for x in fb), sum(x[1] for x in fb), ms, len(recs), dtype_name, mfma_peak)
+    rec['shape'] = list(shp)
+    return rec
 
 
-HBM_PEAK_GBS = 8000.0                             # MI355X HBM3E (MI355X_MICROARCH.md)
-
-
-def measured_traffic(entry_point):
-    """HBM bytes per launch of `entry_point` from the committed rocprofv3 PMC passes (profiles/latest_traffic.json,
-    written by profiles/summarize_rocprof.py: 2*FETCH_SIZE + WRITE_SIZE KiB, the gfx950 correction of the guide)."""
+# kernel instantiation behind an (entry point, shape) group, as substrings of the mangled name rocprofv3 prints - used to
+# look the group's measured HBM traffic up in profiles/latest_traffic.json.  Only groups that map to ONE instantiation
+# launched at ONE shape per step are listed (others share a kernel between shapes: their per-launch average would not
+# belong to the group, and the bench reports null rather than a number that does not).
+def traffic_lookup(workload_key, key):
+    n, shp = key
+    subs = None
+    if n == 'rvt_lstm_scan_bwd':
+        subs = ['lstm_scan_bwd_kernel', f'DF16bLi{shp[-3]}E']
+    elif n == 'rvt_lstm_scan_fwd':
+        subs = ['lstm_scan_fwd_kernel', f'DF16bLi{shp[-3]}E']
+    elif n == 'rvt_mlp_fwd':
+        subs = ['mlpc_fwd_kernel' if shp[-1] == 64 else 'mlp_fwd_kernel', f'DF16bLi{shp[-1]}E']
+    elif n == 'rvt_mlp_bwd_recompute_dgrad':
+        subs = ['mlpc_bwd_dgrad_kernel']
+    elif n == 'rvt_mlp_bwd_recompute_wgrad':
+        subs = ['mlpc_bwd_wgrad_kernel']
+    elif n == 'rvt_stem_fwd':
+        subs = ['stem_fwd_kernel']
+    elif n == 'rvt_stem_wgrad':
+        subs = ['stem_wgrad_kernel']
+    elif n in ('rvt_attn_block_bwd', 'rvt_attn_block_fwd'):
+        subs = [n[4:] + '_kernel', 'Li2ELb0ELi' if shp[-1] == 1 else 'Li2ELb1ELi']      # (RVT-Base: the window block of a stage has no norm1, the grid block has)
+    if subs is None:
+        return None
     try:
         with open(os.path.join(ROOT, 'profiles', 'latest_traffic.json')) as f:
-            t = json.load(f)
-        return t[entry_point]['traffic_bytes_per_launch']
+            t = json.load(f)[workload_key]['kernels']
+        hits = [v for k, v in t.items() if all(x in k for x in subs)]
+        return hits[0]['traffic_bytes_per_launch'] if len(hits) == 1 else None
     except Exception:
         return None
+
+
+def step_traffic(workload_key):
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'latest_traffic.json')) as f:
+            return json.load(f)[workload_key]['traffic_bytes_per_step']
+    except Exception:
+        return None
+
+
+def mfma_peak_sustained(device):
+    """bf16 MFMA rate this part sustains on a pure-MFMA kernel at the clock it actually runs (rvt_probe_mfma), TFLOP/s."""
+    from rvt_amd import _lib
+    lib = _lib.get_lib()
+    scratch = torch.empty(4096 * 256, dtype=torch.float32, device=device)
+    st = _lib.stream_of(scratch)
+    best = 0.0
+    for it in range(4):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        flops = lib.rvt_probe_mfma(scratch.data_ptr(), 20000, 4096, st)
+        e1.record()
+        torch.cuda.synchronize()
+        if it:
+            best = max(best, flops / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+    return best
 
 
 def build_model(wl, dtype, device):
@@ -166,23 +201,37 @@ def cpu_baseline_worker(workload: str):
     torch.set_num_threads(ncores)
     cfgd = backbone_config(wl['size'], wl['dataset'])
     cfg = O.OracleCfg(embed_dim=cfgd.embed_dim, dim_head=cfgd.stage.attention.dim_head,
-                      partition_size=tuple(cfgd.stage.attention.partition_size))
+                      partition_size=tuple(cfgd.stage.attention.partition_size), conv_impl='aten')
     m = build_model(wl, torch.float32, 'cpu')
     params = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
-    B, T = 1, 2
+    B, T = 2, 3                    # the probe shape of BASELINE.md §3 (reference measured there: 6.2 event-tensors/s on 8 vCPUs)
     g = torch.Generator().manual_seed(1)
     xs = torch.randint(0, 11, (T, B, 20, *wl['hw']), generator=g, dtype=torch.uint8)
     best, t_start, passes = float('inf'), time.perf_counter(), 0
-    while passes < 3 and (passes == 0 or time.perf_counter() - t_start < 20.0):
+    while passes < 5 and (passes == 0 or time.perf_counter() - t_start < 25.0):
         t0 = time.perf_counter()
         feats, _ = O.sequence_forward(xs, None, params, cfg, tuple(cfgd.in_res_hw))
         loss = sum(feats[t][s].sum() for t in range(T) for s in (2, 3, 4))
         torch.autograd.grad(loss, list(params.values()), allow_unused=True)
         best = min(best, time.perf_counter() - t0)
         passes += 1
-    print(json.dumps(dict(value=round(B * T / best, 3), unit='event-tensors/s', cores=ncores, kind='port',
-                          sample=f'{wl["label"].split(",")[0]} at the same resolution, B={B}, T={T}, fp32, fwd+bwd, '
-                                 f'best of {passes} ({best:.2f} s per pass), {ncores} torch CPU threads')))
+    ratio = None
+    try:        # port / reference speed ratio measured in the authoring container (oracle/port_vs_reference.py; same ops, same cores)
+        with open(os.path.join(ROOT, 'profiles', 'r4', 'port_vs_reference.json')) as f:
+            ratio = json.load(f)['port_over_reference']
+    except Exception:
+        pass
+    out = dict(value=round(B * T / best, 3), unit='event-tensors/s', cores=ncores, kind='port',
+               sample=f'{wl["label"].split(",")[0]} at the same resolution, B={B}, T={T}, fp32, fwd+bwd, best of {passes} '
+                      f'({best:.2f} s per pass), {ncores} torch CPU threads; oracle in its ATen-op timing mode '
+                      f'(F.conv2d / F.layer_norm / F.gelu, as the reference calls them)')
+    if ratio and workload == 'base_1mpx':
+        out['port_over_reference'] = ratio
+        out['reference_estimate'] = round(B * T / best / ratio, 3)
+        out['reference_provenance'] = ('the unmodified reference cannot run on the GPU box; in the authoring container (8 vCPUs) the same '
+                                       'B=2, T=3 probe ran the reference and the port side by side: profiles/r4/port_vs_reference.json; '
+                                       'survey-time reference probe: 6.2 event-tensors/s on 8 vCPUs (BASELINE.md section 3)')
+    print(json.dumps(out))
 
 
 def cpu_baseline(workload: str):
@@ -306,13 +355,27 @@ def main():
     for _ in range(args.warmup):
         step()
 
-    # which GEMM-family entry point dominates? (one instrumented, untimed step)
+    # which kernel dominates?  One instrumented, untimed step with HIP events around EVERY launch; groups = (entry point, problem
+    # shape), i.e. one kernel at one shape; every entry point has an algorithmic FLOP / byte model (opmodel.py), so the choice is
+    # over ALL of them (round 3 could only price GEMM-family launches)
     timer = OpTimer()
     timer.install()
     step()
     prof = timer.summary()
-    dominant = max((n for n in prof if gemm_flops_of_call(n, timer.records[n][0][2]) is not None),
-                   key=lambda n: prof[n]['total_ms'])
+    sustained = mfma_peak_sustained(device) if args.dtype == 'bf16' else None
+    groups = kernel_groups(timer.records)
+    table = [r for r in (group_roofline(k, v, args.dtype) for k, v in groups.items()) if r is not None]
+    table.sort(key=lambda r: -r['ms'])
+    dom_key = max((k for k in groups if opmodel.model(k[0], groups[k][0][2]) is not None),
+                  key=lambda k: sum(a.elapsed_time(b) for a, b, _ in groups[k]))
+    dominant = dom_key[0]
+    step_ms_instrumented = sum(v['total_ms'] for v in prof.values())
+    by_entry = {}
+    for r in table:
+        e = by_entry.setdefault(r['kernel'], [0.0, 0.0, 0.0, 0])
+        e[0] += r['ms']; e[1] += r['algorithmic_gflop']; e[2] += r['algorithmic_gbyte']; e[3] += r['launches']
+    entry_table = [opmodel.roofline_entry(n, e[1] * 1e9, e[2] * 1e9, e[0], e[3], args.dtype) for n, e in
+                   sorted(by_entry.items(), key=lambda kv: -kv[1][0])[:10]]
     if args.op_breakdown and rank == 0:
         with open(args.op_breakdown, 'w') as f:
             tot = sum(v['total_ms'] for v in prof.values())
@@ -332,6 +395,7 @@ def main():
                 f.write(f'{n:28s} {str(key):60s} calls={cnt:4d} total={ms:9.3f} ms\n')
     timer.records.clear()
     timer.enabled_for = {dominant}
+    top_table = table[:12]
     # two more untimed steps: the instrumented step above perturbs the caching allocator's stream-tagged pools (the
     # weight-gradient side stream), and a timed region that still grows the pool pays hipMalloc inside it
     for _ in range(2):
@@ -406,32 +470,23 @@ def main():
     events_per_s = world * B * T / (wall / args.steps)
 
     if rank == 0:
-        # roofline of the dominant GEMM entry point: algorithmic FLOPs of its launches / HIP-event time of the
-        # same launches inside the timed region
-        recs = timer.records[dominant]
-        dom_ms = sum(a.elapsed_time(b) for a, b, _ in recs)
-        dom_flops = sum(gemm_flops_of_call(dominant, r[2]) for r in recs)
+        # roofline of the dominant kernel (entry point at one problem shape): algorithmic FLOPs / bytes of its launches inside the
+        # timed region / the HIP-event time of the same launches
         peak = PEAK_TFLOPS[args.dtype]
-        achieved = dom_flops / (dom_ms * 1e-3) / 1e12
         path_tflops = events_per_s / world * wl['f_fwdbwd'] / 1e12
-        # which roof bounds the dominant kernel?  arithmetic intensity of its launches vs the machine balance
-        elt = 2 if args.dtype == 'bf16' else 4
-        dom_bytes = sum(gemm_bytes_of_call(dominant, r[2], elt) for r in recs)
-        balance = peak * 1e12 / (HBM_PEAK_GBS * 1e9)                     # FLOP per byte at which the roofs cross
-        common = {'kernel': dominant, 'traffic': measured_traffic(dominant), 'launches': len(recs),
-                  'avg_launch_ms': round(dom_ms / len(recs), 4),
-                  'share_of_step': round(dom_ms / (eager_ms * args.steps), 3),
-                  'timing': 'HIP events on the launch stream, eager pass of the same K steps',
-                  'arithmetic_intensity_flop_per_byte': round(dom_flops / dom_bytes, 1),
-                  'algorithmic_bytes_per_launch': int(dom_bytes / len(recs)),
-                  'mfma_tflops': round(achieved, 2), 'mfma_frac': round(achieved / peak, 4)}
-        if dom_flops / dom_bytes < balance:
-            gbs = dom_bytes / (dom_ms * 1e-3) / 1e9
-            roof = {'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': round(gbs / HBM_PEAK_GBS, 4), **common}
-        else:
-            roof = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                    'frac': round(achieved / peak, 4), **common}
+        recs = [r for r in timer.records[dominant] if shape_key(r[2]) == dom_key[1]]
+        roof = group_roofline(dom_key, recs, args.dtype)
+        wkey = f'{args.workload}:{args.dtype}:B{B}:T{T}'
+        dom_ms = roof['ms']
+        ordered = {k: roof[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac')}
+        ordered['traffic'] = traffic_lookup(wkey, dom_key)
+        ordered.update({k: v for k, v in roof.items() if k not in ordered})
+        ordered.update({'algorithmic_bytes_per_launch': int(roof['algorithmic_gbyte'] * 1e9 / max(len(recs), 1)),
+                        'share_of_step': round(dom_ms / (eager_ms * args.steps), 3),
+                        'timing': 'HIP events on the launch stream around every launch of this kernel, inside the timed K steps',
+                        'chosen_as': 'largest total time of one (entry point, problem shape) group over ALL entry points '
+                                     '(instrumented step; opmodel.py prices every entry point)'})
+        roof = ordered
         out = {
             'metric': 'event-tensors/sec (fwd+bwd) RVT-Base T=21 1Mpx; % MFMA roofline' if args.workload == 'base_1mpx'
             else 'event-tensors/sec (fwd+bwd)',
@@ -447,6 +502,17 @@ def main():
             'mfma_roofline_frac_whole_step': round(path_tflops / peak, 4),
             'algorithmic_tflops_per_gpu': round(path_tflops, 2),
             'roofline': roof,
+            # the 12 heaviest kernels (entry point at one shape) and the 10 heaviest entry points of ONE instrumented step
+            # (HIP events around every launch, one stream, untimed): ms, algorithmic GFLOP / GB, which roof binds, fraction of it
+            'roofline_table': top_table,
+            'roofline_entry_points': entry_table,
+            'instrumented_step_ms': round(step_ms_instrumented, 3),
+            'hbm_traffic_per_step': {'measured_bytes': step_traffic(wkey), 'source': 'profiles/latest_traffic.json (rocprofv3 FETCH_SIZE x2 + '
+                                     'WRITE_SIZE passes of this command), null when no pass of THIS workload is committed'},
+            'mfma_peak_sustained': None if not sustained else {
+                'tflops': round(sustained, 1), 'implied_clock_ghz': round(sustained * 1e12 / (256 * 4096) / 1e9, 3),
+                'whole_step_frac_of_sustained': round(path_tflops / sustained, 4),
+                'method': 'rvt_probe_mfma: 4096 workgroups of nothing but independent v_mfma_f32_32x32x16_bf16, HIP-event timed'},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.workload)

@@ -70,6 +70,12 @@ void rvt_tuning_defaults(RvtTuning* t);        /* fills *t with the production d
 int rvt_get_tuning(RvtTuning* t);              /* t->struct_bytes must be set by the caller */
 int rvt_set_tuning(const RvtTuning* t);
 
+/* Measurement aid for bench.py (no reference counterpart): launches `workgroups` x 256 threads that issue nothing but
+ * independent v_mfma_f32_32x32x16_bf16 (`iters` x 4 per wave) and returns the FLOPs the launch executes; timed with HIP
+ * events it gives the bf16 MFMA rate this part SUSTAINS at its clock under load (the 2.5 PFLOP/s peak assumes 2.4 GHz).
+ * scratch: >= workgroups * 256 floats (never written). */
+double rvt_probe_mfma(float* scratch, int iters, int workgroups, void* stream);
+
 /* Weight-gradient GEMMs (rvt_*_wgrad) cut the token contraction into K slices.  `ws` is their scratch for the
  * two-stage reduction: rvt_wgrad_workspace_floats(dtype, out_rows, out_cols, tokens, want_colsum) float32 elements
  * (out = dw's [rows][cols]; conv: [Cout][k*k*Cin]; lstm: [4C][2C]).  ws == NULL selects direct float atomics, which

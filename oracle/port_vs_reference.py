@@ -55,7 +55,7 @@ def main():
     torch.manual_seed(0)
     ref = build_recurrent_backbone(ref_cfg)
     params = {k: v.detach().clone().requires_grad_(True) for k, v in ref.state_dict().items()}
-    ocfg = O.OracleCfg(embed_dim=64, dim_head=32, partition_size=(6, 10))
+    ocfg = O.OracleCfg(embed_dim=64, dim_head=32, partition_size=(6, 10), conv_impl='aten')      # as bench.py's cpu_baseline leg
     g = torch.Generator().manual_seed(1)
     xs = torch.randint(0, 11, (T, B, 20, 360, 640), generator=g, dtype=torch.uint8)
     Hm, Wm = cfgd.in_res_hw
@@ -74,8 +74,10 @@ def main():
         loss = sum(feats[t][s].sum() for t in range(T) for s in (2, 3, 4))
         torch.autograd.grad(loss, list(params.values()), allow_unused=True)
 
-    t_ref = best_of(run_reference)
-    t_port = best_of(run_port)
+    t_ref = t_port = float('inf')
+    for _ in range(3):                           # interleaved: the container's vCPUs are shared and noisy
+        t_ref = min(t_ref, best_of(run_reference, 2))
+        t_port = min(t_port, best_of(run_port, 2))
     print(json.dumps(dict(workload=f'RVT-Base 1Mpx fp32 fwd+bwd, B={B}, T={T}', cores=ncores, torch=torch.__version__,
                           reference_s=round(t_ref, 3), reference_event_tensors_per_s=round(B * T / t_ref, 2),
                           port_s=round(t_port, 3), port_event_tensors_per_s=round(B * T / t_port, 2),

@@ -54,6 +54,11 @@ class OracleCfg:
     dws_conv_only_hidden: bool = True
     dws_conv_kernel_size: int = 3
     enable_masking: bool = False
+    # 'im2col': conv, LayerNorm and GELU stated as explicit arithmetic (unfold + contraction, mean / variance, erf) - what the parity
+    # tests use; 'aten': the fused ATen ops the reference itself calls (F.conv2d maxvit.py:160-168, F.layer_norm layers/norm.py:44-56,
+    # F.gelu layers/activations.py:138-145) - used by bench.py's cpu_baseline leg so that the timed port does not understate the
+    # reference; tests/test_oracle_golden.py checks that both give the same numbers
+    conv_impl: str = 'im2col'
 
     @property
     def stage_dims(self) -> List[int]:
@@ -63,11 +68,15 @@ class OracleCfg:
 # ----------------------------------------------------------------------------
 # building blocks
 # ----------------------------------------------------------------------------
+_ATEN = [False]          # set by sequence_forward from OracleCfg.conv_impl == 'aten' (timing mode, see OracleCfg)
+
 
 def layer_norm_last(x: Tensor, w: Tensor, b: Tensor, eps: float) -> Tensor:
     """LayerNorm over the last (channel) axis, biased variance.
     reference: maxvit.py:172,177 (`LayerNorm(num_channels, eps=1e-5)` → F.layer_norm,
     layers/norm.py:44-56)."""
+    if _ATEN[0]:
+        return F.layer_norm(x, (x.shape[-1],), w, b, eps)
     mu = x.mean(dim=-1, keepdim=True)
     var = ((x - mu) ** 2).mean(dim=-1, keepdim=True)
     return (x - mu) / torch.sqrt(var + eps) * w + b
@@ -75,11 +84,13 @@ def layer_norm_last(x: Tensor, w: Tensor, b: Tensor, eps: float) -> Tensor:
 
 def gelu_erf(x: Tensor) -> Tensor:
     """Exact (erf) GELU.  reference: layers/activations.py:138-145 (F.gelu)."""
+    if _ATEN[0]:
+        return F.gelu(x)
     return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
 
 
 def conv_downsample_ln(x_nchw: Tensor, p: Dict[str, Tensor], pre: str, factor: int,
-                       overlap: bool, eps: float) -> Tensor:
+                       overlap: bool, eps: float, conv_impl: str = 'im2col') -> Tensor:
     """Strided conv (bias-free) → channels-last → LayerNorm.
     reference: maxvit.py:143-178 — kernel (f-1)*2+1, padding k//2, stride f when
     ``overlap`` else kernel f, padding 0."""
@@ -91,9 +102,12 @@ def conv_downsample_ln(x_nchw: Tensor, p: Dict[str, Tensor], pre: str, factor: i
     B, Cin, H, W = x_nchw.shape
     Ho = (H + 2 * pad - k) // factor + 1
     Wo = (W + 2 * pad - k) // factor + 1
-    cols = F.unfold(x_nchw, kernel_size=k, padding=pad, stride=factor)     # (B, Cin*k*k, Ho*Wo)
-    y = torch.einsum('bkn,ok->bno', cols, w.reshape(w.shape[0], -1))       # (B, N, Cout)
-    y = y.reshape(B, Ho, Wo, -1)
+    if conv_impl == 'aten':
+        y = F.conv2d(x_nchw, w, None, stride=factor, padding=pad).permute(0, 2, 3, 1)
+    else:
+        cols = F.unfold(x_nchw, kernel_size=k, padding=pad, stride=factor)     # (B, Cin*k*k, Ho*Wo)
+        y = torch.einsum('bkn,ok->bno', cols, w.reshape(w.shape[0], -1))       # (B, N, Cout)
+        y = y.reshape(B, Ho, Wo, -1)
     return layer_norm_last(y, p[pre + 'norm.weight'], p[pre + 'norm.bias'], eps)
 
 
@@ -202,7 +216,7 @@ def stage_forward(x_nchw: Tensor, state: State, token_mask: Optional[Tensor], p:
     reference: maxvit_rnn.py:169-182."""
     pre = f'stages.{si}.'
     factor = cfg.patch_size if si == 0 else 2
-    x = conv_downsample_ln(x_nchw, p, pre + 'downsample_cf2cl.', factor, cfg.overlap, cfg.norm_eps)
+    x = conv_downsample_ln(x_nchw, p, pre + 'downsample_cf2cl.', factor, cfg.overlap, cfg.norm_eps, cfg.conv_impl)
     if token_mask is not None:
         # maxvit_rnn.py:174-176: x[token_mask] = mask_token
         x = torch.where(token_mask[..., None], p[pre + 'mask_token'].reshape(1, 1, 1, -1).to(x.dtype), x)
@@ -248,6 +262,7 @@ def sequence_forward(xs: Tensor, prev_states, p: Dict[str, Tensor], cfg: OracleC
     Returns ([{stage: (B,C,H,W)} for t in 0..T-1], final_states)."""
     outs = []
     states = prev_states
+    _ATEN[0] = cfg.conv_impl == 'aten'
     for t in range(xs.shape[0]):
         x = pad_to(xs[t].to(dtype), in_res_hw)
         tm = None if token_masks is None else token_masks[t]

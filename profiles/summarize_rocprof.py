@@ -44,44 +44,30 @@ for what in ('fetch', 'write'):
             print(f'{k:90s} dispatches={n:6d} sum={v / 1024 / 1024:10.3f} GiB avg={v / n / 1024:10.3f} MiB')
 
 
-# ---- per-entry-point HBM traffic (bytes per launch) for bench.py's `roofline.traffic` --------------------------------
-# gfx950 correction (MI355X_MICROARCH.md §HBM): FETCH_SIZE under-reports wide coalesced reads by exactly 2x; WRITE_SIZE was
-# calibrated here on ln_fwd (equal read and write bytes) and matches the byte count 1:1.  Counter unit: KiB.
+# ---- per-kernel HBM traffic (bytes per launch) for bench.py's `roofline.traffic` ------------------------------------------
+# gfx950 correction (MI355X_MICROARCH.md, HBM / rocprofv3 section): FETCH_SIZE under-reports wide coalesced reads by exactly 2x;
+# WRITE_SIZE was calibrated here on ln_fwd (equal read and write bytes) and matches the byte count 1:1.  Counter unit: KiB.
+# Round 4: keyed by the WORKLOAD the profiled command ran (argv[2], e.g. "base_1mpx:bf16:B24:T21") and by kernel instantiation
+# (the mangled name as rocprofv3 prints it, truncated), so that bench.py only quotes a traffic figure that belongs to the
+# workload it is timing and to the kernel it names - anything else is reported as null.
 import json
 
-ENTRY = {   # kernel-name predicate -> C entry point
-    'rvt_linear_wgrad': lambda k: 'gemm_kernel' in k and 'Lb1ELb0' in k and 'PlainSrc' in k and 'ConcatSrc' not in k and 'Im2colSrc' not in k,
-    'rvt_linear_dgrad': lambda k: False,
-}
-raw = {}
+workload = sys.argv[2] if len(sys.argv) > 2 else 'base_1mpx:bf16:B24:T21'
+per = {}
 for what in ('fetch', 'write'):
     for f in glob.glob(os.path.join(out, what, '**', '*counter_collection.csv'), recursive=True):
-        rows = list(csv.DictReader(open(f)))
-        for r in rows:
-            for ep, pred in ENTRY.items():
-                if pred(r['Kernel_Name']):
-                    e = raw.setdefault(ep, {'fetch': 0.0, 'write': 0.0, 'n_fetch': 0, 'n_write': 0})
-                    e[what] += float(r['Counter_Value'])
-                    e['n_' + what] += 1
-        # round 3: the stage-3 / stage-4 weight gradients run on ppgemm_tn_kernel, which rvt_lstm_wgrad launches too.  Per
-        # stage the backward issues [lstm_wgrad, then fc2 / fc1 / proj / qkv weight gradients of the two blocks]: of every nine
-        # consecutive ppgemm_tn dispatches the first is the ConvLSTM's (checked: it is the largest of its group, its rows
-        # being 4C + 2C wide) and is left out of the rvt_linear_wgrad average.
-        tn = sorted((r for r in rows if 'ppgemm_tn_kernel' in r['Kernel_Name']), key=lambda r: int(r['Dispatch_Id']))
-        if tn and len(tn) % 9 == 0:
-            e = raw.setdefault('rvt_linear_wgrad', {'fetch': 0.0, 'write': 0.0, 'n_fetch': 0, 'n_write': 0})
-            for g0 in range(0, len(tn), 9):
-                grp = [float(r['Counter_Value']) for r in tn[g0:g0 + 9]]
-                if what == 'fetch':
-                    assert grp[0] == max(grp), 'ppgemm_tn dispatch order changed: the ConvLSTM launch is not first of its group'
-                e[what] += sum(grp[1:])
-                e['n_' + what] += 8
-res = {}
-for ep, e in raw.items():
+        for r in csv.DictReader(open(f)):
+            e = per.setdefault(r['Kernel_Name'][:200], {'fetch': 0.0, 'write': 0.0, 'n_fetch': 0, 'n_write': 0})
+            e[what] += float(r['Counter_Value'])
+            e['n_' + what] += 1
+res, total = {}, 0.0
+for k, e in per.items():
     if e['n_fetch'] and e['n_write']:
-        res[ep] = {'launches_profiled': e['n_fetch'],
-                   'fetch_size_kib_raw_per_launch': e['fetch'] / e['n_fetch'],
-                   'write_size_kib_raw_per_launch': e['write'] / e['n_write'],
-                   'traffic_bytes_per_launch': int(1024 * (2 * e['fetch'] / e['n_fetch'] + e['write'] / e['n_write']))}
-json.dump(res, open(os.path.join(out, 'traffic.json'), 'w'), indent=1)
-print('== traffic per launch ==', json.dumps(res))
+        b = 1024 * (2 * e['fetch'] / e['n_fetch'] + e['write'] / e['n_write'])
+        res[k] = {'launches_profiled': e['n_fetch'], 'fetch_size_kib_raw_per_launch': round(e['fetch'] / e['n_fetch'], 1),
+                  'write_size_kib_raw_per_launch': round(e['write'] / e['n_write'], 1), 'traffic_bytes_per_launch': int(b)}
+        total += 1024 * (2 * e['fetch'] + e['write'])
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 7       # bench steps inside the profiled command (warmup + probe + timed)
+doc = {workload: {'kernels': res, 'steps_profiled': steps, 'traffic_bytes_per_step': int(total / max(steps, 1))}}
+json.dump(doc, open(os.path.join(out, 'traffic.json'), 'w'), indent=1)
+print(f'== HBM traffic, {workload}: {total / max(steps, 1) / 1e9:.1f} GB per step over {steps} profiled steps, {len(res)} kernel instantiations ==')

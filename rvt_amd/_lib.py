@@ -66,7 +66,7 @@ EXPORTS = sorted(list(_SIGS) + ['rvt_last_error', 'rvt_is_emulator', 'rvt_wgrad_
                                'rvt_mlp_fused_supported', 'rvt_lstm_scan_supported', 'rvt_mlp_bwd_fused_supported',
                                'rvt_mlp_bwd_fused_ws_floats', 'rvt_attn_block_supported', 'rvt_lstm_scan_bwd_ws_floats',
                                'rvt_lstm_scan_saves_gates', 'rvt_stem_supported', 'rvt_stem_wgrad_ws_floats', 'rvt_conv_dgrad4_supported',
-                               'rvt_linear_dgrad_ln_supported', 'rvt_tuning_defaults', 'rvt_get_tuning', 'rvt_set_tuning'])
+                               'rvt_linear_dgrad_ln_supported', 'rvt_tuning_defaults', 'rvt_get_tuning', 'rvt_set_tuning', 'rvt_probe_mfma'])
 
 
 def _bind(lib: ctypes.CDLL) -> ctypes.CDLL:
@@ -102,6 +102,8 @@ def _bind(lib: ctypes.CDLL) -> ctypes.CDLL:
     lib.rvt_stem_wgrad_ws_floats.argtypes = [_i] * 4
     lib.rvt_wgrad_workspace_floats.restype = ctypes.c_size_t
     lib.rvt_wgrad_workspace_floats.argtypes = [_i, _i, _i, _i, _i]
+    lib.rvt_probe_mfma.restype = ctypes.c_double
+    lib.rvt_probe_mfma.argtypes = [_vp, _i, _i, _vp]
     lib.rvt_tuning_defaults.restype = None
     lib.rvt_tuning_defaults.argtypes = [_vp]
     lib.rvt_get_tuning.restype = ctypes.c_int

@@ -27,6 +27,28 @@ RvtTuning g_tuning = RVT_TUNING_DEFAULTS;
 
 using namespace rvt;
 
+namespace rvt {
+// Measurement aid (bench.py `mfma_peak_sustained`): nothing but dependent-free v_mfma_f32_32x32x16_bf16 on four accumulator
+// blocks per wave, 16 waves per CU - the rate the matrix pipes of THIS part sustain at the clock it actually runs under load
+// (the 2.5 PFLOP/s figure assumes 2.4 GHz).
+__global__ void __launch_bounds__(256) mfma_probe_kernel(float* __restrict__ out, int iters) {
+    const int lane = threadIdx.x & 63;
+    frag_t<bf16> a, b;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { a[i] = (bf16)(float)((lane + i) & 3); b[i] = (bf16)(float)((lane ^ i) & 1); }
+    f32x16 c0, c1, c2, c3;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { c0[i] = 0.f; c1[i] = 0.f; c2[i] = 0.f; c3[i] = 0.f; }
+    for (int it = 0; it < iters; it++) {
+        mma32(c0, a, b); mma32(c1, a, b); mma32(c2, a, b); mma32(c3, a, b);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; i++) s += c0[i] + c1[i] + c2[i] + c3[i];
+    if (s == -1.0f) out[blockIdx.x * blockDim.x + threadIdx.x] = s;       // never true: keeps the MFMAs alive
+}
+}  // namespace rvt
+
 extern "C" {
 
 const char* rvt_last_error(void) { return g_err; }
@@ -37,6 +59,12 @@ int rvt_is_emulator(void) {
 #else
     return 0;
 #endif
+}
+
+double rvt_probe_mfma(float* scratch, int iters, int workgroups, void* stream) {
+    if (iters < 1 || workgroups < 1) return 0.0;
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3(workgroups), dim3(256), 0, (hipStream_t)stream, scratch, iters);
+    return (double)workgroups * 4.0 /*waves*/ * (double)iters * 4.0 /*MFMAs*/ * (2.0 * 32 * 32 * 16);
 }
 
 void rvt_tuning_defaults(RvtTuning* t) {

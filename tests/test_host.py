@@ -331,3 +331,98 @@ def test_default_gradient_handoff_obeys_autograd_contracts():
             assert torch.allclose(p.grad, 3.0 * snap[n], rtol=1e-5, atol=1e-6 * float(snap[n].abs().max())), n
     finally:
         _lib._install_test_library(None)
+
+
+DROPIN_WORKER = r'''
+# The drop-in claim of INTEGRATION.md section 1, executed: the reference's OWN detector class is built with the registry branch
+# a maintainer would add, gets rvt_amd.RNNDetector as its backbone, loads a reference state_dict strictly, and
+# YoloXDetector.forward_backbone is compared with the unmodified reference backbone over a short sequence with carried states.
+import os, sys
+sys.dont_write_bytecode = True
+root = sys.argv[1]
+sys.path.insert(0, os.path.join(root, 'oracle', '_stubs'))     # omegaconf / strenum / torchvision stand-ins (not installed here)
+sys.path.insert(1, '/root/reference')
+sys.path.insert(2, root)
+import torch
+import torch.nn.functional as F
+torch.set_num_threads(4)
+from omegaconf import OmegaConf
+import models.detection.recurrent_backbone as registry
+import models.detection.yolox_extension.models.detector as detector_mod
+from models.detection.yolox_extension.models.detector import YoloXDetector
+import rvt_amd
+from rvt_amd import _lib, tuning
+from tests.backends import emu_library
+tuning.use(**tuning.TEST_GEOMETRY)
+_lib._install_test_library(emu_library())          # CPU SIMT-emulator build of the HIP kernels (tests only; no GPU in this container)
+
+reference_builder = registry.build_recurrent_backbone
+def build_recurrent_backbone(backbone_cfg):          # == the branch of INTEGRATION.md section 1
+    if backbone_cfg.name == 'MaxViTRNN' and backbone_cfg.get('impl', 'torch') == 'mi355x':
+        return rvt_amd.RNNDetector(backbone_cfg, compute_dtype=torch.float32)
+    return reference_builder(backbone_cfg)
+detector_mod.build_recurrent_backbone = build_recurrent_backbone     # (detector.py:11 binds the name at import)
+
+def model_cfg(impl):
+    return OmegaConf.create({
+        'backbone': {'name': 'MaxViTRNN', 'impl': impl, 'compile': {'enable': False, 'args': {'mode': 'reduce-overhead'}},
+                     'input_channels': 20, 'enable_masking': False, 'partition_split_32': 1, 'embed_dim': 32,
+                     'dim_multiplier': [1, 2, 4, 8], 'num_blocks': [1, 1, 1, 1], 'T_max_chrono_init': [4, 8, 16, 32],
+                     'stem': {'patch_size': 4}, 'in_res_hw': [64, 96],
+                     'stage': {'downsample': {'type': 'patch', 'overlap': True, 'norm_affine': True},
+                               'attention': {'use_torch_mha': False, 'partition_size': [2, 3], 'dim_head': 32,
+                                             'attention_bias': True, 'mlp_activation': 'gelu', 'mlp_gated': False,
+                                             'mlp_bias': True, 'mlp_ratio': 4, 'drop_mlp': 0, 'drop_path': 0,
+                                             'ls_init_value': 1e-5},
+                               'lstm': {'dws_conv': False, 'dws_conv_only_hidden': True, 'dws_conv_kernel_size': 3,
+                                        'drop_cell_update': 0}}},
+        'fpn': {'name': 'PAFPN', 'compile': {'enable': False, 'args': {'mode': 'reduce-overhead'}}, 'depth': 0.67,
+                'in_stages': [2, 3, 4], 'depthwise': False, 'act': 'silu'},
+        'head': {'name': 'YoloX', 'compile': {'enable': False, 'args': {'mode': 'reduce-overhead'}}, 'depthwise': False,
+                 'act': 'silu'},
+    })
+
+torch.manual_seed(0)
+ref = YoloXDetector(model_cfg('torch')).eval()
+ours = YoloXDetector(model_cfg('mi355x')).eval()
+assert type(ours.backbone).__module__.startswith('rvt_amd'), type(ours.backbone)
+assert type(ref.backbone).__module__.startswith('models.detection'), type(ref.backbone)
+g = torch.Generator().manual_seed(5)
+with torch.no_grad():                                # LayerScale 1e-5 would hide the attention / MLP branches
+    for n, p in ref.named_parameters():
+        if n.endswith('.gamma'):
+            p.copy_(0.5 + torch.rand(p.shape, generator=g))
+missing = ours.load_state_dict(ref.state_dict(), strict=True)          # the WHOLE detector: backbone + FPN + head names agree
+assert not missing.missing_keys and not missing.unexpected_keys
+assert list(ours.fpn.state_dict()) == list(ref.fpn.state_dict())      # FPN / head were built from OUR get_stage_dims / get_strides
+xs = torch.randint(0, 11, (3, 2, 20, 60, 90), generator=g, dtype=torch.uint8)
+st_r = st_o = None
+with torch.no_grad():
+    for t in range(3):
+        x = F.pad(xs[t].float(), [0, 6, 0, 4])                          # modules/detection.py:133-134
+        fr, st_r = ref.forward_backbone(x, st_r)
+        fo, st_o = ours.forward_backbone(x, st_o)
+        assert sorted(fo) == sorted(fr) == [1, 2, 3, 4]
+        for s in fr:
+            assert tuple(fo[s].shape) == tuple(fr[s].shape)
+            err = (fo[s].float() - fr[s]).abs().max().item() / fr[s].abs().max().item()
+            assert err < 1e-3, (t, s, err)
+        for (ho, co), (hr, cr) in zip(st_o, st_r):
+            assert (co.float() - cr).abs().max().item() <= 1e-3 * cr.abs().max().item()
+    # the reference FPN + head consume OUR features unchanged (eval: decoded predictions)
+    out_o, _ = ours.forward_detect(backbone_features=fo)
+    out_r, _ = ref.forward_detect(backbone_features=fr)
+    assert out_o.shape == out_r.shape
+    assert (out_o - out_r).abs().max().item() <= 2e-3 * out_r.abs().max().item()
+print('DROPIN OK')
+'''
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/models'), reason='the reference tree exists only in the authoring container')
+def test_dropin_through_reference_registry_and_detector(tmp_path):
+    """VERDICT r3 item 9 / SURVEY.md §8b: the drop-in claim executed through the reference's own `YoloXDetector`
+    (models/detection/yolox_extension/models/detector.py:18-41) and registry branch, on the emulator library."""
+    script = tmp_path / 'dropin.py'
+    script.write_text(DROPIN_WORKER)
+    r = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'DROPIN OK' in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]

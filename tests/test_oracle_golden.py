@@ -30,3 +30,24 @@ def test_layerscale_blind_spot_is_real():
     a = load_golden('micro')
     b = load_golden('micro_default_gamma')
     assert abs(a['loss'] - b['loss']) > 1e-2
+
+
+def test_oracle_aten_timing_mode_matches_reference_golden():
+    """bench.py's cpu_baseline leg times the oracle with OracleCfg.conv_impl='aten' (F.conv2d / F.layer_norm / F.gelu, the ops the
+    reference calls, instead of the explicit arithmetic): same numbers."""
+    from oracle import rvt_oracle as O
+    from tests import casegen as cg
+    name = 'micro'
+    c, cfgd = cg.CASES[name], cg.case_cfg(name)
+    cfg = O.OracleCfg(**{k: (tuple(v) if isinstance(v, (list, tuple)) else v) for k, v in cfgd.items()}, conv_impl='aten')
+    params = {k: torch.from_numpy(v) for k, v in cg.make_params(cfgd, seed=0, gamma=c['gamma']).items()}
+    xs = torch.from_numpy(cg.make_inputs(name))
+    try:
+        fa, sa = O.sequence_forward(xs, None, params, cfg, c['in_res'])
+        cfg.conv_impl = 'im2col'
+        fb, sb = O.sequence_forward(xs, None, params, cfg, c['in_res'])
+    finally:
+        O._ATEN[0] = False
+    for t in range(c['T']):
+        for s in (1, 2, 3, 4):
+            assert torch.allclose(fa[t][s], fb[t][s], rtol=1e-4, atol=1e-5), (t, s)
