@@ -63,9 +63,10 @@ typedef struct RvtTuning {
     int route_lstm_scan_wgrad;/* 1: ConvLSTM weight gradients inside the reverse scan where built */
     int route_conv_dgrad4;    /* 1: 3x3 / stride-2 conv input gradient as one gather GEMM */
     int route_wgrad_stream;   /* 1: weight-gradient launches on a second HIP stream */
-    int reserved[12];         /* zero */
+    int lstm_scan_v2;         /* 1: bf16 C = 64 ConvLSTM scans take the T-form kernels of lstm_scan2.hpp (0: lstm_scan.hpp, A/B) */
+    int reserved[11];         /* zero */
 } RvtTuning;
-#define RVT_TUNING_DEFAULTS {(int)sizeof(RvtTuning), 0, 1, 0, 512, 8192, 1, 4096, 0, 0, 0, 0, 1, 4, 0, 1, 1, 0, 0, 1, -1, 1, 1, -1, 1, 1, 0, {0}}
+#define RVT_TUNING_DEFAULTS {(int)sizeof(RvtTuning), 0, 1, 0, 512, 8192, 1, 4096, 0, 0, 0, 0, 1, 4, 0, 1, 1, 0, 0, 1, -1, 1, 1, -1, 1, 1, 0, 1, {0}}
 void rvt_tuning_defaults(RvtTuning* t);        /* fills *t with the production defaults */
 int rvt_get_tuning(RvtTuning* t);              /* t->struct_bytes must be set by the caller */
 int rvt_set_tuning(const RvtTuning* t);

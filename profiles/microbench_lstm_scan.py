@@ -1,23 +1,52 @@
-"""GPU micro-benchmark: stage-1 ConvLSTM reverse scan (368640 pixels x 21 steps, C = 64, bf16, in-kernel weight gradients)."""
-import sys, os, torch
+"""GPU micro-benchmark of the ConvLSTM scan kernels at the RVT-Base 1Mpx stage-1 / stage-2 shapes (T = 21, B = 24):
+lstm_scan.hpp (round 2/3, N-form) against lstm_scan2.hpp (round 4, T-form) through tuning.lstm_scan_v2, each checked
+against the other (same arithmetic, different summation order)."""
+import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from rvt_amd import ops
-torch.manual_seed(0)
-dev, dt = torch.device('cuda', 0), torch.bfloat16
-rnd = lambda *s: torch.randn(*s, device=dev).to(dt)
-T_, Mp, Cc = 21, 368640, 64
-xa, Hall, Cs = rnd(T_, Mp, Cc), rnd(T_ + 1, Mp, Cc) * 0.5, rnd(T_, Mp, Cc)
-w, b = rnd(4 * Cc, 2 * Cc) * 0.1, torch.zeros(4 * Cc, device=dev)
-dH, dxa = rnd(T_, Mp, Cc), torch.empty(T_, Mp, Cc, device=dev, dtype=dt)
-dh0, dc0 = torch.empty(Mp, Cc, device=dev, dtype=dt), torch.empty(Mp, Cc, device=dev)
-wt = w.t().contiguous()
-def run():
-    dw, db = torch.zeros(4 * Cc, 2 * Cc, device=dev), torch.zeros(4 * Cc, device=dev)
-    ops.lstm_scan_bwd(xa, Hall, Cs, None, dH, None, w, wt, b, dxa, None, dh0, dc0, dw=dw, db=db)
-    return dw, db
-dw, db = run(); torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(5): run()
-e1.record(); torch.cuda.synchronize()
-print(f'[HELP={os.environ.get("RVT_LSTM_SCAN_HELP", "0")}] lstm_scan_bwd C=64: {e0.elapsed_time(e1) / 5:.3f} ms   checksum dw {float(dw.double().abs().sum()):.6e} db {float(db.double().abs().sum()):.6e} dx {float(dxa.double().abs().sum()):.6e}', flush=True)
+from rvt_amd import ops, tuning
+
+dev, dt, T = torch.device('cuda', 0), torch.bfloat16, 21
+
+
+def timeit(fn, n=5):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def rel(a, b):
+    return float((a.float() - b.float()).abs().max() / b.float().abs().max().clamp_min(1e-9))
+
+
+for C, M in ((64, 368640), (128, 92160)):
+    g = torch.Generator(device=dev).manual_seed(0)
+    rn = lambda *s, sc=1.0: (torch.randn(*s, device=dev, generator=g) * sc)
+    x, h0, c0 = rn(T, M, C).to(dt), rn(M, C, sc=0.5).to(dt), rn(M, C, sc=0.7)
+    w, b = rn(4 * C, 2 * C, sc=2.0 / (2 * C) ** 0.5).to(dt), rn(4 * C, sc=0.2)
+    wt = w.t().contiguous()
+    dH, dcl = rn(T, M, C).to(dt), rn(M, C)
+    res = {}
+    for v2 in ((0, 1) if C == 64 else (0,)):
+        with tuning.override(lstm_scan_v2=v2, route_lstm_scan=1):
+            Hall = torch.empty(T + 1, M, C, dtype=dt, device=dev); Hall[0].copy_(h0)
+            c_last = torch.empty(M, C, device=dev)
+            Csave = torch.empty(T, M, C, dtype=dt, device=dev)
+            gsave = torch.empty(T, M, 4 * C, dtype=dt, device=dev) if ops.lstm_scan_saves_gates(dt, C) else None
+            t_f = timeit(lambda: ops.lstm_scan_fwd(x, Hall, c0, c_last, Csave, w, b, gates_out=gsave))
+            dx, dh0, dc0 = torch.empty(T, M, C, dtype=dt, device=dev), torch.empty(M, C, dtype=dt, device=dev), torch.empty(M, C, device=dev)
+            wg = ops.lstm_scan_wgrad_supported(dt, C, M) and gsave is None
+            dw, db = torch.zeros(4 * C, 2 * C, device=dev), torch.zeros(4 * C, device=dev)
+            dz = None if wg else torch.empty(T, M, 4 * C, dtype=dt, device=dev)
+            run = lambda: ops.lstm_scan_bwd(x, Hall, Csave, c0, dH, dcl, w, wt, b, dx, dz, dh0, dc0, dw=dw if wg else None,
+                                            db=db if wg else None, gates=gsave)
+            t_b = timeit(run)
+            dw.zero_(); db.zero_(); run()
+            res[v2] = (Hall.clone(), c_last.clone(), dx.clone(), dh0.clone(), dc0.clone(), dw.clone(), db.clone())
+            print(f'C={C} M={M} T={T} lstm_scan_v2={v2}: fwd {t_f:.3f} ms | bwd{" (+ in-kernel wgrad)" if wg else ""} {t_b:.3f} ms', flush=True)
+    if len(res) == 2:
+        names = ('Hall', 'c_last', 'dx', 'dh0', 'dc0', 'dw', 'db')
+        print('   v2 vs v1 rel err: ' + ', '.join(f'{n} {rel(a, b_):.2e}' for n, a, b_ in zip(names, res[1], res[0])), flush=True)

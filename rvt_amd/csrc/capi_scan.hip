@@ -2,6 +2,7 @@
 #include "host.hpp"
 #include "gemm.hpp"
 #include "lstm_scan.hpp"
+#include "lstm_scan2.hpp"
 
 using namespace rvt;
 
@@ -63,7 +64,12 @@ size_t rvt_lstm_scan_bwd_ws_floats(int dtype, int C, int M) {
     if (!scan_wgrad_built(dtype, C)) return 0;
     const int grid = C == 32 ? lstm_scan_bwd_grid<bf16, 32, 4, true, true>(M) : lstm_scan_bwd_grid<bf16, 64, 4, true, true>(M);
     const int NWM = 4 / (C / 32);
-    return (size_t)grid * ((size_t)4 * C * 2 * C + (size_t)NWM * 4 * C);
+    size_t n = (size_t)grid * ((size_t)4 * C * 2 * C + (size_t)NWM * 4 * C);
+    if (C == 64) {                          // the T-form kernel (lstm_scan2.hpp): one record per workgroup
+        const size_t n2 = (size_t)scan_grid(lstm_scan2_bwd_kernel, 256, M, Scan2BwdSmem::TM) * Scan2BwdSmem::REC;
+        if (n2 > n) n = n2;
+    }
+    return n;
 }
 
 int rvt_lstm_scan_saves_gates(int dtype, int C) { return scan_regw_built(dtype, C) ? 1 : 0; }
@@ -76,6 +82,11 @@ int rvt_lstm_scan_fwd(const void* x_all, void* Hall, const float* c0, float* c_l
 #define RVT_SCAN_FWD(TT, CC, NWW, RBB, LDS) launch_lstm_scan_fwd<TT, CC, NWW, RBB, LDS>(x_all, Hall, c0, c_last, Csave, w, bias, nullptr, M, T_steps, st)
     if (dtype == RVT_BF16) {
         if (C == 32) RVT_SCAN_FWD(bf16, 32, 4, 1, true);
+        else if (C == 64 && tuning().lstm_scan_v2) {          // T-form rebuild (lstm_scan2.hpp): one wave = 32 tokens, no barriers
+            auto k = lstm_scan2_fwd_kernel<8>;
+            hipLaunchKernelGGL(k, dim3(scan_grid(k, 512, M, 256)), dim3(512), 0, st, (const bf16*)x_all, (bf16*)Hall, c0, c_last,
+                               (bf16*)Csave, (const bf16*)w, bias, M, T_steps);
+        }
         else if (C == 64) RVT_SCAN_FWD(bf16, 64, 8, 1, true);
         else launch_lstm_scan_fwd<bf16, 128, 4, 1, false, true>(x_all, Hall, c0, c_last, Csave, w, bias, gates_out, M, T_steps, st);     // (64-token tiles spill: 2.3 ms against 1.65)
     } else {             // (four waves: the f32 variants need more than the 256 registers an 8-wave workgroup leaves)
@@ -111,6 +122,17 @@ int rvt_lstm_scan_bwd(const void* x_all, const void* Hall, const void* Csave, co
 #define RVT_SCAN_BWD(TT, CC, NWW, LDS, WG) launch_lstm_scan_bwd<TT, CC, NWW, LDS, WG>(x_all, Hall, Csave, c0, dH, dc_last, w, wt, bias, dx_all, dz_all, dh0, dc0, dw, db, ws, M, T_steps, st)
     if (dtype == RVT_BF16) {
         if (C == 32) { if (wgrad) RVT_SCAN_BWD(bf16, 32, 4, true, true); else RVT_SCAN_BWD(bf16, 32, 4, true, false); }
+        else if (C == 64 && wgrad && tuning().lstm_scan_v2) {       // T-form rebuild (lstm_scan2.hpp)
+            auto k = lstm_scan2_bwd_kernel;
+            const int grid = scan_grid(k, 256, M, Scan2BwdSmem::TM);
+            hipLaunchKernelGGL(k, dim3(grid), dim3(256), 0, st, (const bf16*)x_all, (const bf16*)Hall, (const bf16*)Csave, c0,
+                               (const bf16*)dH, dc_last, (const bf16*)w, bias, (bf16*)dx_all, (bf16*)dh0, dc0, ws, M, T_steps);
+            const size_t wn = (size_t)4 * C * 2 * C;
+            hipLaunchKernelGGL(strided_reduce_kernel, dim3(reduce_grid(wn)), dim3(256), 0, st, (const float*)ws, dw, grid,
+                               Scan2BwdSmem::REC, wn);
+            hipLaunchKernelGGL(strided_reduce_kernel, dim3(reduce_grid((size_t)4 * C)), dim3(256), 0, st, (const float*)(ws + wn), db,
+                               grid, Scan2BwdSmem::REC, (size_t)4 * C);
+        }
         else if (C == 64) { if (wgrad) RVT_SCAN_BWD(bf16, 64, 4, true, true); else RVT_SCAN_BWD(bf16, 64, 4, true, false); }
         else RVT_SCAN_BWD(bf16, 128, 4, false, false);
     } else {

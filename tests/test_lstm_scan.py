@@ -124,7 +124,12 @@ def test_lstm_scan_fwd_bwd(backend, dt, C, M, T, zero_state):
         db = torch.ones(4 * C, dtype=torch.float32, device=dev)
         dx2, dh02, dc02 = torch.empty_like(dx), torch.empty_like(dh0), torch.empty_like(dc0)
         ops.lstm_scan_bwd(x, Hall, Csave, c0, dH, dc_last, w, w.t().contiguous(), b, dx2, None, dh02, dc02, dw=dw, db=db)
-        assert torch.equal(dx2.cpu(), dx.cpu()) and torch.equal(dh02.cpu(), dh0.cpu()) and torch.equal(dc02.cpu(), dc0.cpu())
+        if C == 64:      # round 4: the in-kernel-gradient variant at C = 64 is the T-form kernel of lstm_scan2.hpp (other summation order)
+            assert rel(dx2, xr.grad) <= tol, ('v2 dx', rel(dx2, xr.grad))
+            assert rel(dh02, h0r.grad) <= tol and rel(dc02, c0r.grad) <= tol, ('v2 dh0 / dc0', rel(dh02, h0r.grad), rel(dc02, c0r.grad))
+            assert rel(dx2, dx) <= 2 * tol and rel(dh02, dh0) <= 2 * tol and rel(dc02, dc0) <= 2 * tol
+        else:
+            assert torch.equal(dx2.cpu(), dx.cpu()) and torch.equal(dh02.cpu(), dh0.cpu()) and torch.equal(dc02.cpu(), dc0.cpu())
         assert rel(dw - 1.0, wr.grad) <= tol * 2, ('in-kernel dW', rel(dw - 1.0, wr.grad))
         assert rel(db - 1.0, br.grad) <= tol * 2, ('in-kernel db', rel(db - 1.0, br.grad))
     else:
