@@ -157,6 +157,21 @@ elif op in ('dgrad_ln_k512', 'dgrad_ln_k384'):    # stage-2 fc1 / qkv input grad
     w, lw = rnd(Ks, Cs_) * 0.1, torch.rand(Cs_, device=dev) + 0.5
     dw, db, out = torch.zeros(Cs_, device=dev), torch.zeros(Cs_, device=dev), torch.empty(Ms, Cs_, device=dev, dtype=dt)
     fn = lambda: ops.linear_dgrad_ln(dys, w, xs, dres, lw, dw, db, 1e-5, out=out)
+elif op in ('scan_fwd_s1', 'scan_bwd_s1', 'scan_fwd_s1_v1', 'scan_bwd_s1_v1'):     # stage-1 ConvLSTM scans, 368640 pixels x 21 steps, C = 64 (lstm_scan2.hpp / lstm_scan.hpp)
+    from rvt_amd import tuning
+    tuning.use(lstm_scan_v2=0 if op.endswith('_v1') else 1)
+    T_, Mp, Cc = 21, 368640, 64
+    xa, Hall, Cs = rnd(T_, Mp, Cc), rnd(T_ + 1, Mp, Cc) * 0.5, rnd(T_, Mp, Cc)
+    wl, bl = rnd(4 * Cc, 2 * Cc) * 0.1, torch.zeros(4 * Cc, device=dev)
+    if op.startswith('scan_fwd'):
+        c_last = torch.empty(Mp, Cc, device=dev)
+        fn = lambda: ops.lstm_scan_fwd(xa, Hall, None, c_last, Cs, wl, bl)
+    else:
+        dH, dxa = rnd(T_, Mp, Cc), torch.empty(T_, Mp, Cc, device=dev, dtype=dt)
+        dh0, dc0 = torch.empty(Mp, Cc, device=dev, dtype=dt), torch.empty(Mp, Cc, device=dev)
+        wt = wl.t().contiguous()
+        dw, db = torch.zeros(4 * Cc, 2 * Cc, device=dev), torch.zeros(4 * Cc, device=dev)
+        fn = lambda: ops.lstm_scan_bwd(xa, Hall, Cs, None, dH, None, wl, wt, bl, dxa, None, dh0, dc0, dw=dw, db=db)
 for _ in range(3):
     fn()
 torch.cuda.synchronize()

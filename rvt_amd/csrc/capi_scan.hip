@@ -66,7 +66,7 @@ size_t rvt_lstm_scan_bwd_ws_floats(int dtype, int C, int M) {
     const int NWM = 4 / (C / 32);
     size_t n = (size_t)grid * ((size_t)4 * C * 2 * C + (size_t)NWM * 4 * C);
     if (C == 64) {                          // the T-form kernel (lstm_scan2.hpp): one record per workgroup
-        const size_t n2 = (size_t)scan_grid(lstm_scan2_bwd_kernel, 256, M, Scan2BwdSmem::TM) * Scan2BwdSmem::REC;
+        const size_t n2 = (size_t)scan_grid(lstm_scan2_bwd_kernel, 512, M, Scan2BwdSmem::TM) * Scan2BwdSmem::REC;
         if (n2 > n) n = n2;
     }
     return n;
@@ -124,8 +124,8 @@ int rvt_lstm_scan_bwd(const void* x_all, const void* Hall, const void* Csave, co
         if (C == 32) { if (wgrad) RVT_SCAN_BWD(bf16, 32, 4, true, true); else RVT_SCAN_BWD(bf16, 32, 4, true, false); }
         else if (C == 64 && wgrad && tuning().lstm_scan_v2) {       // T-form rebuild (lstm_scan2.hpp)
             auto k = lstm_scan2_bwd_kernel;
-            const int grid = scan_grid(k, 256, M, Scan2BwdSmem::TM);
-            hipLaunchKernelGGL(k, dim3(grid), dim3(256), 0, st, (const bf16*)x_all, (const bf16*)Hall, (const bf16*)Csave, c0,
+            const int grid = scan_grid(k, 512, M, Scan2BwdSmem::TM);
+            hipLaunchKernelGGL(k, dim3(grid), dim3(512), 0, st, (const bf16*)x_all, (const bf16*)Hall, (const bf16*)Csave, c0,
                                (const bf16*)dH, dc_last, (const bf16*)w, bias, (bf16*)dx_all, (bf16*)dh0, dc0, ws, M, T_steps);
             const size_t wn = (size_t)4 * C * 2 * C;
             hipLaunchKernelGGL(strided_reduce_kernel, dim3(reduce_grid(wn)), dim3(256), 0, st, (const float*)ws, dw, grid,

@@ -284,7 +284,7 @@ template <int N> struct IntC { static constexpr int v = N; };
 template <int... I, class F> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(IntC<I>{}), ...); }
 template <int N, class F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(512)
 lstm_scan2_bwd_kernel(const bf16* __restrict__ x_all, const bf16* __restrict__ Hall, const bf16* __restrict__ Csave,
                       const float* __restrict__ c0, const bf16* __restrict__ dH, const float* __restrict__ dc_last,
                       const bf16* __restrict__ W, const float* __restrict__ bias, bf16* __restrict__ dx_all, bf16* __restrict__ dh0,
@@ -295,15 +295,21 @@ lstm_scan2_bwd_kernel(const bf16* __restrict__ x_all, const bf16* __restrict__ H
     __shared__ __attribute__((aligned(16))) char smem[S::BYTES];
     char* const Adz = smem + S::OFF_DZ;
     float* const kb = reinterpret_cast<float*>(smem + S::OFF_BIAS);
-    const int tid = threadIdx.x, wave = wave_uniform(tid >> 6);
+    // Eight waves, two roles (round 4, third cut): waves 0-3 carry the recurrence (P1, gate backward, P2) for 32 tokens x 32
+    // channels each; waves 4-7 only accumulate the weight gradient (P3) from the tiles the others publish.  Neither role needs
+    // more than 256 registers (the 160 weight-gradient accumulators were what pushed the single-role kernel to 512 = one wave per
+    // SIMD), so a SIMD holds one wave of each role and the helper's MFMA work runs under the other's gate math.
+    const int tid = threadIdx.x, wave8 = wave_uniform(tid >> 6);
+    const bool helper = wave8 >= 4;
+    const int wave = wave8 & 3;                            // recurrence: (wm, wn); helper: weight-gradient row blocks 2 wave, 2 wave + 1
     const int wm = wave >> 1, wn = wave & 1;
-    for (int f = tid; f < 4 * C * 16; f += 256) {          // W -> LDS, both halves in natural column order
+    for (int f = tid; f < 4 * C * 16; f += 512) {          // W -> LDS, both halves in natural column order
         const int n = f >> 4, g8 = f & 15;
         const frag_t<T> v = frag_load<T>(W + (size_t)n * 2 * C + g8 * 8);
         if (g8 < 8) opm_store_frag<T>(smem + S::OFF_WX, 4 * C, n, g8, v);
         else opm_store_frag<T>(smem + S::OFF_WH, 4 * C, n, g8 - 8, v);
     }
-    for (int i = tid; i < 4 * C; i += 256) kb[i] = bias[i];
+    for (int i = tid; i < 4 * C; i += 512) kb[i] = bias[i];
     // ---- per-lane address terms, recomputed from an opaque copy of the lane id at the top of every step ----
     int lane, li, half;
     int w_base, w_v;          // weight fragments (P1): row n = g C + 32 wn + li -> smem + g * 8192 + ((w_v ^ c) + w_base), c = ((2 ks) ^ ((g & 1) << 2)) << 4
@@ -327,20 +333,67 @@ lstm_scan2_bwd_kernel(const bf16* __restrict__ x_all, const bf16* __restrict__ H
         tr_xh[1].init(32, TM, lane);
     };
     refresh_lane();
-    f32x16 dwacc[2][4], dbacc[2];
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        acc_zero(dbacc[i]);
-#pragma unroll
-        for (int j = 0; j < 4; j++) acc_zero(dwacc[i][j]);
-    }
-    frag_t<T> ones;
-#pragma unroll
-    for (int e = 0; e < 8; e++) ones[e] = (T)1.0f;
     __syncthreads();
-
     const size_t MC = (size_t)M * C;
     const int n_tiles = (M + TM - 1) / TM;
+
+    if (helper) {
+        // ================= weight-gradient waves: P3 of every step from the published tiles =================
+        f32x16 dwacc[2][4], dbacc[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            acc_zero(dbacc[i]);
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc_zero(dwacc[i][j]);
+        }
+        frag_t<T> ones;
+#pragma unroll
+        for (int e = 0; e < 8; e++) ones[e] = (T)1.0f;
+        for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+            lds_barrier();                                 // (B') the recurrence waves may overwrite the tiles of the previous tile's last step
+            lds_barrier();                                 // (A)  tiles of step Tn - 1 complete
+            for (int t = Tn - 1; t >= 0; t--) {
+                refresh_lane();
+                const char* const xh_cur = smem + S::OFF_XH + (t & 1) * S::XH_BUF;
+                static_for<4>([&](auto kq) __attribute__((always_inline)) {
+                    constexpr int K0 = 16 * decltype(kq)::v;
+                    frag_t<T> a[2], b[4];
+#pragma unroll
+                    for (int i = 0; i < 2; i++) a[i] = tr_dz[i].load<K0>(Adz);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) b[j] = tr_xh[j & 1].load<K0>(xh_cur + (j < 2 ? 0 : S::XT));
+#pragma unroll
+                    for (int i = 0; i < 2; i++) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) mma32(dwacc[i][j], a[i], b[j]);
+                        mma32(dbacc[i], a[i], ones);
+                    }
+                });
+                if (t > 0) {
+                    lds_barrier();                         // (B) done with the dz tile of step t
+                    lds_barrier();                         // (A) tiles of step t - 1 complete
+                }
+            }
+        }
+        // per-workgroup partial record: [4C][2C] weight gradient, [4C] bias gradient (every column of dbacc is the same sum: column 0)
+        float* const p_dw = ws + (size_t)blockIdx.x * S::REC;
+        float* const p_db = p_dw + (size_t)4 * C * 2 * C;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    p_dw[(size_t)((2 * wave + i) * 32 + acc_row(r, lane)) * (2 * C) + j * 32 + li] = dwacc[i][j][r];
+            if (li == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) p_db[(2 * wave + i) * 32 + acc_row(r, lane)] = dbacc[i][r];
+            }
+        }
+        return;
+    }
+
+    // ================= recurrence waves =================
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         int row;
         bool valid;
@@ -431,19 +484,6 @@ lstm_scan2_bwd_kernel(const bf16* __restrict__ x_all, const bf16* __restrict__ H
                 zp[g][p] = __builtin_bit_cast(unsigned, v);
             }
         };
-        // P3 in eight chunks of five products: chunk P = token step 16 (P >> 1), weight-gradient row block P & 1
-        frag_t<T> p3b[4];
-        auto p3_chunk = [&](auto pc, const char* xh_cur) __attribute__((always_inline)) {
-            constexpr int P = decltype(pc)::v, K0 = 16 * (P >> 1), I = P & 1;
-            if (I == 0) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) p3b[j] = tr_xh[j & 1].load<K0>(xh_cur + (j < 2 ? 0 : S::XT));
-            }
-            const frag_t<T> a = tr_dz[I].load<K0>(Adz);
-#pragma unroll
-            for (int j = 0; j < 4; j++) mma32(dwacc[I][j], a, p3b[j]);
-            mma32(dbacc[I], a, ones);
-        };
         auto park_rows = [&](char* xh) __attribute__((always_inline)) {    // this wave's x or h rows of the step -> its [x | h] buffer
 #pragma unroll
             for (int ks = 0; ks < KS; ks++)
@@ -484,7 +524,7 @@ lstm_scan2_bwd_kernel(const bf16* __restrict__ x_all, const bf16* __restrict__ H
                 const frag_t<T> b = *reinterpret_cast<const frag_t<T>*>(Adz + (KC >> 6) * 8192 + ((r_hs ^ (((KC >> 3) & 6) << 4)) + r_base));
                 mma32(acc2[0], tr_w.load<KC>(smem + S::OFF_WX), b);
                 mma32(acc2[1], tr_w.load<KC>(smem + S::OFF_WH), b);
-                if ((KC & 16) != 0) sched_fence();         // (two k-steps of fragment reads in flight, not all sixteen)
+                if ((KC & 48) == 48) sched_fence();        // (four k-steps of fragment reads in flight, not all sixteen)
             });
             if (t > 0) {
                 p1();                                      // P1 of step t - 1 queues behind P2 ...
@@ -504,14 +544,10 @@ lstm_scan2_bwd_kernel(const bf16* __restrict__ x_all, const bf16* __restrict__ H
                     *reinterpret_cast<u32x4*>(xd + 16) = piece[1];
                 }
             }
-            // ---- gate backward of step t - 1 (VALU) interleaved with P3 of step t (MFMA: weight gradient rows 64 wave.. + bias) ----
-            const char* const xh_cur = smem + S::OFF_XH + (t & 1) * S::XH_BUF;
-            static_for<8>([&](auto pc) __attribute__((always_inline)) {
-                if (t > 0) gate_pair(decltype(pc)::v);
-                p3_chunk(pc, xh_cur);
-                sched_fence();
-            });
+            // ---- gate backward of step t - 1 (the helper waves run P3 of step t meanwhile) ----
             if (t > 0) {
+#pragma unroll
+                for (int p = 0; p < 8; p++) gate_pair(p);
                 lds_barrier();                             // every wave is done with the dz tile of step t
                 write_dz();
                 if (t > 1) fetch(t - 2);                   // (cpf / dhf are dead from here on)
@@ -529,21 +565,6 @@ lstm_scan2_bwd_kernel(const bf16* __restrict__ x_all, const bf16* __restrict__ H
                 *reinterpret_cast<u32x4*>(hd + 16) = piece[1];
                 s2_store_acc_f32(dc0 + ro, wn, half, dc_rec);
             }
-        }
-    }
-    // per-workgroup partial record: [4C][2C] weight gradient, [4C] bias gradient (every column of dbacc is the same sum: column 0)
-    float* const p_dw = ws + (size_t)blockIdx.x * S::REC;
-    float* const p_db = p_dw + (size_t)4 * C * 2 * C;
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-                p_dw[(size_t)((2 * wave + i) * 32 + acc_row(r, lane)) * (2 * C) + j * 32 + li] = dwacc[i][j][r];
-        if (li == 0) {
-#pragma unroll
-            for (int r = 0; r < 16; r++) p_db[(2 * wave + i) * 32 + acc_row(r, lane)] = dbacc[i][r];
         }
     }
 }
