@@ -8,14 +8,18 @@ from rvt_amd import ops, tuning
 dev, dt, T = torch.device('cuda', 0), torch.bfloat16, 21
 
 
-def timeit(fn, n=5):
-    fn(); torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(n):
+def timeit(fn, n=9):
+    """median of n single launches (boxes differ by up to 20 %: compare variants inside ONE run, against lstm_scan_v2=0)"""
+    for _ in range(3):
         fn()
-    e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ts.sort()
+    return ts[n // 2]
 
 
 def rel(a, b):

@@ -66,7 +66,7 @@ size_t rvt_lstm_scan_bwd_ws_floats(int dtype, int C, int M) {
     const int NWM = 4 / (C / 32);
     size_t n = (size_t)grid * ((size_t)4 * C * 2 * C + (size_t)NWM * 4 * C);
     if (C == 64) {                          // the T-form kernel (lstm_scan2.hpp): one record per workgroup
-        const size_t n2 = (size_t)scan_grid(lstm_scan2_bwd_kernel, 512, M, Scan2BwdSmem::TM) * Scan2BwdSmem::REC;
+        const size_t n2 = (size_t)scan_grid(lstm_scan2_bwd_kernel, 512, M, Scan2BwdSmem::TM) * Scan2BwdSmem::REC + 64;      // (+ 64: phase timers of the -DSCAN2_PROF measurement build)
         if (n2 > n) n = n2;
     }
     return n;

@@ -250,6 +250,21 @@ lstm_scan2_fwd_kernel(const bf16* __restrict__ x_all, bf16* __restrict__ Hall, c
 // that the rows of step t - 1 can be parked right after P1 consumed them.
 // Every LDS address is "few per-lane terms (refreshed through an opaque copy of the lane id once per step) XOR / + compile-time
 // constants": left to itself hipcc hoists ~150 per-lane addresses out of the time loop and spills them.
+#ifndef SCAN2_HELPER_SLEEP
+#define SCAN2_HELPER_SLEEP 32        // x 64 cycles
+#endif
+// -DSCAN2_PROF: wave 0 of workgroup 0 accumulates the shader-clock time of its phases into ws[grid * REC + 0..7] (measurement build only)
+#ifdef SCAN2_PROF
+#define S2P_DECL unsigned long long s2p_t = 0, s2p_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const bool s2p_on = blockIdx.x == 0 && wave8 == 0;
+#define S2P_START() do { if (s2p_on) s2p_t = __builtin_amdgcn_s_memtime(); } while (0)
+#define S2P_MARK(i) do { if (s2p_on) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); s2p_acc[i] += n_ - s2p_t; s2p_t = n_; } } while (0)
+#define S2P_FLUSH() do { if (s2p_on && (threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 8; i_++) ws[(size_t)gridDim.x * S::REC + i_] = (float)s2p_acc[i_]; } while (0)
+#else
+#define S2P_DECL
+#define S2P_START()
+#define S2P_MARK(i)
+#define S2P_FLUSH()
+#endif
 struct Scan2BwdSmem {
     static constexpr int C = 64, TM = 64;
     static constexpr int W_PART = 4 * C * 128;
@@ -355,6 +370,11 @@ lstm_scan2_bwd_kernel(const bf16* __restrict__ x_all, const bf16* __restrict__ H
             for (int t = Tn - 1; t >= 0; t--) {
                 refresh_lane();
                 const char* const xh_cur = smem + S::OFF_XH + (t & 1) * S::XH_BUF;
+#ifndef RVT_EMU
+                // the recurrence wave of this SIMD starts its own 64 MFMAs (P2, P1) at this barrier and then spends ~5k cycles on VALU
+                // work: stay off the matrix pipe until it is through with them
+                __builtin_amdgcn_s_sleep(SCAN2_HELPER_SLEEP);
+#endif
                 static_for<4>([&](auto kq) __attribute__((always_inline)) {
                     constexpr int K0 = 16 * decltype(kq)::v;
                     frag_t<T> a[2], b[4];
@@ -394,6 +414,7 @@ lstm_scan2_bwd_kernel(const bf16* __restrict__ x_all, const bf16* __restrict__ H
     }
 
     // ================= recurrence waves =================
+    S2P_DECL
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         int row;
         bool valid;
@@ -410,6 +431,8 @@ lstm_scan2_bwd_kernel(const bf16* __restrict__ x_all, const bf16* __restrict__ H
         if (dc_last != nullptr && valid) s2_load_acc_f32(dc_last + ro, wn, half, dc_rec);
         // operands of a step: x_t, h_{t-1} rows (natural order, 16 B per k-step), c_{t-1} and dH_t of this wave's channel block
         // (accumulator order); fetched one step ahead
+        // (requesting the set earlier - right after P1 consumed the rows, c / dH into a second register set - changed nothing:
+        // 2.757 -> 2.779 ms; the HBM round trip is not what the recurrence waves wait for)
         frag_t<T> xf[KS], hf[KS], cpf[2], dhf[2];
         auto fetch = [&](int t) __attribute__((always_inline)) {
             const T* xs = uniform_ptr(x_all + (size_t)t * MC);
@@ -437,22 +460,32 @@ lstm_scan2_bwd_kernel(const bf16* __restrict__ x_all, const bf16* __restrict__ H
                 s2_pack(cp0, cpf);
             }
         };
+
         f32x16 acc[4];                                                 // pre-activations of the step whose gates come next
         auto p1 = [&]() __attribute__((always_inline)) {               // P1: recompute the pre-activations of this wave's 32 channels
 #pragma unroll
             for (int g = 0; g < 4; g++) acc_load_rows(acc[g], kb + g * C + wn * 32, half);
+            // software-pipelined: a matrix instruction holds the wave's issue slot for its 32 cycles, so the LDS round trip of a
+            // group's fragments has to be started BEFORE the four products of the group in front of it (requested after them it
+            // is waited for with the matrix pipe idle: ~150 cycles per group of 128)
+            frag_t<T> wq[2][4];
+            auto wload = [&](int grp, frag_t<T> (&a)[4]) __attribute__((always_inline)) {
+                const int part = grp >> 2, ks = grp & 3;
 #pragma unroll
-            for (int part = 0; part < 2; part++)
-#pragma unroll
-                for (int ks = 0; ks < KS; ks++) {
-#pragma unroll
-                    for (int g = 0; g < 4; g++) {
-                        const int c = ((2 * ks) ^ ((g & 1) << 2)) << 4;
-                        const frag_t<T> a = *reinterpret_cast<const frag_t<T>*>(smem + (part ? S::OFF_WH : S::OFF_WX) + g * 8192 + ((w_v ^ c) + w_base));
-                        mma32(acc[g], a, part ? hf[ks] : xf[ks]);
-                    }
-                    sched_fence();
+                for (int g = 0; g < 4; g++) {
+                    const int c = ((2 * ks) ^ ((g & 1) << 2)) << 4;
+                    a[g] = *reinterpret_cast<const frag_t<T>*>(smem + (part ? S::OFF_WH : S::OFF_WX) + g * 8192 + ((w_v ^ c) + w_base));
                 }
+            };
+            wload(0, wq[0]);
+#pragma unroll
+            for (int grp = 0; grp < 8; grp++) {
+                if (grp + 1 < 8) wload(grp + 1, wq[(grp + 1) & 1]);
+                sched_fence();
+#pragma unroll
+                for (int g = 0; g < 4; g++) mma32(acc[g], wq[grp & 1][g], (grp >> 2) ? hf[grp & 3] : xf[grp & 3]);
+                sched_fence();
+            }
         };
         // gate backward (autograd of rnn.py:57-67) of accumulator registers 2p, 2p+1; dz leaves as bf16 pairs
         unsigned zp[4][8];
@@ -515,21 +548,43 @@ lstm_scan2_bwd_kernel(const bf16* __restrict__ x_all, const bf16* __restrict__ H
             // tiles of step t are in LDS; the operands of step t - 1 are in registers (t > 0)
             refresh_lane();
             refresh_row();
+            S2P_START();
             // ---- P2: [dx_t | dh_{t-1}]^T for this wave's 32 + 32 columns ----
             f32x16 acc2[2];
             acc_zero(acc2[0]);
             acc_zero(acc2[1]);
-            static_for<16>([&](auto kk) __attribute__((always_inline)) {
-                constexpr int KC = 16 * decltype(kk)::v;   // (compile-time k-step: every LDS address is per-lane term ^ constant + immediate)
-                const frag_t<T> b = *reinterpret_cast<const frag_t<T>*>(Adz + (KC >> 6) * 8192 + ((r_hs ^ (((KC >> 3) & 6) << 4)) + r_base));
-                mma32(acc2[0], tr_w.load<KC>(smem + S::OFF_WX), b);
-                mma32(acc2[1], tr_w.load<KC>(smem + S::OFF_WH), b);
-                if ((KC & 48) == 48) sched_fence();        // (four k-steps of fragment reads in flight, not all sixteen)
-            });
+            {
+                frag_t<T> pb[2][2], pax[2][2], pah[2][2];   // [buffer][k-step of the pair]
+                auto p2load = [&](auto pp, int buf) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int u = 0; u < 2; u++) { }
+                    constexpr int KC0 = 32 * decltype(pp)::v, KC1 = KC0 + 16;   // (compile-time k-steps: LDS address = per-lane term ^ constant + immediate)
+                    pb[buf][0] = *reinterpret_cast<const frag_t<T>*>(Adz + (KC0 >> 6) * 8192 + ((r_hs ^ (((KC0 >> 3) & 6) << 4)) + r_base));
+                    pb[buf][1] = *reinterpret_cast<const frag_t<T>*>(Adz + (KC1 >> 6) * 8192 + ((r_hs ^ (((KC1 >> 3) & 6) << 4)) + r_base));
+                    pax[buf][0] = tr_w.load<KC0>(smem + S::OFF_WX);
+                    pah[buf][0] = tr_w.load<KC0>(smem + S::OFF_WH);
+                    pax[buf][1] = tr_w.load<KC1>(smem + S::OFF_WX);
+                    pah[buf][1] = tr_w.load<KC1>(smem + S::OFF_WH);
+                };
+                p2load(IntC<0>{}, 0);
+                static_for<8>([&](auto pp) __attribute__((always_inline)) {
+                    constexpr int PP = decltype(pp)::v;
+                    if constexpr (PP + 1 < 8) p2load(IntC<PP + 1>{}, (PP + 1) & 1);
+                    sched_fence();
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        mma32(acc2[0], pax[PP & 1][u], pb[PP & 1][u]);
+                        mma32(acc2[1], pah[PP & 1][u], pb[PP & 1][u]);
+                    }
+                    sched_fence();
+                });
+            }
+            S2P_MARK(0);
             if (t > 0) {
                 p1();                                      // P1 of step t - 1 queues behind P2 ...
                 park_rows(smem + S::OFF_XH + ((t - 1) & 1) * S::XH_BUF);   // ... and its rows go to the other [x | h] buffer (xf / hf dead from here)
             }
+            S2P_MARK(1);
             {                                              // dx rows out while the matrix pipe works; dh_{t-1} stays
                 float dxv[16];
 #pragma unroll
@@ -544,14 +599,19 @@ lstm_scan2_bwd_kernel(const bf16* __restrict__ x_all, const bf16* __restrict__ H
                     *reinterpret_cast<u32x4*>(xd + 16) = piece[1];
                 }
             }
+            S2P_MARK(2);
             // ---- gate backward of step t - 1 (the helper waves run P3 of step t meanwhile) ----
             if (t > 0) {
 #pragma unroll
                 for (int p = 0; p < 8; p++) gate_pair(p);
+                S2P_MARK(3);
                 lds_barrier();                             // every wave is done with the dz tile of step t
+                S2P_MARK(4);
                 write_dz();
-                if (t > 1) fetch(t - 2);                   // (cpf / dhf are dead from here on)
+                if (t > 1) fetch(t - 2);                   // (xf / hf / cpf / dhf are dead from here on)
+                S2P_MARK(5);
                 lds_barrier();                             // tiles of step t - 1 complete
+                S2P_MARK(6);
             }
         }
         {
@@ -567,6 +627,7 @@ lstm_scan2_bwd_kernel(const bf16* __restrict__ x_all, const bf16* __restrict__ H
             }
         }
     }
+    S2P_FLUSH();
 }
 
 }  // namespace rvt
