@@ -64,9 +64,11 @@ typedef struct RvtTuning {
     int route_conv_dgrad4;    /* 1: 3x3 / stride-2 conv input gradient as one gather GEMM */
     int route_wgrad_stream;   /* 1: weight-gradient launches on a second HIP stream */
     int lstm_scan_v2;         /* 1: bf16 C = 64 ConvLSTM scans take the T-form kernels of lstm_scan2.hpp (0: lstm_scan.hpp, A/B) */
-    int reserved[11];         /* zero */
+    int route_stage_driver;   /* 1: the no-grad forward of rvt_amd takes rvt_stage_seq_fwd (one call per stage); 0: the Python host loop */
+    int route_mlp_store_pre;  /* 1: the LDS-staged fused MLP forward (C = 128) saves the pre-activation h only, not GELU(h) and GELU'(h); default 0: measured slower (GELU on load costs more than the bytes it saves, profiles/r4/microbench_mlp128.txt) */
+    int reserved[9];          /* zero */
 } RvtTuning;
-#define RVT_TUNING_DEFAULTS {(int)sizeof(RvtTuning), 0, 1, 0, 512, 8192, 1, 4096, 0, 0, 0, 0, 1, 4, 0, 1, 1, 0, 0, 1, -1, 1, 1, -1, 1, 1, 0, 1, {0}}
+#define RVT_TUNING_DEFAULTS {(int)sizeof(RvtTuning), 0, 1, 0, 512, 8192, 1, 4096, 0, 0, 0, 0, 1, 4, 0, 1, 1, 0, 0, 1, -1, 1, 1, -1, 1, 1, 0, 1, 1, 0, {0}}
 void rvt_tuning_defaults(RvtTuning* t);        /* fills *t with the production defaults */
 int rvt_get_tuning(RvtTuning* t);              /* t->struct_bytes must be set by the caller */
 int rvt_set_tuning(const RvtTuning* t);
@@ -162,7 +164,9 @@ int rvt_linear_wgrad(const void* dy, const void* x, float* dw, float* dy_colsum,
 /* Fused MLP half of a block (maxvit.py:269 + :100-118), built for the HBM-bound stages:
  * rvt_mlp_fused_supported(dtype, C) != 0  (bf16: C in {64,128}; f32: C == 64).
  *   rvt_mlp_fwd:  xout = xmid + gamma * (GELU(LN(xmid) W1^T + b1) W2^T + b2) in one pass; if g_out/gp_out are non-NULL
- *                 also g = GELU(h), gp = GELU'(h) [M][4C] for backward, and if v2_out is non-NULL the LayerNorm output
+ *                 also g = GELU(h), gp = GELU'(h) [M][4C] for backward; g_out alone (gp_out NULL) receives the PRE-ACTIVATION
+ *                 h = LN(xmid) W1^T + b1 instead (half the bytes; the backward applies GELU / GELU' on load through
+ *                 rvt_linear_wgrad(gelu_in) and rvt_linear_dgrad(gelu_pre)); and if v2_out is non-NULL the LayerNorm output
  *                 LN(xmid) [M][C] (B operand of the fc1 weight gradient); nothing else of the chain reaches HBM.
  *   rvt_mlp_bwd_dgrad: dh = (dxout (W2*gamma)) * gp;  dxmid = dxout + LN'(dh W1; xmid);  dln_w/dln_b += LayerNorm
  *                 parameter gradients.  w2g_t = (W2*gamma[:,None])^T stored [4C][C]; w1_t = W1^T stored [C][4C].
@@ -259,6 +263,44 @@ int rvt_lstm_scan_bwd(const void* x_all, const void* Hall, const void* Csave, co
                       const float* dc_last, const void* w, const void* wt, const float* bias, void* dx_all, void* dz_all,
                       void* dh0, float* dc0, float* dw, float* db, float* ws, const void* gates, int dtype, int M, int C,
                       int T_steps, void* stream);
+
+/* ---- stage-major driver (rvt_stage_seq_fwd) -------------------------------------------------------------
+ * One backbone stage (reference maxvit_rnn.py:169-182: down-sampling conv + LayerNorm, the window and grid attention blocks,
+ * the ConvLSTM) over ALL T time steps of B sequences in ONE call, for the NO-GRAD forward: validation and streaming inference
+ * (modules/detection.py:231-255 with T = 1 per call).  The kernel routing and the per-step ConvLSTM loop that rvt_amd/stage.py
+ * runs in Python happen inside the library; it launches exactly the operators declared in this header, on `stream`.
+ * (The training forward / backward keep their host loop in rvt_amd/stage.py: the saved-activation bookkeeping lives there.)
+ * All pointers in the descriptors are DEVICE pointers except `blocks`, a HOST array of 2 * num_blocks records
+ * (window block, grid block, window, grid, ...).  Unsupported here (call the operators instead): token masks, DWS-ConvLSTM. */
+typedef struct RvtBlockWeights {          /* one PartitionAttentionCl block, maxvit.py:193-270 */
+    const float *n1_w, *n1_b;             /* norm1 (NULL, NULL: Identity - the first window block of a stage) */
+    const void* qkv_w; const float* qkv_b;      /* [3C][C] (dtype), [3C] */
+    const void* proj_w; const float* proj_b;    /* [C][C], [C] */
+    const float* g1;                      /* LayerScale 1 [C] */
+    const float *n2_w, *n2_b;             /* norm2 */
+    const void* fc1_w; const float* fc1_b;      /* [4C][C], [4C] */
+    const void* fc2_w; const float* fc2_b;      /* [C][4C], [C] */
+    const float* g2;                      /* LayerScale 2 [C] */
+} RvtBlockWeights;
+typedef struct RvtStageDesc {
+    int struct_bytes;                     /* sizeof(RvtStageDesc) */
+    int dtype, C, Cin, cin_pad;           /* cin_pad: channel count of the packed conv weight / prepacked input (multiple of 8) */
+    int H_in, W_in, k, stride, pad;       /* conv geometry on the (padded) input resolution */
+    int ph, pw, dim_head, num_blocks;
+    float eps;
+    int inp_u8, h_raw, w_raw;             /* stage 1 fed by the loader's uint8 planes [F][Cin][h_raw][w_raw] (cast + zero pad fused in) */
+    const void* conv_w;                   /* [C][k*k*cin_pad] tap-major (rvt_conv_fwd layout) */
+    const float *ln_w, *ln_b;             /* LayerNorm after the conv */
+    const RvtBlockWeights* blocks;        /* HOST array, 2 * num_blocks entries */
+    const void* lstm_w; const float* lstm_b;      /* gate-interleaved rows (rvt_lstm_fwd) */
+    const void* lstm_wn; const float* lstm_bn;    /* natural row order (rvt_lstm_scan_fwd) */
+} RvtStageDesc;
+/* inp: [T*B][H_in][W_in][cin_pad] channels-last (dtype), or the uint8 planes when inp_u8;  h0 [B][H][W][C] (dtype) / c0 fp32,
+ * both NULL = zero state;  Hall [T+1][B][H][W][C]: slot 0 is scratch for the incoming h, slots 1..T receive h_t (the stage's
+ * output features = the next stage's input);  c_last fp32 [B][H][W][C];  ws: rvt_stage_seq_fwd_ws_bytes(desc, T, B) bytes. */
+size_t rvt_stage_seq_fwd_ws_bytes(const RvtStageDesc* desc, int T, int B);
+int rvt_stage_seq_fwd(const RvtStageDesc* desc, const void* inp, const void* h0, const float* c0, void* Hall, float* c_last,
+                      void* ws, size_t ws_bytes, int T, int B, void* stream);
 
 /* Depth-wise k x k conv (k = 3; groups = channels, padding k/2, stride 1) of the DWS-ConvLSTM (rnn.py:25-29,50-54)
  * on channels-last maps: y[n][y][x][c] = b[c] + sum_taps w[c][ky][kx] x[...][c].  x / y rows have pitch ldx / ldy

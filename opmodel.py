@@ -83,7 +83,7 @@ def model(name: str, a) -> Optional[Tuple[float, float]]:
         return 2.0 * M * N * K, 1.0 * M * (N + K) * e + 4.0 * N * K
     if name == 'rvt_mlp_fwd':                            # LN2 -> fc1 -> GELU -> fc2 -> gamma, + residual
         e, M, C = _elt(a[12]), a[13], a[14]
-        rows = 2 + (8 if P(2) else 0) + (1 if P(4) else 0)
+        rows = 2 + ((8 if P(3) else 4) if P(2) else 0) + (1 if P(4) else 0)        # (g_out alone = the pre-activation only)
         return 16.0 * M * C * C, (1.0 * rows * M * C + 8 * C * C) * e
     if name == 'rvt_mlp_bwd_dgrad':                      # fc2 dgrad * gp -> dh (stored) -> fc1 dgrad -> LN2' + residual
         e, M, C = _elt(a[10]), a[11], a[12]

@@ -22,7 +22,7 @@ from typing import Dict, List, Optional, Sequence, Tuple, Union
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import ops, tuning
 from .stage import SideStream, StageGeom, stage_seq_backward, stage_seq_forward
 from .weights import ModelWeights, param_signature, param_versions, round8
 
@@ -211,6 +211,11 @@ class RNNDetector(nn.Module):
         for st in prev_states:
             flat_states += [None, None] if st is None else [st[0], st[1]]
         params = [p for _, p in self.named_parameters()]
+        if not torch.is_grad_enabled() and tuning.get('route_stage_driver') != 0:
+            # validation / streaming inference: no autograd node, one library call per stage (csrc/capi_stage.hip)
+            r = self._forward_nograd(xs, prev_states, token_masks, params)
+            if r is not None:
+                return r
         # grad mode is read HERE: inside autograd.Function.forward it is always off, and needs_input_grad stays True for
         # parameters under torch.no_grad() — validation / streaming inference must not take the training path
         outs = _BackboneSeqFn.apply(self, xs, token_masks, torch.is_grad_enabled(), *flat_states, *params)
@@ -222,6 +227,45 @@ class RNNDetector(nn.Module):
         for s in range(self.num_stages):
             h, c = outs[2 * s][-1], outs[2 * s + 1]
             states.append((h if h.requires_grad else h.clone(memory_format=torch.preserve_format), c))
+        return feats, states
+
+    def _forward_nograd(self, xs: Tensor, prev_states, token_masks, params):
+        """The no-grad forward through the C-side stage driver (include/rvt_hip.h: rvt_stage_seq_fwd): Python allocates, the library
+        sequences the kernels.  Returns None when a stage is outside the driver's coverage (token masks, DWS-ConvLSTM): the caller
+        then takes the operator-by-operator host loop of rvt_amd/stage.py (same kernels)."""
+        from . import stage_driver as SD
+        ns, dt = self.num_stages, self.compute_dtype
+        T, B, Cin, h, w = xs.shape
+        Hm, Wm = self.in_res_hw if self.in_res_hw is not None else (h, w)
+        assert h <= Hm and w <= Wm, f'input {h}x{w} larger than model resolution {Hm}x{Wm}'
+        geoms = self.stage_geoms(Hm, Wm)
+        mw = self.model_weights(params, geoms, dt, False)
+        if token_masks is not None or any(sw.dws is not None for sw in mw.stages):
+            return None
+        src = xs.reshape(T * B, Cin, h, w)
+        if src.dtype not in (torch.uint8, torch.float32):
+            src = src.float()
+        u8 = src.dtype == torch.uint8
+        if u8:
+            inp = src.contiguous()
+        else:
+            inp = ops.prepack_input(src, Hm, Wm, round8(Cin), dt)
+        key = (dt, u8, h, w, Hm, Wm)
+        calls = getattr(mw, '_stage_calls', None)
+        if calls is None or calls[0] != key:
+            calls = (key, [SD.StageCall(mw.stages[si], geoms[si], dt, u8 and si == 0, h, w) for si in range(ns)])
+            mw._stage_calls = calls
+        feats, states = {}, []
+        for si in range(ns):
+            st = prev_states[si]
+            h0 = c0 = None
+            if st is not None:
+                h0, c0 = _to_cl(st[0], dt), _to_cl(st[1], torch.float32)
+            Hall, c_last = SD.stage_seq_fwd(calls[1][si], inp, h0, c0, T, B)
+            g = geoms[si]
+            inp = Hall[1:].reshape(T * B, g.H, g.W, g.C)
+            feats[si + 1] = Hall[1:].permute(0, 1, 4, 2, 3)
+            states.append((feats[si + 1][-1].clone(memory_format=torch.preserve_format), c_last.permute(0, 3, 1, 2)))
         return feats, states
 
     def invalidate_weight_cache(self) -> None:

@@ -73,7 +73,7 @@ int rvt_mlp_fwd(const void* xmid, void* xout, void* g_out, void* gp_out, void* v
                 const void* w1, const float* b1, const void* w2, const float* b2, const float* gamma, int dtype, int M,
                 int C, float eps, void* stream) {
     RVT_CHECK(rvt_mlp_fused_supported(dtype, C), "mlp_fwd: fused MLP not built for dtype=%d C=%d", dtype, C);
-    RVT_CHECK((g_out == nullptr) == (gp_out == nullptr), "mlp_fwd: g_out and gp_out go together");
+    RVT_CHECK(gp_out == nullptr || g_out != nullptr, "mlp_fwd: gp_out needs g_out (g_out alone = the pre-activation h)");
     hipStream_t st = (hipStream_t)stream;
     if (g_out == nullptr && v2_out == nullptr && mlp_chain_on(dtype, C)) {
         // nothing to save: the register-chained kernel (csrc/mlp_chain.hpp)

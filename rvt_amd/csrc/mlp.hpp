@@ -318,8 +318,12 @@ mlp_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, T* __restrict__
                     opm_store_frag<T>(Ah, TM, row, cu, gf);
                     if (g_out != nullptr && m0 + row < M) {
                         const size_t o = (size_t)(m0 + row) * HID + j0 + cu * 8;
-                        frag_store<T>(g_out + o, gf);
-                        frag_store<T>(gp_out + o, frag_from_float<T>(b));
+                        if (gp_out != nullptr) {
+                            frag_store<T>(g_out + o, gf);
+                            frag_store<T>(gp_out + o, frag_from_float<T>(b));
+                        } else {                      // pre-activation only (round 4): half the 4C-wide bytes; the backward applies GELU /
+                            frag_store<T>(g_out + o, frag_from_float<T>(v));   // GELU' on load (rvt_linear_wgrad gelu_in, rvt_linear_dgrad gelu_pre)
+                        }
                     }
                 }
             }

@@ -205,17 +205,17 @@ def mlp_fused_supported(dtype: torch.dtype, C: int) -> bool:
 
 
 def mlp_fwd(xmid: Tensor, ln_w: Tensor, ln_b: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, gamma: Tensor,
-            eps: float, want_grad: bool = False, out: Optional[Tensor] = None, want_v2: bool = False):
+            eps: float, want_grad: bool = False, out: Optional[Tensor] = None, want_v2: bool = False, want_pre: bool = False):
     """xout = xmid + gamma*(GELU(LN(xmid) W1^T + b1) W2^T + b2) in one fused kernel; with want_grad also returns
-    g = GELU(h), gp = GELU'(h) (the only intermediates backward needs).  Returns (xout, g, gp), or with want_v2
-    (xout, g, gp, LN(xmid))."""
+    g = GELU(h), gp = GELU'(h) (the only intermediates backward needs); with want_pre instead the pre-activation h alone
+    (returned in g's place, gp None).  Returns (xout, g, gp), or with want_v2 (xout, g, gp, LN(xmid))."""
     C = xmid.shape[-1]
     M = xmid.numel() // C
     y = _out(xmid, xmid.shape, out=out)
     g = gp = None
-    if want_grad:
+    if want_grad or want_pre:
         g = torch.empty((*xmid.shape[:-1], 4 * C), dtype=xmid.dtype, device=xmid.device)
-        gp = torch.empty_like(g)
+        gp = None if want_pre else torch.empty_like(g)
     v2 = torch.empty_like(xmid) if want_v2 else None
     L.call('rvt_mlp_fwd', L.ptr(xmid), L.ptr(y), L.ptr(g), L.ptr(gp), L.ptr(v2), L.ptr(ln_w), L.ptr(ln_b), L.ptr(w1),
            L.ptr(b1), L.ptr(w2), L.ptr(b2), L.ptr(gamma), L.dtype_code(xmid.dtype), M, C, float(eps), L.stream_of(xmid))

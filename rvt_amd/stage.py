@@ -173,14 +173,19 @@ def stage_seq_forward(sw: StageWeights, g: StageGeom, inp: Tensor, h0: Optional[
                 a = ops.attn_fwd(qkv, F_, H, W, C, g.dim_head, g.ph, g.pw, window)    # maxvit.py:349-352
                 xmid = ops.linear_scale_res_fwd(a, bw['proj_w'], bw['proj_b'], bw['g1'], x)        # :353, :268
             v2 = None
+            hpre = False
             if save and use_fused_mlp(dt, C, 'bwd_fused'):
                 # the backward recomputes everything from xmid: inference-flavoured forward, nothing else kept
                 xout, hg, hgp = ops.mlp_fwd(xmid, bw['n2_w'], bw['n2_b'], bw['fc1_w'], bw['fc1_b'], bw['fc2_w'], bw['fc2_b'],
                                             bw['g2'], g.eps, want_grad=False)
             elif use_fused_mlp(dt, C, 'fwd_train' if save else 'fwd_infer'):
+                # training forward at C = 128: by default only the pre-activation h is kept (hg = h, hgp = None); the backward
+                # applies GELU on load in the fc2 weight gradient and GELU' in the epilogue of the fc2 input gradient
+                pre = save and tuning.get('route_mlp_store_pre') != 0 and not use_fused_mlp(dt, C, 'bwd')
                 r = ops.mlp_fwd(xmid, bw['n2_w'], bw['n2_b'], bw['fc1_w'], bw['fc1_b'], bw['fc2_w'], bw['fc2_b'], bw['g2'],
-                                g.eps, want_grad=save, want_v2=save)
+                                g.eps, want_grad=save and not pre, want_v2=save, want_pre=pre)
                 xout, hg, hgp = r[:3]
+                hpre = pre
                 v2 = r[3] if save else None     # LN2(xmid), saved for the fc1 weight gradient
             else:
                 v2 = ops.layernorm_fwd(xmid, bw['n2_w'], bw['n2_b'], g.eps)
@@ -190,7 +195,7 @@ def stage_seq_forward(sw: StageWeights, g: StageGeom, inp: Tensor, h0: Optional[
             if save:
                 # the LayerNorm outputs are the B operands of the qkv / fc1 weight gradients: kept (1 row of C per token
                 # each, 288 GB of HBM) rather than recomputed — a recompute is a read + a write + the re-read
-                sv.blocks.append(dict(xin=x, qkv=qkv, a=a, xmid=xmid, hg=hg, hgp=hgp, u=u, v2=v2))
+                sv.blocks.append(dict(xin=x, qkv=qkv, a=a, xmid=xmid, hg=hg, hgp=hgp, u=u, v2=v2, hpre=hpre))
             x = xout
 
     Hall = torch.empty((T + 1, B, H, W, C), dtype=dt, device=dev)
@@ -354,12 +359,14 @@ def stage_seq_backward(sw: StageWeights, g: StageGeom, sv: StageSaved, dH: Optio
                                                     bw['fc2_wt'], bw['fc1_wt'], dn2w, dn2b, g.eps)
             else:
                 def fc2_wgrad_fn(dx=dx, s=s, bp=bp):
-                    ops.linear_wgrad(dx, s['hg'], G(bp + 'S2'), colsum_out=G(bp + 'cs2'))
+                    ops.linear_wgrad(dx, s['hg'], G(bp + 'S2'), gelu_in=s['hpre'], colsum_out=G(bp + 'cs2'))
                 side.run(fc2_wgrad_fn, dx, s['hg'])
                 fused = use_fused_mlp(dt, C, 'bwd')
                 if fused:       # fc2 dgrad * gp, fc1 dgrad and LayerNorm-2 backward (+ residual) in one kernel
                     dhd, dxmid = ops.mlp_bwd_dgrad(dx, s['hgp'], s['xmid'], bw['n2_w'], bw['fc2_wt'], bw['fc1_wt'], dn2w,
                                                    dn2b, g.eps)
+                elif s['hpre']:
+                    dhd = ops.linear_dgrad(dx, bw['fc2_wt'], gelu_pre=s['hg'])
                 else:
                     dhd = ops.linear_dgrad(dx, bw['fc2_wt'], mul=s['hgp'])
                 def fc1_wgrad_fn(dhd=dhd, s=s, bw=bw, bp=bp):

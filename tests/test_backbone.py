@@ -81,14 +81,16 @@ def test_backbone_fp32_vs_reference_golden_emu(name):
     compare(got, load_golden(name), rtol=1e-3, what=f'hip(emu) vs reference [{name}]', grad_rtol=1e-3)
 
 
-@pytest.mark.parametrize('dtype,rtol,grtol', [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 3e-2, 5e-2)])
-def test_backbone_fused_mlp_path_emu(dtype, rtol, grtol):
-    """Opt-in fused-MLP route (tuning.route_fused_mlp = 1; stages with C in {64,128}) against the reference golden."""
+@pytest.mark.parametrize('dtype,rtol,grtol,route', [(torch.float32, 1e-3, 1e-3, 1), (torch.bfloat16, 3e-2, 5e-2, 1),
+                                                    (torch.bfloat16, 3e-2, 5e-2, -1)])
+def test_backbone_fused_mlp_path_emu(dtype, rtol, grtol, route):
+    """Fused-MLP routes against the reference golden: tuning.route_fused_mlp = 1 (every supported half; stages with C in {64,128})
+    and the bf16 default -1 (C = 128: fused forward that saves only the pre-activation + op-by-op backward with GELU on load)."""
     from rvt_amd import _lib, tuning
     from tests.backends import emu_library
     _lib._install_test_library(emu_library())
     try:
-        with tuning.override(route_fused_mlp=1):
+        with tuning.override(route_fused_mlp=route):
             got = run_hip_case('micro', torch.device('cpu'), dtype, with_batch2=False)
     finally:
         _lib._install_test_library(None)

@@ -168,6 +168,17 @@ def test_mlp_fused(backend, dt, C, M):
     g2, gp2 = ops.linear_gelu_fwd(v2h, w1, b1, want_grad=True)
     y2 = ops.linear_scale_res_fwd(g2, w2, b2, gam, x)
     close(y, y2.double(), dt, 'mlp_fwd fused vs chain', mult=mult)
+    # round 4: the pre-activation-only flavour (what the C = 128 training forward keeps) and the backward that consumes it:
+    # GELU on load in the fc2 weight gradient, GELU' in the epilogue of the fc2 input gradient
+    y_pre, hpre, none_gp, _ = ops.mlp_fwd(x, lw, lb, w1, b1, w2, b2, gam, 1e-5, want_pre=True, want_v2=True)
+    assert none_gp is None
+    close(y_pre, want, dt, 'mlp_fwd fused (pre-activation saved)', mult=mult)
+    close(hpre, pre.detach(), dt, 'mlp_fwd saved pre-activation', mult=mult)
+    s2 = torch.zeros(C, 4 * C, device=backend)
+    ops.linear_wgrad(dy, hpre, s2, gelu_in=True)
+    close(s2, f64(dy).t() @ h.detach(), dt, 'fc2 weight gradient from the pre-activation', mult=2 * mult)
+    dh_pre = ops.linear_dgrad(dy, (f64(w2) * f64(gam)[:, None]).t().to(dt).contiguous().to(backend), gelu_pre=hpre)
+    close(dh_pre, pre.grad, dt, 'fc2 input gradient * GELU\'(pre-activation)', mult=2 * mult)
 
     # backward dgrad chain: dh (grad of the pre-activation), dxmid, LayerNorm parameter grads
     w2g_t = (f64(w2) * f64(gam)[:, None]).t().to(dt).contiguous().to(backend)
