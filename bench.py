@@ -264,15 +264,19 @@ def stream_latency(wl, dtype, device, args):
             e0.record()
             _, states = model(frames[i % 4], states)
             e1.record()
+            t_host = time.perf_counter() - t0                  # the call has returned: everything is enqueued
             torch.cuda.synchronize()
-            lat.append((1e3 * (time.perf_counter() - t0), e0.elapsed_time(e1)))
+            lat.append((1e3 * (time.perf_counter() - t0), e0.elapsed_time(e1), 1e3 * t_host))
     wall = sorted(x[0] for x in lat)
     gpu = sorted(x[1] for x in lat)
+    host = sorted(x[2] for x in lat)
     pct = lambda a, q: a[min(len(a) - 1, int(q * len(a)))]
     print(json.dumps({'metric': 'streaming-inference step latency (T=1, persistent ConvLSTM state)', 'unit': 'ms',
                       'batch': Bs, 'dtype': args.dtype, 'config': {'workload': wl['label'].split(',')[0] + f', B={Bs}, T=1'},
                       'wall_p50': round(pct(wall, 0.5), 3), 'wall_p99': round(pct(wall, 0.99), 3),
                       'gpu_p50': round(pct(gpu, 0.5), 3), 'gpu_p99': round(pct(gpu, 0.99), 3),
+                      'host_enqueue_p50': round(pct(host, 0.5), 3),
+                      'mfma_frac_p50': round(Bs * wl['f_fwd'] / (pct(wall, 0.5) * 1e-3) / (PEAK_TFLOPS[args.dtype] * 1e12), 4),
                       'event_tensors_per_s_p50': round(Bs / pct(wall, 0.5) * 1e3, 1), 'higher_is_better': False,
                       'data': 'synthetic'}), flush=True)
 
