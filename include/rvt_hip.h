@@ -322,6 +322,27 @@ int rvt_token_mask_bwd(void* dx, const unsigned char* mask, float* dtoken, int d
  * scatter = 1 is the backward: dst[idx[n]] = src[n] (dst zero-filled by the caller; indices distinct). */
 int rvt_gather_frames(const void* src, const int* idx, void* dst, int n_sel, size_t frame_bytes, int scatter, void* stream);
 
+/* ---- YOLOX PAFPN building block (reference models/detection/yolox/models/network_blocks.py:29-53) ----
+ * BaseConv = Conv2d(bias=False) -> BatchNorm2d(eps 1e-5, momentum 0.1) -> SiLU on channels-last maps x[rows = N*H*W][C].  The conv
+ * is rvt_conv_fwd / rvt_conv_dgrad / rvt_conv_wgrad; these are the row-wise kernels around it (csrc/bnact.hpp).  act: 0 none, 1 SiLU.
+ *   rvt_bn_stats:          sum[C] += column sums of x, sumsq[C] += column sums of x^2 (fp32; zero them first; under data parallelism
+ *                          these two vectors are what SyncBatchNorm all-reduces, train.py:133)
+ *   rvt_bn_finalize:       training: mean = sum / rows, var = sumsq / rows - mean^2 (biased), running statistics updated in place with
+ *                          `momentum` (unbiased variance) when non-NULL; eval: mean / var = the running statistics.  Writes
+ *                          scale = gamma * rstd, shift = beta - mean * scale and (nullable) mean_out / rstd_out for the backward.
+ *   rvt_bn_act_fwd:        y = act(x * scale + shift)            (y may alias x)
+ *   rvt_bn_act_bwd_stats:  dz = dy * act'(x * scale + shift);  dsum[C] += sum dz (= dbeta), dxsum[C] += sum dz * xhat (= dgamma)
+ *   rvt_bn_act_bwd_apply:  dx = scale * (dz - dsum / rows - xhat * dxsum / rows)      (training-mode BatchNorm backward) */
+int rvt_bn_stats(const void* x, float* sum, float* sumsq, int dtype, int rows, int C, void* stream);
+int rvt_bn_finalize(const float* sum, const float* sumsq, int rows, const float* gamma, const float* beta, float eps, float momentum,
+                    float* running_mean, float* running_var, float* mean_out, float* rstd_out, float* scale, float* shift, int C,
+                    int training, void* stream);
+int rvt_bn_act_fwd(const void* x, const float* scale, const float* shift, void* y, int dtype, int rows, int C, int act, void* stream);
+int rvt_bn_act_bwd_stats(const void* dy, const void* x, const float* scale, const float* shift, const float* mean, const float* rstd,
+                         float* dsum, float* dxsum, int dtype, int rows, int C, int act, void* stream);
+int rvt_bn_act_bwd_apply(const void* dy, const void* x, const float* scale, const float* shift, const float* mean, const float* rstd,
+                         const float* dsum, const float* dxsum, void* dx, int dtype, int rows, int C, int act, void* stream);
+
 /* Zero state rows of samples with mask[b] != 0 (modules/utils/detection.py:96-113).
  * st is [B][per_sample] of float32 (is_f32) or `dtype`. */
 int rvt_state_reset_masked(void* st, const unsigned char* mask, int dtype, int B, size_t per_sample, void* stream);

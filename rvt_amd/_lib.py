@@ -61,6 +61,11 @@ _SIGS = {
     'rvt_lstm_scan_fwd': [_vp] * 8 + [_i, _i, _i, _i, _vp],
     'rvt_lstm_scan_bwd': [_vp] * 17 + [_i, _i, _i, _i, _vp],
     'rvt_layerscale_grad_table': [_vp, _i, _i, _vp],
+    'rvt_bn_stats': [_vp, _vp, _vp, _i, _i, _i, _vp],
+    'rvt_bn_finalize': [_vp, _vp, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    'rvt_bn_act_fwd': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    'rvt_bn_act_bwd_stats': [_vp] * 8 + [_i, _i, _i, _i, _vp],
+    'rvt_bn_act_bwd_apply': [_vp] * 9 + [_i, _i, _i, _i, _vp],
 }
 EXPORTS = sorted(list(_SIGS) + ['rvt_last_error', 'rvt_is_emulator', 'rvt_wgrad_workspace_floats',
                                'rvt_mlp_fused_supported', 'rvt_lstm_scan_supported', 'rvt_mlp_bwd_fused_supported',

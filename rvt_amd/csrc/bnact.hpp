@@ -1,0 +1,148 @@
+// BatchNorm2d + SiLU of the YOLOX PAFPN's BaseConv units on channels-last maps (reference
+// models/detection/yolox/models/network_blocks.py:29-53: Conv2d(bias=False) -> BatchNorm2d -> SiLU; nn.BatchNorm2d defaults
+// eps 1e-5, momentum 0.1).  SURVEY.md section 8 row f2.  The conv itself runs on the GEMM engine (rvt_conv_fwd / _dgrad / _wgrad);
+// these are the row-wise kernels around it, all HBM-bound (one 16-byte vector of 8 channels per thread and row):
+//   bn_stats          per-channel sum and sum of squares of the conv output over all N*H*W rows (training: batch statistics;
+//                     under data parallelism the two vectors are what SyncBatchNorm all-reduces, train.py:133)
+//   bn_finalize       mean / rstd, the fused scale = gamma * rstd and shift = beta - mean * scale, running-statistics update
+//   bn_act_fwd        y = silu(x * scale + shift)
+//   bn_act_bwd_stats  dz = dy * silu'(z), z = x * scale + shift;  sum(dz), sum(dz * xhat) per channel  (= dbeta, dgamma)
+//   bn_act_bwd_apply  dx = gamma * rstd * (dz - sum(dz) / N - xhat * sum(dz * xhat) / N)
+#pragma once
+#include "common.hpp"
+
+namespace rvt {
+
+enum { BN_ACT_NONE = 0, BN_ACT_SILU = 1 };
+
+__device__ __forceinline__ float silu_f(float z) { return z * sigmoid_f(z); }
+__device__ __forceinline__ float silu_grad_f(float z) { const float s = sigmoid_f(z); return s * (1.f + z * (1.f - s)); }
+
+// threads: Gp = pow2 >= C/8 column groups x 256/Gp row lanes; a workgroup strides over row blocks
+template <class T, int NACC, class F>
+__device__ __forceinline__ void bn_column_reduce(int rows, int C, int Gp, float* const* outs, F&& per_row) {
+    const int tid = threadIdx.x, cg = tid % Gp, r0 = tid / Gp, nrl = 256 / Gp;
+    const bool cvalid = cg * 8 < C;
+    float acc[NACC][8];
+#pragma unroll
+    for (int a = 0; a < NACC; a++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) acc[a][i] = 0.f;
+    if (cvalid)
+        for (int row = blockIdx.x * nrl + r0; row < rows; row += gridDim.x * nrl) per_row(row, cg, acc);
+    __shared__ float red[256 * 8];                          // [row lane][Gp * 8 columns], one accumulator at a time
+#pragma unroll
+    for (int a = 0; a < NACC; a++) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; i++) red[r0 * (Gp * 8) + cg * 8 + i] = acc[a][i];
+        __syncthreads();
+        for (int c = tid; c < C; c += 256) {
+            float s = 0.f;
+            for (int r = 0; r < nrl; r++) s += red[r * (Gp * 8) + c];
+            atomicAdd(outs[a] + c, s);                      // one atomic per column per workgroup
+        }
+    }
+}
+
+template <class T>
+__global__ void __launch_bounds__(256)
+bn_stats_kernel(const T* __restrict__ x, float* __restrict__ sum, float* __restrict__ sumsq, int rows, int C, int Gp) {
+    float* outs[2] = {sum, sumsq};
+    bn_column_reduce<T, 2>(rows, C, Gp, outs, [&](int row, int cg, float (&acc)[2][8]) {
+        float v[8];
+        frag_to_float<T>(frag_load<T>(x + (size_t)row * C + cg * 8), v);
+#pragma unroll
+        for (int i = 0; i < 8; i++) { acc[0][i] += v[i]; acc[1][i] += v[i] * v[i]; }
+    });
+}
+
+// one workgroup; training: batch statistics (biased variance for the normalisation, unbiased for running_var, as nn.BatchNorm2d)
+__global__ void __launch_bounds__(256)
+bn_finalize_kernel(const float* __restrict__ sum, const float* __restrict__ sumsq, float count, const float* __restrict__ gamma,
+                   const float* __restrict__ beta, float eps, float momentum, float* __restrict__ running_mean,
+                   float* __restrict__ running_var, float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                   float* __restrict__ scale, float* __restrict__ shift, int C, int training) {
+    for (int c = threadIdx.x + blockIdx.x * blockDim.x; c < C; c += blockDim.x * gridDim.x) {
+        float mean, var;
+        if (training) {
+            mean = sum[c] / count;
+            var = fmaxf(sumsq[c] / count - mean * mean, 0.f);
+            if (running_mean != nullptr) {
+                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * (count > 1.f ? count / (count - 1.f) : 1.f);
+            }
+        } else {
+            mean = running_mean[c];
+            var = running_var[c];
+        }
+        const float rstd = 1.0f / sqrtf(var + eps);
+        const float sc = gamma[c] * rstd;
+        if (mean_out != nullptr) { mean_out[c] = mean; rstd_out[c] = rstd; }
+        scale[c] = sc;
+        shift[c] = beta[c] - mean * sc;
+    }
+}
+
+template <class T>
+__global__ void __launch_bounds__(256)
+bn_act_fwd_kernel(const T* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift, T* __restrict__ y,
+                  size_t n_frag, int G, int act) {
+    for (size_t f = (size_t)blockIdx.x * 256 + threadIdx.x; f < n_frag; f += (size_t)gridDim.x * 256) {
+        const int cg = (int)(f % G);
+        float v[8], o[8];
+        frag_to_float<T>(frag_load<T>(x + f * 8), v);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const float z = fmaf(v[i], scale[cg * 8 + i], shift[cg * 8 + i]);
+            o[i] = act == BN_ACT_SILU ? silu_f(z) : z;
+        }
+        frag_store<T>(y + f * 8, frag_from_float<T>(o));
+    }
+}
+
+template <class T>
+__global__ void __launch_bounds__(256)
+bn_act_bwd_stats_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ scale,
+                        const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ rstd,
+                        float* __restrict__ dsum, float* __restrict__ dxsum, int rows, int C, int Gp, int act) {
+    float* outs[2] = {dsum, dxsum};
+    bn_column_reduce<T, 2>(rows, C, Gp, outs, [&](int row, int cg, float (&acc)[2][8]) {
+        float v[8], d[8];
+        frag_to_float<T>(frag_load<T>(x + (size_t)row * C + cg * 8), v);
+        frag_to_float<T>(frag_load<T>(dy + (size_t)row * C + cg * 8), d);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int c = cg * 8 + i;
+            const float z = fmaf(v[i], scale[c], shift[c]);
+            const float dz = act == BN_ACT_SILU ? d[i] * silu_grad_f(z) : d[i];
+            acc[0][i] += dz;
+            acc[1][i] += dz * (v[i] - mean[c]) * rstd[c];
+        }
+    });
+}
+
+template <class T>
+__global__ void __launch_bounds__(256)
+bn_act_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ scale,
+                        const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ rstd,
+                        const float* __restrict__ dsum, const float* __restrict__ dxsum, T* __restrict__ dx, size_t n_frag, int G,
+                        float inv_count, int act) {
+    for (size_t f = (size_t)blockIdx.x * 256 + threadIdx.x; f < n_frag; f += (size_t)gridDim.x * 256) {
+        const int cg = (int)(f % G);
+        float v[8], d[8], o[8];
+        frag_to_float<T>(frag_load<T>(x + f * 8), v);
+        frag_to_float<T>(frag_load<T>(dy + f * 8), d);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int c = cg * 8 + i;
+            const float z = fmaf(v[i], scale[c], shift[c]);
+            const float dz = act == BN_ACT_SILU ? d[i] * silu_grad_f(z) : d[i];
+            const float xh = (v[i] - mean[c]) * rstd[c];
+            o[i] = scale[c] * (dz - dsum[c] * inv_count - xh * dxsum[c] * inv_count);       // scale = gamma * rstd
+        }
+        frag_store<T>(dx + f * 8, frag_from_float<T>(o));
+    }
+}
+
+}  // namespace rvt

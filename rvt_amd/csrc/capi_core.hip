@@ -4,6 +4,7 @@
 #include "rowops.hpp"
 #include "events.hpp"
 #include "pack.hpp"
+#include "bnact.hpp"
 
 namespace rvt {
 static thread_local char g_err[512] = "";
@@ -229,6 +230,48 @@ int rvt_gather_frames(const void* src, const int* idx, void* dst, int n_sel, siz
     else
         hipLaunchKernelGGL((gather_frames_kernel<false>), dim3(grid), dim3(256), 0, st, (const u32x4*)src, idx, (u32x4*)dst, n_sel, fv);
     return check_launch("gather_frames");
+}
+
+// ---------------------------------------------------------------- BatchNorm2d + SiLU of the PAFPN's BaseConv units (bnact.hpp)
+int rvt_bn_stats(const void* x, float* sum, float* sumsq, int dtype, int rows, int C, void* stream) {
+    RVT_CHECK(C % 8 == 0 && C >= 8 && C <= 1024 && rows >= 1, "bn_stats: C=%d must be a multiple of 8 in [8, 1024]", C);
+    const int Gp = pow2_ge(C / 8), nrl = 256 / Gp;
+    const int grid = imin(1024, imax(1, (rows + nrl * 8 - 1) / (nrl * 8)));
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_stats_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)x, sum, sumsq, rows, C, Gp));
+    return check_launch("bn_stats");
+}
+int rvt_bn_finalize(const float* sum, const float* sumsq, int rows, const float* gamma, const float* beta, float eps, float momentum,
+                    float* running_mean, float* running_var, float* mean_out, float* rstd_out, float* scale, float* shift, int C,
+                    int training, void* stream) {
+    RVT_CHECK(C >= 1 && gamma && beta && scale && shift, "bn_finalize: bad arguments");
+    RVT_CHECK(training ? (sum && sumsq && rows >= 1) : (running_mean && running_var), "bn_finalize: training needs sums, eval needs running statistics");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sum, sumsq, (float)rows, gamma, beta, eps, momentum,
+                       running_mean, running_var, mean_out, rstd_out, scale, shift, C, training);
+    return check_launch("bn_finalize");
+}
+int rvt_bn_act_fwd(const void* x, const float* scale, const float* shift, void* y, int dtype, int rows, int C, int act, void* stream) {
+    RVT_CHECK(C % 8 == 0 && C >= 8 && rows >= 1 && (act == 0 || act == 1), "bn_act_fwd: bad shape / activation");
+    const size_t nf = (size_t)rows * (C / 8);
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_act_fwd_kernel<T>), dim3(grid_for(nf, 8192)), dim3(256), 0, (hipStream_t)stream, (const T*)x, scale,
+                                             shift, (T*)y, nf, C / 8, act));
+    return check_launch("bn_act_fwd");
+}
+int rvt_bn_act_bwd_stats(const void* dy, const void* x, const float* scale, const float* shift, const float* mean, const float* rstd,
+                         float* dsum, float* dxsum, int dtype, int rows, int C, int act, void* stream) {
+    RVT_CHECK(C % 8 == 0 && C >= 8 && C <= 1024 && rows >= 1, "bn_act_bwd_stats: C=%d must be a multiple of 8 in [8, 1024]", C);
+    const int Gp = pow2_ge(C / 8), nrl = 256 / Gp;
+    const int grid = imin(1024, imax(1, (rows + nrl * 8 - 1) / (nrl * 8)));
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_act_bwd_stats_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)dy, (const T*)x,
+                                             scale, shift, mean, rstd, dsum, dxsum, rows, C, Gp, act));
+    return check_launch("bn_act_bwd_stats");
+}
+int rvt_bn_act_bwd_apply(const void* dy, const void* x, const float* scale, const float* shift, const float* mean, const float* rstd,
+                         const float* dsum, const float* dxsum, void* dx, int dtype, int rows, int C, int act, void* stream) {
+    RVT_CHECK(C % 8 == 0 && C >= 8 && rows >= 1, "bn_act_bwd_apply: bad shape");
+    const size_t nf = (size_t)rows * (C / 8);
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T>), dim3(grid_for(nf, 8192)), dim3(256), 0, (hipStream_t)stream, (const T*)dy,
+                                             (const T*)x, scale, shift, mean, rstd, dsum, dxsum, (T*)dx, nf, C / 8, 1.0f / (float)rows, act));
+    return check_launch("bn_act_bwd_apply");
 }
 
 int rvt_state_reset_masked(void* st_, const unsigned char* mask, int dtype, int B, size_t per_sample, void* stream) {

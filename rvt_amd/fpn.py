@@ -1,0 +1,203 @@
+"""YOLOX PAFPN on the backbone's stage 2-4 features — MI355X-native.
+
+Mirror of the reference module surface (models/detection/yolox_extension/models/yolo_pafpn.py:18-139 built from the blocks of
+models/detection/yolox/models/network_blocks.py:29-141): same constructor arguments, same parameter / buffer names and shapes
+(`lateral_conv0.conv.weight`, `C3_p4.m.0.conv1.bn.running_var`, ...: reference checkpoints load with strict=True), same
+`forward(input: Dict[int, Tensor]) -> (pan_out2, pan_out1, pan_out0)`.
+
+Every BaseConv unit (Conv2d(bias=False) -> BatchNorm2d -> SiLU) runs on the HIP kernels behind include/rvt_hip.h, forward AND
+backward, channels-last end to end: the convolution on the im2col GEMM engine (rvt_conv_fwd / _dgrad / _wgrad), BatchNorm
+(batch statistics in training, running statistics in eval, running-statistics update) + SiLU on the row-wise kernels of
+csrc/bnact.hpp.  torch is used for memory and for the two pure data movements of the neck (channel concatenation and nearest
+2x up-sampling of channels-last maps), whose autograd is index arithmetic.  Under data parallelism the two statistics vectors of
+each BatchNorm are all-reduced (what SyncBatchNorm does, train.py:133).
+
+Not built: depthwise=True (DWConv, no shipped config), activations other than SiLU.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import ops, weights
+
+Tensor = torch.Tensor
+BN_ACT_SILU = 1
+
+
+def _bn_reduce(t: Tensor) -> None:
+    """SyncBatchNorm's exchange: sum the statistics over the data-parallel ranks (no-op at world size 1)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t)
+
+
+class _BaseConvFn(torch.autograd.Function):
+    """y = SiLU(BatchNorm(conv(x))) on a channels-last (N, H, W, Cin) map; every arithmetic step is a HIP kernel."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, w: Tensor, gamma: Tensor, beta: Tensor, mod: 'BaseConv', training: bool, sync: bool):
+        dt, dev = x.dtype, x.device
+        N, H, W, Cin = x.shape
+        Cout, k, s, pad = mod.out_channels, mod.ksize, mod.stride, mod.pad
+        wp = weights.pack_conv_fwd(w.detach(), Cin, dt)                                  # [Cout][k*k*Cin] tap-major
+        y0 = ops.conv_fwd(x, wp, k, s, pad)                                               # network_blocks.py:37-45 (bias=False)
+        rows = y0.numel() // Cout
+        f32 = torch.float32
+        st = L.stream_of(y0)
+        stats = torch.zeros(2, Cout, dtype=f32, device=dev)
+        count = rows
+        if training:
+            L.call('rvt_bn_stats', L.ptr(y0), L.ptr(stats[0]), L.ptr(stats[1]), L.dtype_code(dt), rows, Cout, st)
+            if sync:
+                cnt = torch.tensor([float(rows)], device=dev)
+                _bn_reduce(stats)
+                _bn_reduce(cnt)
+                count = int(cnt.item())
+        fin = torch.empty(4, Cout, dtype=f32, device=dev)                                 # mean, rstd, scale, shift
+        bn = mod.bn
+        g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        L.call('rvt_bn_finalize', L.ptr(stats[0]), L.ptr(stats[1]), count, L.ptr(g32), L.ptr(b32), float(bn.eps),
+               float(bn.momentum if bn.momentum is not None else 0.1),
+               L.ptr(bn.running_mean) if bn.track_running_stats else None, L.ptr(bn.running_var) if bn.track_running_stats else None,
+               L.ptr(fin[0]), L.ptr(fin[1]), L.ptr(fin[2]), L.ptr(fin[3]), Cout, int(training), st)
+        if training and bn.track_running_stats:
+            bn.num_batches_tracked += 1
+        y = torch.empty_like(y0)
+        L.call('rvt_bn_act_fwd', L.ptr(y0), L.ptr(fin[2]), L.ptr(fin[3]), L.ptr(y), L.dtype_code(dt), rows, Cout, BN_ACT_SILU, st)
+        ctx.save_for_backward(x, w, y0, fin)
+        ctx.mod, ctx.count, ctx.sync, ctx.training = mod, count, sync, training
+        return y
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        x, w, y0, fin = ctx.saved_tensors
+        mod = ctx.mod
+        assert ctx.training, 'the PAFPN backward is the training-mode (batch-statistics) BatchNorm backward'
+        dt, dev = x.dtype, x.device
+        N, H, W, Cin = x.shape
+        Cout, k, s, pad = mod.out_channels, mod.ksize, mod.stride, mod.pad
+        rows = y0.numel() // Cout
+        dy = dy.contiguous()
+        st = L.stream_of(dy)
+        ds = torch.zeros(2, Cout, dtype=torch.float32, device=dev)                        # sum dz (= dbeta), sum dz * xhat (= dgamma)
+        L.call('rvt_bn_act_bwd_stats', L.ptr(dy), L.ptr(y0), L.ptr(fin[2]), L.ptr(fin[3]), L.ptr(fin[0]), L.ptr(fin[1]), L.ptr(ds[0]),
+               L.ptr(ds[1]), L.dtype_code(dt), rows, Cout, BN_ACT_SILU, st)
+        if ctx.sync:
+            _bn_reduce(ds)
+        dconv = torch.empty_like(y0)
+        # (the kernel divides the two sums by its `rows` argument; with synchronised statistics the divisor is the global count)
+        dsk = ds if ctx.count == rows else ds * (float(rows) / float(ctx.count))
+        L.call('rvt_bn_act_bwd_apply', L.ptr(dy), L.ptr(y0), L.ptr(fin[2]), L.ptr(fin[3]), L.ptr(fin[0]), L.ptr(fin[1]), L.ptr(dsk[0]),
+               L.ptr(dsk[1]), L.ptr(dconv), L.dtype_code(dt), rows, Cout, BN_ACT_SILU, st)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wd = weights.pack_conv_dgrad(w.detach(), s, pad, dt)
+            dx = ops.conv_dgrad(dconv, wd, None, H, W, Cin, k, s, pad)
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dwp = torch.zeros(Cout, k * k * Cin, dtype=torch.float32, device=dev)
+            ops.conv_wgrad(x, dconv, dwp, k, s, pad)
+            dw = weights.unpack_conv_wgrad(dwp, Cin, k).to(w.dtype)
+        return dx, dw, ds[1].to(w.dtype), ds[0].to(w.dtype), None, None, None
+
+
+class BaseConv(nn.Module):
+    """Conv2d -> BatchNorm2d -> SiLU (network_blocks.py:29-53).  `conv` and `bn` are the reference's own parameter containers
+    (same names, shapes, initialisation); their torch forward is never called."""
+
+    def __init__(self, in_channels: int, out_channels: int, ksize: int, stride: int, groups: int = 1, bias: bool = False, act: str = 'silu'):
+        super().__init__()
+        if groups != 1 or bias or act != 'silu':
+            raise NotImplementedError('rvt_amd.fpn.BaseConv: groups = 1, bias = False, act = "silu" (every shipped config)')
+        self.in_channels, self.out_channels, self.ksize, self.stride, self.pad = in_channels, out_channels, ksize, stride, (ksize - 1) // 2
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=ksize, stride=stride, padding=self.pad, groups=1, bias=False)
+        self.bn = nn.BatchNorm2d(out_channels)
+
+    def forward(self, x: Tensor) -> Tensor:
+        """x: channels-last (N, H, W, Cin) in the compute dtype."""
+        return _BaseConvFn.apply(x.contiguous(), self.conv.weight, self.bn.weight, self.bn.bias, self, self.training, self.training)
+
+
+class Bottleneck(nn.Module):
+    def __init__(self, in_channels, out_channels, shortcut=True, expansion=0.5, depthwise=False, act='silu'):
+        super().__init__()
+        if depthwise:
+            raise NotImplementedError('depthwise PAFPN blocks are not built (no shipped config enables them)')
+        hidden = int(out_channels * expansion)
+        self.conv1 = BaseConv(in_channels, hidden, 1, stride=1, act=act)
+        self.conv2 = BaseConv(hidden, out_channels, 3, stride=1, act=act)
+        self.use_add = shortcut and in_channels == out_channels
+
+    def forward(self, x):
+        y = self.conv2(self.conv1(x))
+        return y + x if self.use_add else y
+
+
+class CSPLayer(nn.Module):
+    """network_blocks.py:104-141."""
+
+    def __init__(self, in_channels, out_channels, n=1, shortcut=True, expansion=0.5, depthwise=False, act='silu'):
+        super().__init__()
+        hidden = int(out_channels * expansion)
+        self.conv1 = BaseConv(in_channels, hidden, 1, stride=1, act=act)
+        self.conv2 = BaseConv(in_channels, hidden, 1, stride=1, act=act)
+        self.conv3 = BaseConv(2 * hidden, out_channels, 1, stride=1, act=act)
+        self.m = nn.Sequential(*[Bottleneck(hidden, hidden, shortcut, 1.0, depthwise, act=act) for _ in range(n)])
+
+    def forward(self, x):
+        x_1 = self.m(self.conv1(x))
+        x_2 = self.conv2(x)
+        return self.conv3(torch.cat((x_1, x_2), dim=-1))                  # channels-last: the channel axis is the last one
+
+
+def _upsample2(x: Tensor) -> Tensor:
+    """nearest-exact, scale 2 (yolo_pafpn.py:49) on a channels-last map: output pixel (y, x) <- input (y // 2, x // 2)."""
+    return x.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
+
+
+class YOLOPAFPN(nn.Module):
+    def __init__(self, depth: float = 1.0, in_stages: Tuple[int, ...] = (2, 3, 4), in_channels: Tuple[int, ...] = (256, 512, 1024),
+                 depthwise: bool = False, act: str = 'silu', compile_cfg: Optional[Dict] = None,
+                 compute_dtype: torch.dtype = torch.float32):
+        super().__init__()
+        assert len(in_stages) == len(in_channels) == 3, 'Current implementation only for 3 feature maps'
+        if depthwise:
+            raise NotImplementedError('depthwise PAFPN is not built (no shipped config enables it)')
+        self.in_features, self.in_channels, self.compute_dtype = tuple(in_stages), tuple(in_channels), compute_dtype
+        c0, c1, c2 = in_channels
+        n = round(3 * depth)
+        self.lateral_conv0 = BaseConv(c2, c1, 1, 1, act=act)
+        self.C3_p4 = CSPLayer(2 * c1, c1, n, False, depthwise=depthwise, act=act)
+        self.reduce_conv1 = BaseConv(c1, c0, 1, 1, act=act)
+        self.C3_p3 = CSPLayer(2 * c0, c0, n, False, depthwise=depthwise, act=act)
+        self.bu_conv2 = BaseConv(c0, c0, 3, 2, act=act)
+        self.C3_n3 = CSPLayer(2 * c0, c1, n, False, depthwise=depthwise, act=act)
+        self.bu_conv1 = BaseConv(c1, c1, 3, 2, act=act)
+        self.C3_n4 = CSPLayer(2 * c1, c2, n, False, depthwise=depthwise, act=act)
+
+    def forward(self, input: Dict[int, Tensor]):
+        """input[stage]: (N, C, H, W)-shaped backbone features (channels-last views are free).  Returns the three FPN maps,
+        (N, C, H, W)-shaped channels-last views like the backbone's."""
+        dt = self.compute_dtype
+        x2, x1, x0 = (input[f].permute(0, 2, 3, 1).to(dt).contiguous() for f in self.in_features)
+        fpn_out0 = self.lateral_conv0(x0)
+        f_out0 = self.C3_p4(torch.cat([_upsample2(fpn_out0), x1], -1))
+        fpn_out1 = self.reduce_conv1(f_out0)
+        pan_out2 = self.C3_p3(torch.cat([_upsample2(fpn_out1), x2], -1))
+        pan_out1 = self.C3_n3(torch.cat([self.bu_conv2(pan_out2), fpn_out1], -1))
+        pan_out0 = self.C3_n4(torch.cat([self.bu_conv1(pan_out1), fpn_out0], -1))
+        return tuple(t.permute(0, 3, 1, 2) for t in (pan_out2, pan_out1, pan_out0))
+
+
+def build_yolox_fpn(fpn_cfg, in_channels: Tuple[int, ...], compute_dtype: torch.dtype = torch.float32) -> YOLOPAFPN:
+    """Registry entry point (reference yolox_extension/models/build.py:21-29)."""
+    d = dict(fpn_cfg)
+    name = d.pop('name')
+    if name not in ('PAFPN', 'pafpn'):
+        raise NotImplementedError(name)
+    d.pop('compile', None)
+    return YOLOPAFPN(in_channels=tuple(in_channels), compute_dtype=compute_dtype, **{k: (tuple(v) if isinstance(v, list) else v) for k, v in d.items()})

@@ -1,0 +1,122 @@
+"""YOLOX PAFPN: rvt_amd.fpn on the HIP kernels (emulator build on CPU, gfx950 build on the GPU)
+and the CPU oracle, both against fixtures recorded from the unmodified reference (oracle/make_golden_fpn.py): eval-mode forward
+(running statistics), training-mode forward + backward (every parameter gradient, the input gradients, the running-statistics
+update).  fp32 bar 1e-3 of the tensor scale (the north_star tolerance); bf16 against the fp32 reference at a stated looser bound."""
+import numpy as np
+import pytest
+import torch
+
+from rvt_amd import fpn as F_
+from tests import casegen_fpn as cg
+from tests.backends import backend  # noqa: F401
+from tests.harness import load_golden
+
+
+def _rel(got, want):
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    return float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-30))
+
+
+def _check_grads(get_grad, gold, tol, what):
+    worst = 0.0
+    for k in gold:
+        if k.startswith('grad/'):
+            err = _rel(get_grad(k[5:]), gold[k])
+        elif k.startswith('gradstat/'):
+            g = np.asarray(get_grad(k[9:]), dtype=np.float64).reshape(-1)
+            err = abs(np.sqrt((g * g).sum()) - gold[k][0]) / max(gold[k][0], 1e-30)
+            samp = g[np.linspace(0, g.size - 1, 512).astype(np.int64)]
+            err = max(err, _rel(samp, gold['gradsamp/' + k[9:]]))
+        else:
+            continue
+        worst = max(worst, err)
+        assert err <= tol, f'{what}: gradient of {k.split("/", 1)[1]}: rel err {err:.3e} > {tol:.1e}'
+    return worst
+
+
+@pytest.mark.parametrize('name', list(cg.CASES))
+def test_fpn_oracle_matches_reference_golden(name):
+    """Pins oracle/fpn_oracle.py to the reference (CPU only)."""
+    from oracle import fpn_oracle as O
+    c, gold = cg.CASES[name], load_golden(name)
+    p = {k: torch.from_numpy(v) for k, v in cg.make_params(name, _shapes(name, gold)).items()}
+    xs = {s: torch.from_numpy(a) for s, a in cg.make_inputs(name).items()}
+    cots = [torch.from_numpy(a) for a in cg.make_cotangents(name)]
+    outs, _ = O.pafpn_forward(xs, p, c['depth'], training=False)
+    for i, o in enumerate(outs):
+        assert _rel(o.numpy(), gold[f'eval_out{i}']) <= 2e-4
+    pg = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and 'running' not in k else v) for k, v in p.items()}
+    xg = {s: x.clone().requires_grad_(True) for s, x in xs.items()}
+    outs, ns = O.pafpn_forward(xg, pg, c['depth'], training=True)
+    loss = sum((o * ct).sum() for o, ct in zip(outs, cots))
+    loss.backward()
+    for i, o in enumerate(outs):
+        assert _rel(o.detach().numpy(), gold[f'train_out{i}']) <= 2e-4
+    for s in (2, 3, 4):
+        assert _rel(xg[s].grad.numpy(), gold[f'dx{s}']) <= 5e-4
+    _check_grads(lambda k: pg[k].grad.numpy(), gold, 5e-4, f'oracle [{name}]')
+    for k, v in ns.items():
+        assert _rel(v.numpy(), gold['buf/' + k]) <= 2e-4, k
+
+
+def _shapes(name, gold):
+    """state_dict names + shapes of the case, from the module itself (asserted equal to the reference's by make_golden_fpn.py)."""
+    c = cg.CASES[name]
+    m = F_.YOLOPAFPN(depth=c['depth'], in_channels=c['in_channels'])
+    shapes = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+    assert [k for k, _ in shapes] == [str(n) for n in gold['names']], 'parameter / buffer names differ from the reference state_dict'
+    return shapes
+
+
+def _build(name, dev, dtype):
+    c, gold = cg.CASES[name], load_golden(name)
+    m = F_.YOLOPAFPN(depth=c['depth'], in_channels=c['in_channels'], compute_dtype=dtype)
+    sd = {k: torch.from_numpy(v) for k, v in cg.make_params(name, _shapes(name, gold)).items()}
+    r = m.load_state_dict(sd, strict=True)
+    assert not r.missing_keys and not r.unexpected_keys
+    return m.to(dev), gold
+
+
+@pytest.mark.parametrize('name,dtype,tol,gtol', [('fpn_micro', torch.float32, 1e-3, 1e-3), ('fpn_base', torch.float32, 1e-3, 1e-3),
+                                                 ('fpn_micro', torch.bfloat16, 4e-2, 6e-2), ('fpn_base', torch.bfloat16, 4e-2, 6e-2)])
+def test_fpn_hip_vs_reference_golden(backend, name, dtype, tol, gtol):
+    dev = backend
+    if name == 'fpn_base' and dev.type == 'cpu':
+        pytest.skip('RVT-Base widths: GPU only (minutes on the CPU emulator)')
+    m, gold = _build(name, dev, dtype)
+    xs = {s: torch.from_numpy(a).to(dev) for s, a in cg.make_inputs(name).items()}
+    cots = [torch.from_numpy(a).to(dev) for a in cg.make_cotangents(name)]
+    m.eval()
+    with torch.no_grad():
+        outs = m(xs)
+    for i, o in enumerate(outs):
+        assert tuple(o.shape) == tuple(gold[f'eval_out{i}'].shape)
+        err = _rel(o.float().cpu().numpy(), gold[f'eval_out{i}'])
+        assert err <= tol, f'eval forward, output {i}: rel err {err:.3e}'
+    m.train()
+    xg = {s: x.clone().requires_grad_(True) for s, x in xs.items()}
+    outs = m(xg)
+    loss = sum((o.float() * ct).sum() for o, ct in zip(outs, cots))
+    loss.backward()
+    for i, o in enumerate(outs):
+        err = _rel(o.detach().float().cpu().numpy(), gold[f'train_out{i}'])
+        assert err <= tol, f'training forward, output {i}: rel err {err:.3e}'
+    for s in (2, 3, 4):
+        err = _rel(xg[s].grad.float().cpu().numpy(), gold[f'dx{s}'])
+        assert err <= gtol, f'input gradient of stage {s}: rel err {err:.3e}'
+    grads = dict(m.named_parameters())
+    worst = _check_grads(lambda k: grads[k].grad.float().cpu().numpy(), gold, gtol, f'hip [{name}, {dtype}]')
+    for k, b in m.named_buffers():
+        if k.endswith('num_batches_tracked'):
+            assert int(b) == 1
+        else:
+            err = _rel(b.float().cpu().numpy(), gold['buf/' + k])
+            assert err <= tol, f'running statistic {k}: rel err {err:.3e}'
+    print(f'{name} {dtype}: worst gradient err {worst:.3e}')
+
+
+def test_fpn_rejects_what_is_not_built():
+    with pytest.raises(NotImplementedError):
+        F_.YOLOPAFPN(depthwise=True)
+    with pytest.raises(NotImplementedError):
+        F_.BaseConv(8, 8, 3, 1, act='relu')
