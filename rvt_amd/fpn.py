@@ -86,7 +86,9 @@ class _BaseConvFn(torch.autograd.Function):
         ds = torch.zeros(2, Cout, dtype=torch.float32, device=dev)                        # sum dz (= dbeta), sum dz * xhat (= dgamma)
         L.call('rvt_bn_act_bwd_stats', L.ptr(dy), L.ptr(y0), L.ptr(fin[2]), L.ptr(fin[3]), L.ptr(fin[0]), L.ptr(fin[1]), L.ptr(ds[0]),
                L.ptr(ds[1]), L.dtype_code(dt), rows, Cout, BN_ACT_SILU, st)
-        if ctx.sync:
+        ds_local = ds
+        if ctx.sync:                                   # the input gradient needs the GLOBAL sums; dgamma / dbeta stay this rank's share
+            ds = ds.clone()                            # (the data-parallel gradient reduction sums / averages them like every other parameter)
             _bn_reduce(ds)
         dconv = torch.empty_like(y0)
         # (the kernel divides the two sums by its `rows` argument; with synchronised statistics the divisor is the global count)
@@ -102,7 +104,7 @@ class _BaseConvFn(torch.autograd.Function):
             dwp = torch.zeros(Cout, k * k * Cin, dtype=torch.float32, device=dev)
             ops.conv_wgrad(x, dconv, dwp, k, s, pad)
             dw = weights.unpack_conv_wgrad(dwp, Cin, k).to(w.dtype)
-        return dx, dw, ds[1].to(w.dtype), ds[0].to(w.dtype), None, None, None
+        return dx, dw, ds_local[1].to(w.dtype), ds_local[0].to(w.dtype), None, None, None
 
 
 class BaseConv(nn.Module):

@@ -123,3 +123,57 @@ def test_fpn_rejects_what_is_not_built():
         F_.YOLOPAFPN(depthwise=True)
     with pytest.raises(NotImplementedError):
         F_.BaseConv(8, 8, 3, 1, act='relu')
+
+
+SYNCBN_WORKER = r'''
+# Data-parallel PAFPN: each rank holds half of the batch; the BatchNorm statistics are all-reduced (SyncBatchNorm, reference
+# train.py:133), so outputs / input gradients of the local samples and the SUM over ranks of the parameter gradients must equal the
+# single-process full-batch fixture recorded from the reference.
+import os, sys, numpy as np, torch, torch.distributed as dist
+root = sys.argv[1]
+sys.path.insert(0, root)
+from rvt_amd import _lib, tuning
+from tests.backends import emu_library
+from tests import casegen_fpn as cg
+from tests.harness import load_golden
+from tests.test_fpn import _build, _rel, _check_grads
+tuning.use(**tuning.TEST_GEOMETRY)
+_lib._install_test_library(emu_library())
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+dist.init_process_group('gloo')
+torch.set_num_threads(2)
+name = 'fpn_micro'
+m, gold = _build(name, torch.device('cpu'), torch.float32)
+xs = {s: torch.from_numpy(a)[rank:rank + 1].clone().requires_grad_(True) for s, a in cg.make_inputs(name).items()}
+cots = [torch.from_numpy(a)[rank:rank + 1] for a in cg.make_cotangents(name)]
+m.train()
+outs = m(xs)
+sum((o * ct).sum() for o, ct in zip(outs, cots)).backward()
+for i, o in enumerate(outs):
+    assert _rel(o.detach().numpy(), gold[f'train_out{i}'][rank:rank + 1]) <= 1e-3, ('out', i)
+for s in (2, 3, 4):
+    assert _rel(xs[s].grad.numpy(), gold[f'dx{s}'][rank:rank + 1]) <= 1e-3, ('dx', s)
+grads = {}
+for k, p in m.named_parameters():
+    g = p.grad.clone()
+    dist.all_reduce(g)
+    grads[k] = g.numpy()
+_check_grads(lambda k: grads[k], gold, 1e-3, 'syncbn')
+for k, b in m.named_buffers():
+    if not k.endswith('num_batches_tracked'):
+        assert _rel(b.numpy(), gold['buf/' + k]) <= 1e-3, k
+dist.destroy_process_group()
+print('OK', rank)
+'''
+
+
+def test_fpn_syncbn_world2_gloo(tmp_path):
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'w.py'
+    script.write_text(SYNCBN_WORKER)
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+                        '--master-port', '29743', str(script), root], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.count('OK') == 2, r.stdout[-2000:] + r.stderr[-3000:]

@@ -362,6 +362,13 @@ def build_recurrent_backbone(backbone_cfg):          # == the branch of INTEGRAT
         return rvt_amd.RNNDetector(backbone_cfg, compute_dtype=torch.float32)
     return reference_builder(backbone_cfg)
 detector_mod.build_recurrent_backbone = build_recurrent_backbone     # (detector.py:11 binds the name at import)
+reference_fpn_builder = detector_mod.build_yolox_fpn
+def build_yolox_fpn(fpn_cfg, in_channels):           # == the branch of INTEGRATION.md section 5 (yolox_extension/models/build.py:21-29)
+    if fpn_cfg.get('impl', 'torch') == 'mi355x':
+        from rvt_amd.fpn import build_yolox_fpn as ours
+        return ours({k: v for k, v in fpn_cfg.items() if k != 'impl'}, in_channels, compute_dtype=torch.float32)
+    return reference_fpn_builder(OmegaConf.create({k: v for k, v in fpn_cfg.items() if k != 'impl'}), in_channels)
+detector_mod.build_yolox_fpn = build_yolox_fpn
 
 def model_cfg(impl):
     return OmegaConf.create({
@@ -376,7 +383,7 @@ def model_cfg(impl):
                                              'ls_init_value': 1e-5},
                                'lstm': {'dws_conv': False, 'dws_conv_only_hidden': True, 'dws_conv_kernel_size': 3,
                                         'drop_cell_update': 0}}},
-        'fpn': {'name': 'PAFPN', 'compile': {'enable': False, 'args': {'mode': 'reduce-overhead'}}, 'depth': 0.67,
+        'fpn': {'name': 'PAFPN', 'impl': impl, 'compile': {'enable': False, 'args': {'mode': 'reduce-overhead'}}, 'depth': 0.67,
                 'in_stages': [2, 3, 4], 'depthwise': False, 'act': 'silu'},
         'head': {'name': 'YoloX', 'compile': {'enable': False, 'args': {'mode': 'reduce-overhead'}}, 'depthwise': False,
                  'act': 'silu'},
@@ -394,6 +401,7 @@ with torch.no_grad():                                # LayerScale 1e-5 would hid
             p.copy_(0.5 + torch.rand(p.shape, generator=g))
 missing = ours.load_state_dict(ref.state_dict(), strict=True)          # the WHOLE detector: backbone + FPN + head names agree
 assert not missing.missing_keys and not missing.unexpected_keys
+assert type(ours.fpn).__module__.startswith('rvt_amd'), type(ours.fpn)  # ... and OUR PAFPN (rvt_amd/fpn.py) sits between backbone and head
 assert list(ours.fpn.state_dict()) == list(ref.fpn.state_dict())      # FPN / head were built from OUR get_stage_dims / get_strides
 xs = torch.randint(0, 11, (3, 2, 20, 60, 90), generator=g, dtype=torch.uint8)
 st_r = st_o = None
@@ -409,7 +417,7 @@ with torch.no_grad():
             assert err < 1e-3, (t, s, err)
         for (ho, co), (hr, cr) in zip(st_o, st_r):
             assert (co.float() - cr).abs().max().item() <= 1e-3 * cr.abs().max().item()
-    # the reference FPN + head consume OUR features unchanged (eval: decoded predictions)
+    # OUR PAFPN (HIP kernels, eval-mode BatchNorm) + the reference head consume OUR features (eval: decoded predictions)
     out_o, _ = ours.forward_detect(backbone_features=fo)
     out_r, _ = ref.forward_detect(backbone_features=fr)
     assert out_o.shape == out_r.shape
