@@ -343,6 +343,30 @@ int rvt_bn_act_bwd_stats(const void* dy, const void* x, const float* scale, cons
 int rvt_bn_act_bwd_apply(const void* dy, const void* x, const float* scale, const float* shift, const float* mean, const float* rstd,
                          const float* dsum, const float* dxsum, void* dx, int dtype, int rows, int C, int act, void* stream);
 
+/* YOLOX head tail on [B][A][5 + num_classes] fp32 prediction tensors (rvt_amd/csrc/simota.hpp; host mirror rvt_amd/head.py).
+ * Replaces models/detection/yolox/models/yolo_head.py:236-290 (decode) and :291-606 (get_losses / get_assignments /
+ * simota_matching: the per-image Python loop with its int(nlabel[b]) / .item() host syncs and per-ground-truth topk) by a fixed
+ * sequence of launches with no host synchronisation.  Anchors are ordered level by level, row-major inside a level.
+ *   rvt_yolox_decode:     one FPN level.  reg_obj [B*H*W][ld_ro] (columns 0-3 box regression, 4 objectness logit) and
+ *                         cls [B*H*W][ld_cls] (class logits) of `dtype` -> rows anchor_offset.. of pred_train (decoded cx cy w h,
+ *                         raw logits; NULL = skip) and pred_infer (decoded box, sigmoid scores; NULL = skip), both [B][A][5+nc].
+ *   rvt_yolox_decode_bwd: d_reg_obj / d_cls = gradient of pred_train's rows of this level, columns scaled by
+ *                         col_scale[0] (box) / [1] (objectness) / [2] (class) read from DEVICE memory; padding columns zeroed.
+ *   rvt_simota_loss:      labels [B][G][5] fp32 rows (class, cx, cy, w, h), zero rows = padding AFTER the real ones (:309).
+ *                         losses[5] (device) = loss, 5 * iou loss, objectness loss, class loss, num_fg / max(num_gts, 1);
+ *                         g_pred (NULL = skip) = d(sum iou) / d box, d(sum obj) / d objectness, d(sum cls) / d class, each divided
+ *                         by max(num_fg, 1): the caller scales the three column groups (5 * dloss + d(iou loss) ...);
+ *                         match_out [B][A] (NULL = skip) = matched ground-truth row or -1, piou_out [B][A] = IoU with it.
+ *                         use_l1 (an option no RVT config turns on) is not implemented. */
+int rvt_yolox_decode(const void* reg_obj, const void* cls, int ld_ro, int ld_cls, int dtype, int B, int H, int W, int stride,
+                     int num_classes, int anchor_offset, int A, float* pred_train, float* pred_infer, void* stream);
+int rvt_yolox_decode_bwd(const float* g_pred, const float* pred_train, const float* col_scale, void* d_reg_obj, void* d_cls, int ld_ro,
+                         int ld_cls, int dtype, int B, int H, int W, int stride, int num_classes, int anchor_offset, int A, void* stream);
+size_t rvt_simota_ws_bytes(int B, int G, int A);
+int rvt_simota_loss(const float* pred_train, const float* labels, const int* level_hw, const int* level_stride, int L, int B, int G, int A,
+                    int num_classes, float* losses, float* g_pred, int* match_out, float* piou_out, void* ws, size_t ws_bytes,
+                    void* stream);
+
 /* Zero state rows of samples with mask[b] != 0 (modules/utils/detection.py:96-113).
  * st is [B][per_sample] of float32 (is_f32) or `dtype`. */
 int rvt_state_reset_masked(void* st, const unsigned char* mask, int dtype, int B, size_t per_sample, void* stream);

@@ -66,13 +66,16 @@ _SIGS = {
     'rvt_bn_act_fwd': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     'rvt_bn_act_bwd_stats': [_vp] * 8 + [_i, _i, _i, _i, _vp],
     'rvt_bn_act_bwd_apply': [_vp] * 9 + [_i, _i, _i, _i, _vp],
+    'rvt_yolox_decode': [_vp, _vp] + [_i] * 10 + [_vp, _vp, _vp],
+    'rvt_yolox_decode_bwd': [_vp] * 5 + [_i] * 10 + [_vp],
+    'rvt_simota_loss': [_vp] * 4 + [_i] * 5 + [_vp] * 5 + [ctypes.c_size_t, _vp],
 }
 EXPORTS = sorted(list(_SIGS) + ['rvt_last_error', 'rvt_is_emulator', 'rvt_wgrad_workspace_floats',
                                'rvt_mlp_fused_supported', 'rvt_lstm_scan_supported', 'rvt_mlp_bwd_fused_supported',
                                'rvt_mlp_bwd_fused_ws_floats', 'rvt_attn_block_supported', 'rvt_lstm_scan_bwd_ws_floats',
                                'rvt_lstm_scan_saves_gates', 'rvt_stem_supported', 'rvt_stem_wgrad_ws_floats', 'rvt_conv_dgrad4_supported',
                                'rvt_linear_dgrad_ln_supported', 'rvt_tuning_defaults', 'rvt_get_tuning', 'rvt_set_tuning', 'rvt_probe_mfma',
-                               'rvt_stage_seq_fwd', 'rvt_stage_seq_fwd_ws_bytes'])
+                               'rvt_stage_seq_fwd', 'rvt_stage_seq_fwd_ws_bytes', 'rvt_simota_ws_bytes'])
 
 
 def _bind(lib: ctypes.CDLL) -> ctypes.CDLL:
@@ -108,6 +111,8 @@ def _bind(lib: ctypes.CDLL) -> ctypes.CDLL:
     lib.rvt_stem_wgrad_ws_floats.argtypes = [_i] * 4
     lib.rvt_wgrad_workspace_floats.restype = ctypes.c_size_t
     lib.rvt_wgrad_workspace_floats.argtypes = [_i, _i, _i, _i, _i]
+    lib.rvt_simota_ws_bytes.restype = ctypes.c_size_t
+    lib.rvt_simota_ws_bytes.argtypes = [_i, _i, _i]
     lib.rvt_probe_mfma.restype = ctypes.c_double
     lib.rvt_probe_mfma.argtypes = [_vp, _i, _i, _vp]
     lib.rvt_tuning_defaults.restype = None

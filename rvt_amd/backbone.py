@@ -266,6 +266,7 @@ class RNNDetector(nn.Module):
             inp = Hall[1:].reshape(T * B, g.H, g.W, g.C)
             feats[si + 1] = Hall[1:].permute(0, 1, 4, 2, 3)
             states.append((feats[si + 1][-1].clone(memory_format=torch.preserve_format), c_last.permute(0, 3, 1, 2)))
+        self._last_saved = None      # (test hook, see _BackboneSeqFn.forward: nothing is kept on this route)
         return feats, states
 
     def invalidate_weight_cache(self) -> None:

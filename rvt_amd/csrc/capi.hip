@@ -1,5 +1,5 @@
 // Unity translation unit of the C ABI (include/rvt_hip.h): the CPU SIMT-emulator build (tests/emu/build_emu.sh) compiles
-// this one file; the gfx950 build (build.sh) compiles the nine capi_*.hip parts in parallel and links them.
+// this one file; the gfx950 build (build.sh) compiles the ten capi_*.hip parts in parallel and links them.
 #include "capi_core.hip"
 #include "capi_conv.hip"
 #include "capi_linear.hip"
@@ -9,3 +9,4 @@
 #include "capi_lstm.hip"
 #include "capi_scan.hip"
 #include "capi_stage.hip"
+#include "capi_head.hip"

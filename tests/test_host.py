@@ -369,6 +369,13 @@ def build_yolox_fpn(fpn_cfg, in_channels):           # == the branch of INTEGRAT
         return ours({k: v for k, v in fpn_cfg.items() if k != 'impl'}, in_channels, compute_dtype=torch.float32)
     return reference_fpn_builder(OmegaConf.create({k: v for k, v in fpn_cfg.items() if k != 'impl'}), in_channels)
 detector_mod.build_yolox_fpn = build_yolox_fpn
+reference_head_builder = detector_mod.build_yolox_head
+def build_yolox_head(head_cfg, in_channels, strides):  # == the branch of INTEGRATION.md section 6 (yolox_extension/models/build.py:9-18)
+    if head_cfg.get('impl', 'torch') == 'mi355x':
+        from rvt_amd.head import build_yolox_head as ours
+        return ours({k: v for k, v in head_cfg.items() if k != 'impl'}, in_channels, strides, compute_dtype=torch.float32)
+    return reference_head_builder(OmegaConf.create({k: v for k, v in head_cfg.items() if k != 'impl'}), in_channels, strides)
+detector_mod.build_yolox_head = build_yolox_head
 
 def model_cfg(impl):
     return OmegaConf.create({
@@ -385,8 +392,8 @@ def model_cfg(impl):
                                         'drop_cell_update': 0}}},
         'fpn': {'name': 'PAFPN', 'impl': impl, 'compile': {'enable': False, 'args': {'mode': 'reduce-overhead'}}, 'depth': 0.67,
                 'in_stages': [2, 3, 4], 'depthwise': False, 'act': 'silu'},
-        'head': {'name': 'YoloX', 'compile': {'enable': False, 'args': {'mode': 'reduce-overhead'}}, 'depthwise': False,
-                 'act': 'silu'},
+        'head': {'name': 'YoloX', 'impl': impl, 'compile': {'enable': False, 'args': {'mode': 'reduce-overhead'}}, 'depthwise': False,
+                 'act': 'silu', 'num_classes': 3},
     })
 
 torch.manual_seed(0)
@@ -417,11 +424,30 @@ with torch.no_grad():
             assert err < 1e-3, (t, s, err)
         for (ho, co), (hr, cr) in zip(st_o, st_r):
             assert (co.float() - cr).abs().max().item() <= 1e-3 * cr.abs().max().item()
-    # OUR PAFPN (HIP kernels, eval-mode BatchNorm) + the reference head consume OUR features (eval: decoded predictions)
+    # OUR PAFPN + OUR head (HIP kernels, eval-mode BatchNorm) consume OUR features (eval: decoded predictions)
+    assert type(ours.yolox_head).__module__.startswith('rvt_amd'), type(ours.yolox_head)
     out_o, _ = ours.forward_detect(backbone_features=fo)
     out_r, _ = ref.forward_detect(backbone_features=fr)
     assert out_o.shape == out_r.shape
     assert (out_o - out_r).abs().max().item() <= 2e-3 * out_r.abs().max().item()
+# training mode through the reference detector's forward_detect: targets -> OUR batched on-device SimOTA + losses vs the reference's
+# per-image loop (yolo_head.py:291-606); same assignment, same losses, same gradient into the backbone features
+targets = torch.zeros(2, 4, 5)
+targets[0, 0] = torch.tensor([1., 30., 20., 24., 18.]); targets[0, 1] = torch.tensor([0., 70., 44., 30., 28.])
+targets[1, 0] = torch.tensor([2., 50., 30., 60., 40.])
+ref.train(); ours.train()
+fr_g = {s: v.detach().clone().requires_grad_(True) for s, v in fr.items()}
+fo_g = {s: v.detach().float().clone().requires_grad_(True) for s, v in fr.items()}       # the SAME features into both necks
+out_r, loss_r = ref.forward_detect(backbone_features=fr_g, targets=targets)
+out_o, loss_o = ours.forward_detect(backbone_features=fo_g, targets=targets)
+assert sorted(loss_o) == sorted(loss_r)
+for k in ('loss', 'iou_loss', 'conf_loss', 'cls_loss', 'num_fg'):
+    a, b = float(loss_o[k]), float(loss_r[k])
+    assert abs(a - b) <= 2e-3 * max(abs(b), 1e-6), (k, a, b)
+loss_r['loss'].backward(); loss_o['loss'].backward()
+for s in (2, 3, 4):
+    err = (fo_g[s].grad - fr_g[s].grad).abs().max().item() / fr_g[s].grad.abs().max().item()
+    assert err < 2e-3, (s, err)
 print('DROPIN OK')
 '''
 
