@@ -141,6 +141,29 @@ def model(name: str, a) -> Optional[Tuple[float, float]]:
     if name in ('rvt_token_mask_fwd', 'rvt_token_mask_bwd'):
         e, M, C = _elt(a[3]), a[4], a[5]
         return 0.0, 1.0 * M * C * e
+    # ---- detection tail (rows f2 / f3): BatchNorm + SiLU row kernels around the PAFPN / head convolutions, decode, SimOTA + losses
+    if name == 'rvt_bn_stats':                                   # one read of the conv output
+        e, rows, C = _elt(a[3]), a[4], a[5]
+        return 0.0, 1.0 * rows * C * e
+    if name == 'rvt_bn_act_fwd':                                 # read + write
+        e, rows, C = _elt(a[4]), a[5], a[6]
+        return 0.0, 2.0 * rows * C * e
+    if name == 'rvt_bn_act_bwd_stats':                           # dy and x in
+        e, rows, C = _elt(a[8]), a[9], a[10]
+        return 0.0, 2.0 * rows * C * e
+    if name == 'rvt_bn_act_bwd_apply':                           # dy and x in, dx out
+        e, rows, C = _elt(a[9]), a[10], a[11]
+        return 0.0, 3.0 * rows * C * e
+    if name == 'rvt_bn_finalize':
+        return 0.0, 40.0 * a[13]
+    if name in ('rvt_yolox_decode', 'rvt_yolox_decode_bwd'):     # the level's two prediction maps <-> [B][A][5+nc] fp32 rows
+        o = 2 if name == 'rvt_yolox_decode' else 5
+        ld_ro, ld_cls, e, B, H, W, _st, nc = a[o], a[o + 1], _elt(a[o + 2]), *a[o + 3:o + 8]
+        outs = (1 if P(12) else 0) + (1 if P(13) else 0) if name == 'rvt_yolox_decode' else 2
+        return 0.0, 1.0 * B * H * W * ((ld_ro + ld_cls) * e + outs * (5 + nc) * 4)
+    if name == 'rvt_simota_loss':                                # pred in (cost, select/resolve, loss passes), cost + IoU matrices out and back
+        L_, B, G, A, nc = a[4:9]
+        return 0.0, 3.0 * B * A * (5 + nc) * 4 + (B * A * (5 + nc) * 4 if P(10) else 0) + 4.0 * B * G * A * 4 + 6.0 * B * A * 4
     return None
 
 

@@ -84,20 +84,27 @@ bn_finalize_kernel(const float* __restrict__ sum, const float* __restrict__ sums
     }
 }
 
+// Row-streaming layout of the element-wise kernels: thread = (column group cg = tid % Gp, row lane tid / Gp), Gp = pow2 >= C / 8.
+// A thread keeps its 8 channels' coefficients in registers for the whole launch and walks rows with stride gridDim * (256 / Gp):
+// one 16-byte load / store per tensor and row, nothing else touches memory.
 template <class T>
 __global__ void __launch_bounds__(256)
 bn_act_fwd_kernel(const T* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift, T* __restrict__ y,
-                  size_t n_frag, int G, int act) {
-    for (size_t f = (size_t)blockIdx.x * 256 + threadIdx.x; f < n_frag; f += (size_t)gridDim.x * 256) {
-        const int cg = (int)(f % G);
+                  int rows, int C, int Gp, int act) {
+    const int cg = threadIdx.x % Gp, r0 = threadIdx.x / Gp, nrl = 256 / Gp;
+    if (cg * 8 >= C) return;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) { sc[i] = scale[cg * 8 + i]; sh[i] = shift[cg * 8 + i]; }
+    for (int row = blockIdx.x * nrl + r0; row < rows; row += gridDim.x * nrl) {
         float v[8], o[8];
-        frag_to_float<T>(frag_load<T>(x + f * 8), v);
+        frag_to_float<T>(frag_load<T>(x + (size_t)row * C + cg * 8), v);
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            const float z = fmaf(v[i], scale[cg * 8 + i], shift[cg * 8 + i]);
+            const float z = fmaf(v[i], sc[i], sh[i]);
             o[i] = act == BN_ACT_SILU ? silu_f(z) : z;
         }
-        frag_store<T>(y + f * 8, frag_from_float<T>(o));
+        frag_store<T>(y + (size_t)row * C + cg * 8, frag_from_float<T>(o));
     }
 }
 
@@ -107,17 +114,23 @@ bn_act_bwd_stats_kernel(const T* __restrict__ dy, const T* __restrict__ x, const
                         const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ rstd,
                         float* __restrict__ dsum, float* __restrict__ dxsum, int rows, int C, int Gp, int act) {
     float* outs[2] = {dsum, dxsum};
+    const int cg0 = threadIdx.x % Gp;
+    float sc[8], sh[8], mu[8], rs[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int c = cg0 * 8 + i < C ? cg0 * 8 + i : 0;
+        sc[i] = scale[c]; sh[i] = shift[c]; mu[i] = mean[c]; rs[i] = rstd[c];
+    }
     bn_column_reduce<T, 2>(rows, C, Gp, outs, [&](int row, int cg, float (&acc)[2][8]) {
         float v[8], d[8];
         frag_to_float<T>(frag_load<T>(x + (size_t)row * C + cg * 8), v);
         frag_to_float<T>(frag_load<T>(dy + (size_t)row * C + cg * 8), d);
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            const int c = cg * 8 + i;
-            const float z = fmaf(v[i], scale[c], shift[c]);
+            const float z = fmaf(v[i], sc[i], sh[i]);
             const float dz = act == BN_ACT_SILU ? d[i] * silu_grad_f(z) : d[i];
             acc[0][i] += dz;
-            acc[1][i] += dz * (v[i] - mean[c]) * rstd[c];
+            acc[1][i] += dz * (v[i] - mu[i]) * rs[i];
         }
     });
 }
@@ -126,22 +139,29 @@ template <class T>
 __global__ void __launch_bounds__(256)
 bn_act_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ scale,
                         const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ rstd,
-                        const float* __restrict__ dsum, const float* __restrict__ dxsum, T* __restrict__ dx, size_t n_frag, int G,
+                        const float* __restrict__ dsum, const float* __restrict__ dxsum, T* __restrict__ dx, int rows, int C, int Gp,
                         float inv_count, int act) {
-    for (size_t f = (size_t)blockIdx.x * 256 + threadIdx.x; f < n_frag; f += (size_t)gridDim.x * 256) {
-        const int cg = (int)(f % G);
+    const int cg = threadIdx.x % Gp, r0 = threadIdx.x / Gp, nrl = 256 / Gp;
+    if (cg * 8 >= C) return;
+    float sc[8], sh[8], mu[8], rs[8], k1[8], k2[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int c = cg * 8 + i;
+        sc[i] = scale[c]; sh[i] = shift[c]; mu[i] = mean[c]; rs[i] = rstd[c];
+        k1[i] = dsum[c] * inv_count; k2[i] = dxsum[c] * inv_count;
+    }
+    for (int row = blockIdx.x * nrl + r0; row < rows; row += gridDim.x * nrl) {
         float v[8], d[8], o[8];
-        frag_to_float<T>(frag_load<T>(x + f * 8), v);
-        frag_to_float<T>(frag_load<T>(dy + f * 8), d);
+        frag_to_float<T>(frag_load<T>(x + (size_t)row * C + cg * 8), v);
+        frag_to_float<T>(frag_load<T>(dy + (size_t)row * C + cg * 8), d);
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            const int c = cg * 8 + i;
-            const float z = fmaf(v[i], scale[c], shift[c]);
+            const float z = fmaf(v[i], sc[i], sh[i]);
             const float dz = act == BN_ACT_SILU ? d[i] * silu_grad_f(z) : d[i];
-            const float xh = (v[i] - mean[c]) * rstd[c];
-            o[i] = scale[c] * (dz - dsum[c] * inv_count - xh * dxsum[c] * inv_count);       // scale = gamma * rstd
+            const float xh = (v[i] - mu[i]) * rs[i];
+            o[i] = sc[i] * (dz - k1[i] - xh * k2[i]);                                       // scale = gamma * rstd
         }
-        frag_store<T>(dx + f * 8, frag_from_float<T>(o));
+        frag_store<T>(dx + (size_t)row * C + cg * 8, frag_from_float<T>(o));
     }
 }
 

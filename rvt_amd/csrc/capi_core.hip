@@ -249,11 +249,13 @@ int rvt_bn_finalize(const float* sum, const float* sumsq, int rows, const float*
                        running_mean, running_var, mean_out, rstd_out, scale, shift, C, training);
     return check_launch("bn_finalize");
 }
+// grid of the row-streaming element-wise kernels: 256 / Gp rows per workgroup pass, ~8 passes per workgroup, at most 4096 workgroups
+static inline int bn_row_grid(int rows, int Gp) { const int nrl = 256 / Gp; return imin(4096, imax(1, (rows + nrl * 8 - 1) / (nrl * 8))); }
 int rvt_bn_act_fwd(const void* x, const float* scale, const float* shift, void* y, int dtype, int rows, int C, int act, void* stream) {
-    RVT_CHECK(C % 8 == 0 && C >= 8 && rows >= 1 && (act == 0 || act == 1), "bn_act_fwd: bad shape / activation");
-    const size_t nf = (size_t)rows * (C / 8);
-    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_act_fwd_kernel<T>), dim3(grid_for(nf, 8192)), dim3(256), 0, (hipStream_t)stream, (const T*)x, scale,
-                                             shift, (T*)y, nf, C / 8, act));
+    RVT_CHECK(C % 8 == 0 && C >= 8 && C <= 2048 && rows >= 1 && (act == 0 || act == 1), "bn_act_fwd: bad shape / activation");
+    const int Gp = pow2_ge(C / 8);
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_act_fwd_kernel<T>), dim3(bn_row_grid(rows, Gp)), dim3(256), 0, (hipStream_t)stream, (const T*)x, scale,
+                                             shift, (T*)y, rows, C, Gp, act));
     return check_launch("bn_act_fwd");
 }
 int rvt_bn_act_bwd_stats(const void* dy, const void* x, const float* scale, const float* shift, const float* mean, const float* rstd,
@@ -267,10 +269,10 @@ int rvt_bn_act_bwd_stats(const void* dy, const void* x, const float* scale, cons
 }
 int rvt_bn_act_bwd_apply(const void* dy, const void* x, const float* scale, const float* shift, const float* mean, const float* rstd,
                          const float* dsum, const float* dxsum, void* dx, int dtype, int rows, int C, int act, void* stream) {
-    RVT_CHECK(C % 8 == 0 && C >= 8 && rows >= 1, "bn_act_bwd_apply: bad shape");
-    const size_t nf = (size_t)rows * (C / 8);
-    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T>), dim3(grid_for(nf, 8192)), dim3(256), 0, (hipStream_t)stream, (const T*)dy,
-                                             (const T*)x, scale, shift, mean, rstd, dsum, dxsum, (T*)dx, nf, C / 8, 1.0f / (float)rows, act));
+    RVT_CHECK(C % 8 == 0 && C >= 8 && C <= 2048 && rows >= 1, "bn_act_bwd_apply: bad shape");
+    const int Gp = pow2_ge(C / 8);
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T>), dim3(bn_row_grid(rows, Gp)), dim3(256), 0, (hipStream_t)stream, (const T*)dy,
+                                             (const T*)x, scale, shift, mean, rstd, dsum, dxsum, (T*)dx, rows, C, Gp, 1.0f / (float)rows, act));
     return check_launch("bn_act_bwd_apply");
 }
 

@@ -93,7 +93,7 @@ int rvt_simota_loss(const float* pred_train, const float* labels, const int* lev
     if (G > 0) hipLaunchKernelGGL(simota_select_kernel, dim3(G, B), dim3(256), 0, st, w.cost, w.iou, w.nlabel, G, A, w.count, w.cand);
     hipLaunchKernelGGL(simota_resolve_kernel, ga, dim3(256), 0, st, w.cost, w.iou, w.nlabel, w.count, w.cand, G, A, match, piou, w.meta);
     hipLaunchKernelGGL(yolox_loss_kernel, ga, dim3(256), 0, st, pred_train, labels, match, piou, w.meta, G, A, num_classes, w.partial, g_pred);
-    hipLaunchKernelGGL(yolox_loss_finalize_kernel, dim3(1), dim3(64), 0, st, w.partial, (int)(ga.x * ga.y), w.meta, losses);
+    hipLaunchKernelGGL(yolox_loss_finalize_kernel, dim3(1), dim3(256), 0, st, w.partial, (int)(ga.x * ga.y), w.meta, losses);
     return check_launch("simota_loss");
 }
 

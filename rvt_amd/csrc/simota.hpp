@@ -318,15 +318,24 @@ yolox_loss_kernel(const float* __restrict__ pred, const float* __restrict__ labe
 }
 
 // losses[0..4] = loss, 5 * iou loss, objectness loss, class loss, num_fg / max(num_gts, 1)   (yolo_head.py:432-443)
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 yolox_loss_finalize_kernel(const float* __restrict__ partial, int nblk, const int* __restrict__ meta, float* __restrict__ losses) {
+    __shared__ double red[3][256];                               // fixed summation order: bit-reproducible from run to run
+    double s[3] = {0.0, 0.0, 0.0};
+    for (int k = threadIdx.x; k < nblk; k += 256)
+        for (int i = 0; i < 3; i++) s[i] += (double)partial[(size_t)k * 3 + i];
+    for (int i = 0; i < 3; i++) red[i][threadIdx.x] = s[i];
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w)
+            for (int i = 0; i < 3; i++) red[i][threadIdx.x] += red[i][threadIdx.x + w];
+        __syncthreads();
+    }
     if (threadIdx.x != 0) return;
     const float nf = (float)(meta[1] > 1 ? meta[1] : 1);
     float v[3];
     for (int i = 0; i < 3; i++) {
-        double s = 0.0;
-        for (int k = 0; k < nblk; k++) s += (double)partial[(size_t)k * 3 + i];
-        v[i] = (float)s / nf * (i == 0 ? 5.0f : 1.0f);
+        v[i] = (float)red[i][0] / nf * (i == 0 ? 5.0f : 1.0f);
         losses[1 + i] = v[i];
     }
     losses[0] = v[0] + v[1] + v[2];

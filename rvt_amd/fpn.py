@@ -43,12 +43,14 @@ class _BaseConvFn(torch.autograd.Function):
         dt, dev = x.dtype, x.device
         N, H, W, Cin = x.shape
         Cout, k, s, pad = mod.out_channels, mod.ksize, mod.stride, mod.pad
-        wp = weights.pack_conv_fwd(w.detach(), Cin, dt)                                  # [Cout][k*k*Cin] tap-major
+        pk = mod._pk if mod._pk is not None and mod._pk.dtype == dt and mod._pk.cin == Cin else None
+        wp = pk.wp if pk is not None else weights.pack_conv_fwd(w.detach(), Cin, dt)      # [Cout][k*k*Cin] tap-major
         y0 = ops.conv_fwd(x, wp, k, s, pad)                                               # network_blocks.py:37-45 (bias=False)
         rows = y0.numel() // Cout
         f32 = torch.float32
         st = L.stream_of(y0)
-        stats = torch.zeros(2, Cout, dtype=f32, device=dev)
+        stats = pk.stats if pk is not None and training else torch.zeros(2, Cout, dtype=f32, device=dev)   # (the pack zeroes its arena once per forward)
+        ctx.pk = pk
         count = rows
         if training:
             L.call('rvt_bn_stats', L.ptr(y0), L.ptr(stats[0]), L.ptr(stats[1]), L.dtype_code(dt), rows, Cout, st)
@@ -97,11 +99,11 @@ class _BaseConvFn(torch.autograd.Function):
                L.ptr(dsk[1]), L.ptr(dconv), L.dtype_code(dt), rows, Cout, BN_ACT_SILU, st)
         dx = None
         if ctx.needs_input_grad[0]:
-            wd = weights.pack_conv_dgrad(w.detach(), s, pad, dt)
+            wd = ctx.pk.wd if ctx.pk is not None else weights.pack_conv_dgrad(w.detach(), s, pad, dt)
             dx = ops.conv_dgrad(dconv, wd, None, H, W, Cin, k, s, pad)
         dw = None
         if ctx.needs_input_grad[1]:
-            dwp = torch.zeros(Cout, k * k * Cin, dtype=torch.float32, device=dev)
+            dwp = ctx.pk.dwp.zero_() if ctx.pk is not None else torch.zeros(Cout, k * k * Cin, dtype=torch.float32, device=dev)
             ops.conv_wgrad(x, dconv, dwp, k, s, pad)
             dw = weights.unpack_conv_wgrad(dwp, Cin, k).to(w.dtype)
         return dx, dw, ds_local[1].to(w.dtype), ds_local[0].to(w.dtype), None, None, None
@@ -118,10 +120,84 @@ class BaseConv(nn.Module):
         self.in_channels, self.out_channels, self.ksize, self.stride, self.pad = in_channels, out_channels, ksize, stride, (ksize - 1) // 2
         self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=ksize, stride=stride, padding=self.pad, groups=1, bias=False)
         self.bn = nn.BatchNorm2d(out_channels)
+        self._pk = None                                 # kernel-side weight views, set by the owning module's ConvPack (None: packed per call)
 
     def forward(self, x: Tensor) -> Tensor:
         """x: channels-last (N, H, W, Cin) in the compute dtype."""
         return _BaseConvFn.apply(x.contiguous(), self.conv.weight, self.bn.weight, self.bn.bias, self, self.training, self.training)
+
+
+class _Packed:
+    __slots__ = ('wp', 'wd', 'stats', 'dwp', 'dtype', 'cin')
+
+
+class ConvPack:
+    """Kernel-side weight layouts of EVERY BaseConv below a module in two flat buffers, refreshed by ONE rvt_pack_table launch per
+    forward (training) or per parameter change (eval) — the same descriptor-table mechanism as the backbone's ModelWeights
+    (rvt_amd/weights.py): tap-major forward weights, stride-parity input-gradient panels, plus the BatchNorm statistics and raw
+    weight-gradient scratch, instead of ~10 small torch launches per convolution and step."""
+
+    def __init__(self, root: nn.Module):
+        self.convs = [m for m in root.modules() if isinstance(m, BaseConv)]
+        self.sig = None
+        self.versions = None
+
+    def refresh(self, dtype: torch.dtype, training: bool) -> None:
+        ps = [c.conv.weight for c in self.convs]
+        if not ps or any(p.dtype != torch.float32 or not p.is_contiguous() or c.in_channels % 8 for p, c in zip(ps, self.convs)):
+            for c in self.convs:
+                c._pk = None
+            return
+        sig = (dtype, tuple((p.data_ptr(), p.device) for p in ps))
+        if sig != self.sig:
+            self._build(dtype, ps[0].device)
+            self.sig, self.versions = sig, None
+        ver = tuple(p._version for p in ps)
+        if training or ver != self.versions:             # (optimizers may write through .data without bumping _version: training re-packs)
+            L.call('rvt_pack_table', L.ptr(self.table.dev), len(self.table), self.table.blocks, L.dtype_code(dtype), L.stream_of(self.bufT))
+            self.versions = ver
+        if training:
+            self.stats_all.zero_()
+
+    def _build(self, dtype: torch.dtype, dev) -> None:
+        arT, ar32 = weights._Arena(), weights._Arena()
+        for second in (False, True):
+            if second:
+                arT.buf = torch.empty(max(arT.n, 64), dtype=dtype, device=dev)
+                ar32.buf = torch.zeros(max(ar32.n, 64), dtype=torch.float32, device=dev)
+                n_stats = ar32_stats
+                arT.n = ar32.n = 0
+            tab = weights._Table(weights.PACK_DT, 1024)
+            for c in self.convs:                         # statistics first: one contiguous region to zero per forward
+                st = ar32.take(2, c.out_channels)
+                if second:
+                    c._pk = _Packed()
+                    c._pk.stats, c._pk.dtype, c._pk.cin = st, dtype, c.in_channels
+            ar32_stats = ar32.n
+            for c in self.convs:
+                Cout, Cin, k, s, pad = c.out_channels, c.in_channels, c.ksize, c.stride, c.pad
+                w = c.conv.weight.detach()
+                wp = arT.take(Cout, k * k * Cin)
+                parts, total = [], 0
+                for py in range(s):
+                    for px in range(s):
+                        ky, kx = weights.conv_dgrad_taps(k, s, pad, py), weights.conv_dgrad_taps(k, s, pad, px)
+                        parts.append((ky, kx, Cin * len(ky) * len(kx) * Cout))
+                        total += parts[-1][2]
+                wd = arT.take(total)
+                dwp = ar32.take(Cout, k * k * Cin)
+                if second:
+                    weights._pack_entry(tab, w, wp, weights.PACK_CONV_FWD, (Cout, Cin, k, Cin))
+                    off = 0
+                    for ky, kx, cnt in parts:
+                        if cnt:
+                            weights._pack_entry(tab, w, wd[off:off + cnt], weights.PACK_CONV_DGRAD, (Cout, Cin, k, len(ky), len(kx)), None, ky, kx, n=cnt)
+                        off += cnt
+                    c._pk.wp, c._pk.wd, c._pk.dwp = wp, wd, dwp
+        self.bufT, self.buf32 = arT.buf, ar32.buf
+        self.stats_all = ar32.buf[:n_stats]
+        tab.upload(dev)
+        self.table = tab
 
 
 class Bottleneck(nn.Module):
@@ -157,8 +233,10 @@ class CSPLayer(nn.Module):
 
 
 def _upsample2(x: Tensor) -> Tensor:
-    """nearest-exact, scale 2 (yolo_pafpn.py:49) on a channels-last map: output pixel (y, x) <- input (y // 2, x // 2)."""
-    return x.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
+    """nearest-exact, scale 2 (yolo_pafpn.py:49) on a channels-last map: output pixel (y, x) <- input (y // 2, x // 2).
+    One broadcast copy forward, one 2 x 2 sum backward."""
+    N, H, W, C = x.shape
+    return x[:, :, None, :, None, :].expand(N, H, 2, W, 2, C).reshape(N, 2 * H, 2 * W, C)
 
 
 class YOLOPAFPN(nn.Module):
@@ -180,11 +258,13 @@ class YOLOPAFPN(nn.Module):
         self.C3_n3 = CSPLayer(2 * c0, c1, n, False, depthwise=depthwise, act=act)
         self.bu_conv1 = BaseConv(c1, c1, 3, 2, act=act)
         self.C3_n4 = CSPLayer(2 * c1, c2, n, False, depthwise=depthwise, act=act)
+        self._pack = ConvPack(self)
 
     def forward(self, input: Dict[int, Tensor]):
         """input[stage]: (N, C, H, W)-shaped backbone features (channels-last views are free).  Returns the three FPN maps,
         (N, C, H, W)-shaped channels-last views like the backbone's."""
         dt = self.compute_dtype
+        self._pack.refresh(dt, self.training)
         x2, x1, x0 = (input[f].permute(0, 2, 3, 1).to(dt).contiguous() for f in self.in_features)
         fpn_out0 = self.lateral_conv0(x0)
         f_out0 = self.C3_p4(torch.cat([_upsample2(fpn_out0), x1], -1))

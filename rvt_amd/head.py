@@ -32,7 +32,7 @@ import torch.nn as nn
 
 from . import _lib as L
 from . import ops
-from .fpn import BaseConv
+from .fpn import BaseConv, ConvPack
 
 Tensor = torch.Tensor
 
@@ -175,6 +175,7 @@ class YOLOXHead(nn.Module):
             self.reg_preds.append(nn.Conv2d(hidden, 4, 1, 1, 0))
             self.obj_preds.append(nn.Conv2d(hidden, 1, 1, 1, 0))
         self.initialize_biases(prior_prob=0.01)
+        self._pack = ConvPack(self)
 
     def initialize_biases(self, prior_prob: float) -> None:
         """Focal-loss prior on the class and objectness biases (yolo_head.py:155-165)."""
@@ -185,6 +186,7 @@ class YOLOXHead(nn.Module):
 
     def _pred_maps(self, xin: Sequence[Tensor]):
         dt, nc, hid = self.compute_dtype, self.num_classes, self.hidden_dim
+        self._pack.refresh(dt, self.training)
         maps, hws = [], []
         for k, x in enumerate(xin):
             x = x.permute(0, 2, 3, 1).to(dt).contiguous()                 # channels-last (free for the FPN's own outputs)

@@ -229,3 +229,48 @@ def test_production_route_bf16_whole_tensors_vs_fp32_path(production_route, name
     bounds = dict(feat_l2=1.3e-2, feat_max=3.6e-2, cell_l2=1.25e-2, cell_max=1.8e-2, grad_l2=2.5e-2, grad_max=3.4e-2)
     for k, v in worst.items():
         assert v <= bounds[k], f'{name}: {k} = {v:.3e} > {bounds[k]:.1e}'
+
+
+# ---- detection tail (rows f2 / f3) on the production route: the golden cases again with the library-default launch geometry, and
+# the 1 Mpx tail at the micro-benchmark's size (N = 48 frames, A = 5040) against the CPU oracle on the head's own prediction maps
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['fpn_base', 'head_base'])
+def test_detection_tail_goldens_on_production_route(production_route, name):
+    from tests import test_fpn, test_head
+    dev = torch.device('cuda', 0)
+    if name.startswith('fpn'):
+        test_fpn.test_fpn_hip_vs_reference_golden(dev, name, torch.float32, 1e-3, 1e-3)
+    else:
+        test_head.test_head_fp32_vs_reference_golden(dev, name)
+
+
+@pytest.mark.gpu
+def test_simota_tail_at_1mpx_batch_vs_oracle(production_route):
+    """N = 48 frames of 384x640 (A = 5040 anchors), up to 16 boxes each, bf16 prediction maps: assignment bit-exact, losses 1e-4
+    against oracle/head_oracle.py (pinned to the reference by tests/test_head.py) run on the same maps."""
+    from oracle import head_oracle as O
+    from rvt_amd import head as H_
+    dev = torch.device('cuda', 0)
+    N, G, nc, hws, strides = 48, 16, 3, ((48, 80), (24, 40), (12, 20)), (8, 16, 32)
+    g = torch.Generator().manual_seed(7)
+    labels = torch.zeros(N, G, 5)
+    for b in range(N):
+        n = int(torch.randint(0, G + 1, (1,), generator=g))
+        r = torch.rand(n, 5, generator=g)
+        labels[b, :n] = torch.stack([(r[:, 0] * nc).floor(), 20 + r[:, 1] * 600, 20 + r[:, 2] * 344, 16 + r[:, 3] * 200, 16 + r[:, 4] * 150], 1)
+    maps = []
+    for (h, w) in hws:
+        ro = torch.zeros(N, h, w, 8)
+        ro[..., :5] = torch.randn(N, h, w, 5, generator=g) * torch.tensor([0.5, 0.5, 0.8, 0.8, 2.0])
+        ro[..., 2:4] += 1.0
+        cl = torch.zeros(N, h, w, 8)
+        cl[..., :nc] = torch.randn(N, h, w, nc, generator=g) * 2.0
+        maps += [ro.bfloat16(), cl.bfloat16()]
+    det, ls, match, piou = H_.simota_loss([m.to(dev).requires_grad_(True) for m in maps], labels.to(dev), hws, strides, nc)
+    pred = O.decode_train([m.float() for m in maps], hws, strides, nc)
+    want, wmatch, wpiou = O.head_losses(pred, labels, hws, strides, nc)
+    diff = int((match.cpu() != wmatch).sum())
+    assert diff == 0, f'{diff} of {N * 5040} anchors assigned differently from the oracle'
+    assert float((piou.cpu() - wpiou).abs().max()) <= 1e-5
+    assert float((ls.detach().cpu() - want).abs().max()) <= 1e-4 * float(want.abs().max())
+    assert float((det.cpu() - O.to_infer(pred)).abs().max()) <= 1e-3 * float(pred.abs().max())
