@@ -119,7 +119,7 @@ def traffic_lookup(workload_key, key):
         subs = ['mlpc_fwd_kernel' if shp[-1] == 64 else 'mlp_fwd_kernel', f'DF16bLi{shp[-1]}E']
     elif n == 'rvt_mlp_bwd_recompute_dgrad':
         subs = ['mlpc_bwd_dgrad_kernel']
-    elif n == 'rvt_mlp_bwd_recompute_wgrad':
+    elif n in ('rvt_mlp_bwd_recompute_wgrad', 'rvt_mlp_bwd_recompute_both'):
         subs = ['mlpc_bwd_wgrad_kernel']
     elif n == 'rvt_stem_fwd':
         subs = ['stem_fwd_kernel']

@@ -65,10 +65,11 @@ typedef struct RvtTuning {
     int route_wgrad_stream;   /* 1: weight-gradient launches on a second HIP stream */
     int lstm_scan_v2;         /* 1: bf16 C = 64 ConvLSTM scans take the T-form kernels of lstm_scan2.hpp (0: lstm_scan.hpp, A/B) */
     int route_stage_driver;   /* 1: the no-grad forward of rvt_amd takes rvt_stage_seq_fwd (one call per stage); 0: the Python host loop */
-    int route_mlp_store_pre;  /* 1: the LDS-staged fused MLP forward (C = 128) saves the pre-activation h only, not GELU(h) and GELU'(h); default 0: measured slower (GELU on load costs more than the bytes it saves, profiles/r4/microbench_mlp128.txt) */
-    int reserved[9];          /* zero */
+    int route_mlp_store_pre;
+    int route_mlp_bwd_both;       /* 1: stage-1 MLP backward = ONE launch (rvt_mlp_bwd_recompute_both) instead of dgrad + wgrad */  /* 1: the LDS-staged fused MLP forward (C = 128) saves the pre-activation h only, not GELU(h) and GELU'(h); default 0: measured slower (GELU on load costs more than the bytes it saves, profiles/r4/microbench_mlp128.txt) */
+    int reserved[8];          /* zero */
 } RvtTuning;
-#define RVT_TUNING_DEFAULTS {(int)sizeof(RvtTuning), 0, 1, 0, 512, 8192, 1, 4096, 0, 0, 0, 0, 1, 4, 0, 1, 1, 0, 0, 1, -1, 1, 1, -1, 1, 1, 0, 1, 1, 0, {0}}
+#define RVT_TUNING_DEFAULTS {(int)sizeof(RvtTuning), 0, 1, 0, 512, 8192, 1, 4096, 0, 0, 0, 0, 1, 4, 0, 1, 1, 0, 0, 1, -1, 1, 1, -1, 1, 1, 0, 1, 1, 0, 1, {0}}
 void rvt_tuning_defaults(RvtTuning* t);        /* fills *t with the production defaults */
 int rvt_get_tuning(RvtTuning* t);              /* t->struct_bytes must be set by the caller */
 int rvt_set_tuning(const RvtTuning* t);
@@ -198,6 +199,13 @@ int rvt_mlp_bwd_recompute_dgrad(const void* dxout, const void* xmid, void* dxmid
 int rvt_mlp_bwd_recompute_wgrad(const void* dxout, const void* xmid, const float* ln_w, const float* ln_b, const void* w1,
                                 const float* b1, const void* w2g_t, float* dw1, float* db1, float* s2, float* cs2, float* ws,
                                 int dtype, int M, int C, float eps, void* stream);
+/* Round 4: both of the above in ONE launch where rvt_mlp_bwd_both_supported (bf16, C = 64, RvtTuning.route_mlp_bwd_both): the
+ * weight-gradient kernel's dh tile goes through LDS to two rotating waves that form dh W1, and the LayerNorm backward + residual
+ * runs in the staging role of all threads — one recompute of fc1 / GELU / GELU' and one read of xmid / dxout instead of two. */
+int rvt_mlp_bwd_both_supported(int dtype, int C);
+int rvt_mlp_bwd_recompute_both(const void* dxout, const void* xmid, void* dxmid, const float* ln_w, const float* ln_b, const void* w1,
+                               const float* b1, const void* w2g_t, const void* w1_t, float* dln_w, float* dln_b, float* dw1, float* db1,
+                               float* s2, float* cs2, float* ws, int dtype, int M, int C, float eps, void* stream);
 
 /* Partitioned multi-head attention core (maxvit.py:252-265,273-304,343-354 minus the two linears):
  * qkv [F*H*W][3C] in image token order, per-head layout [q|k|v]; out [F*H*W][C].  window=1: ph x pw

@@ -94,6 +94,9 @@ def model(name: str, a) -> Optional[Tuple[float, float]]:
     if name == 'rvt_mlp_bwd_recompute_wgrad':            # recompute fc1 (8) + fc2 dgrad for dh (8) + both weight gradients (16)
         e, M, C = _elt(a[12]), a[13], a[14]
         return 32.0 * M * C * C, 2.0 * M * C * e + 8.0 * C * C * (e + 4)
+    if name == 'rvt_mlp_bwd_recompute_both':             # recompute fc1 (8) + fc2 dgrad for dh (8) + both weight gradients (16) + fc1 dgrad (8)
+        e, M, C = _elt(a[16]), a[17], a[18]
+        return 40.0 * M * C * C, 3.0 * M * C * e + 8.0 * C * C * (e + 4)
     if name == 'rvt_attn_fwd':
         e, F, H, W, C, dh, ph, pw = _elt(a[2]), *a[3:10]
         M, L = F * H * W, ph * pw

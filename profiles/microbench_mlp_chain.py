@@ -33,5 +33,7 @@ dlw, dlb, dw1, db1, s2, cs2 = z(C), z(C), z(4 * C, C), z(4 * C), z(C, 4 * C), z(
 t_f = timeit(lambda: ops.mlp_fwd(x, lw, lb, w1, b1, w2, b2, gam, 1e-5, want_grad=False))
 t_d = timeit(lambda: ops.mlp_bwd_recompute_dgrad(dy, x, lw, lb, w1, b1, w2gt, w1t, dlw, dlb, 1e-5))
 t_w = timeit(lambda: ops.mlp_bwd_recompute_wgrad(dy, x, lw, lb, w1, b1, w2gt, dw1, db1, s2, cs2, 1e-5))
+t_b = timeit(lambda: ops.mlp_bwd_recompute_both(dy, x, lw, lb, w1, b1, w2gt, w1t, dlw, dlb, dw1, db1, s2, cs2, 1e-5)) if ops.mlp_bwd_both_supported(x.dtype, C) else float('nan')
+print(f'   one-launch backward (rvt_mlp_bwd_recompute_both): {t_b:.3f} ms against {t_d + t_w:.3f} ms for dgrad + wgrad', flush=True)
 print(f'RVT_MLP_CHAIN={os.environ.get("RVT_MLP_CHAIN", "1")} C={C} M={M}: fwd (nothing saved) {t_f:.3f} ms | bwd dgrad {t_d:.3f} ms | '
       f'bwd wgrad {t_w:.3f} ms', flush=True)

@@ -58,6 +58,7 @@ _SIGS = {
     'rvt_pack_table': [_vp, _i, _i, _i, _vp],
     'rvt_mlp_bwd_recompute_dgrad': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
     'rvt_mlp_bwd_recompute_wgrad': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
+    'rvt_mlp_bwd_recompute_both': [_vp] * 16 + [_i, _i, _i, _f, _vp],
     'rvt_lstm_scan_fwd': [_vp] * 8 + [_i, _i, _i, _i, _vp],
     'rvt_lstm_scan_bwd': [_vp] * 17 + [_i, _i, _i, _i, _vp],
     'rvt_layerscale_grad_table': [_vp, _i, _i, _vp],
@@ -75,7 +76,7 @@ EXPORTS = sorted(list(_SIGS) + ['rvt_last_error', 'rvt_is_emulator', 'rvt_wgrad_
                                'rvt_mlp_bwd_fused_ws_floats', 'rvt_attn_block_supported', 'rvt_lstm_scan_bwd_ws_floats',
                                'rvt_lstm_scan_saves_gates', 'rvt_stem_supported', 'rvt_stem_wgrad_ws_floats', 'rvt_conv_dgrad4_supported',
                                'rvt_linear_dgrad_ln_supported', 'rvt_tuning_defaults', 'rvt_get_tuning', 'rvt_set_tuning', 'rvt_probe_mfma',
-                               'rvt_stage_seq_fwd', 'rvt_stage_seq_fwd_ws_bytes', 'rvt_simota_ws_bytes'])
+                               'rvt_stage_seq_fwd', 'rvt_stage_seq_fwd_ws_bytes', 'rvt_simota_ws_bytes', 'rvt_mlp_bwd_both_supported'])
 
 
 def _bind(lib: ctypes.CDLL) -> ctypes.CDLL:
@@ -91,6 +92,8 @@ def _bind(lib: ctypes.CDLL) -> ctypes.CDLL:
     lib.rvt_mlp_fused_supported.argtypes = [_i, _i]
     lib.rvt_mlp_bwd_fused_supported.restype = ctypes.c_int
     lib.rvt_mlp_bwd_fused_supported.argtypes = [_i, _i]
+    lib.rvt_mlp_bwd_both_supported.restype = ctypes.c_int
+    lib.rvt_mlp_bwd_both_supported.argtypes = [_i, _i]
     lib.rvt_mlp_bwd_fused_ws_floats.restype = ctypes.c_size_t
     lib.rvt_mlp_bwd_fused_ws_floats.argtypes = [_i, _i, _i]
     lib.rvt_lstm_scan_bwd_ws_floats.restype = ctypes.c_size_t

@@ -181,8 +181,9 @@ int rvt_mlp_bwd_recompute_wgrad(const void* dxout, const void* xmid, const float
     const int chain_wgrad = tuning().mlp_chain_wgrad;
     if (chain_wgrad && dtype == RVT_BF16 && mlp_chain_on(dtype, C)) {
         grid = one_per_cu_grid((M + 31) / 32);          // one workgroup per CU (tests: tuning.one_per_cu_grid)
-        hipLaunchKernelGGL(mlpc_bwd_wgrad_kernel, dim3(grid), dim3(512), 0, st, (const bf16*)dxout, (const bf16*)xmid, ln_w, ln_b,
-                           (const bf16*)w1, b1, (const bf16*)w2g_t, ws, M, eps);
+        hipLaunchKernelGGL(mlpc_bwd_wgrad_kernel<false>, dim3(grid), dim3(512), 0, st, (const bf16*)dxout, (const bf16*)xmid, ln_w, ln_b,
+                           (const bf16*)w1, b1, (const bf16*)w2g_t, ws, M, eps, (const bf16*)nullptr, (bf16*)nullptr, (float*)nullptr,
+                           (float*)nullptr);
         mlp_fold_partials(ws, grid, C, dw1, db1, s2, cs2, st);
         return check_launch("mlp_bwd_recompute_wgrad(chain)");
     }
@@ -194,6 +195,24 @@ int rvt_mlp_bwd_recompute_wgrad(const void* dxout, const void* xmid, const float
     });
     mlp_fold_partials(ws, grid, C, dw1, db1, s2, cs2, st);
     return check_launch("mlp_bwd_recompute_wgrad");
+}
+
+// Both halves of the recompute backward in ONE launch (mlp_chain.hpp, mlpc_bwd_wgrad_kernel<true>): one recompute of fc1 / GELU /
+// GELU', one read of xmid / dxout for the weight gradients AND the input gradient.
+int rvt_mlp_bwd_both_supported(int dtype, int C) {
+    return tuning().route_mlp_bwd_both != 0 && tuning().mlp_chain_wgrad != 0 && dtype == RVT_BF16 && C == 64 && mlp_chain_on(dtype, C);
+}
+int rvt_mlp_bwd_recompute_both(const void* dxout, const void* xmid, void* dxmid, const float* ln_w, const float* ln_b, const void* w1,
+                               const float* b1, const void* w2g_t, const void* w1_t, float* dln_w, float* dln_b, float* dw1, float* db1,
+                               float* s2, float* cs2, float* ws, int dtype, int M, int C, float eps, void* stream) {
+    RVT_CHECK(rvt_mlp_bwd_both_supported(dtype, C), "mlp_bwd_recompute_both: not built for dtype=%d C=%d (or routed off)", dtype, C);
+    RVT_CHECK(ws && dxmid && w1_t && dln_w && dln_b && M >= 1, "mlp_bwd_recompute_both: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = one_per_cu_grid((M + 31) / 32);
+    hipLaunchKernelGGL(mlpc_bwd_wgrad_kernel<true>, dim3(grid), dim3(512), 0, st, (const bf16*)dxout, (const bf16*)xmid, ln_w, ln_b,
+                       (const bf16*)w1, b1, (const bf16*)w2g_t, ws, M, eps, (const bf16*)w1_t, (bf16*)dxmid, dln_w, dln_b);
+    mlp_fold_partials(ws, grid, C, dw1, db1, s2, cs2, st);
+    return check_launch("mlp_bwd_recompute_both");
 }
 
 }  // extern "C"

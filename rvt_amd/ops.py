@@ -274,6 +274,23 @@ def mlp_bwd_recompute_wgrad(dxout: Tensor, xmid: Tensor, ln_w: Tensor, ln_b: Ten
            L.stream_of(xmid))
 
 
+def mlp_bwd_both_supported(dtype: torch.dtype, C: int) -> bool:
+    return bool(L.get_lib().rvt_mlp_bwd_both_supported(L.dtype_code(dtype), C))
+
+
+def mlp_bwd_recompute_both(dxout: Tensor, xmid: Tensor, ln_w: Tensor, ln_b: Tensor, w1: Tensor, b1: Tensor, w2g_t: Tensor, w1_t: Tensor,
+                           dln_w: Tensor, dln_b: Tensor, dw1: Tensor, db1: Tensor, s2: Tensor, cs2: Tensor, eps: float) -> Tensor:
+    """The whole recompute backward of the MLP half in one launch: returns dxmid; dln_w, dln_b, dw1, db1, s2 (raw), cs2 (raw) += ."""
+    C = xmid.shape[-1]
+    M = xmid.numel() // C
+    dxmid = torch.empty_like(xmid)
+    ws = _mlp_ws(xmid)
+    L.call('rvt_mlp_bwd_recompute_both', L.ptr(dxout), L.ptr(xmid), L.ptr(dxmid), L.ptr(ln_w), L.ptr(ln_b), L.ptr(w1), L.ptr(b1),
+           L.ptr(w2g_t), L.ptr(w1_t), L.ptr(dln_w), L.ptr(dln_b), L.ptr(dw1), L.ptr(db1), L.ptr(s2), L.ptr(cs2), L.ptr(ws),
+           L.dtype_code(xmid.dtype), M, C, float(eps), L.stream_of(xmid))
+    return dxmid
+
+
 def linear_dgrad(dy: Tensor, wt: Tensor, gelu_pre: Optional[Tensor] = None, add: Optional[Tensor] = None,
                  mul: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
     """dx = dy @ wt.T with wt = W^T stored [K][N] (optionally folded with LayerScale), then * gelu'(gelu_pre),

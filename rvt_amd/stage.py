@@ -350,13 +350,20 @@ def stage_seq_backward(sw: StageWeights, g: StageGeom, sv: StageSaved, dH: Optio
                 # gradients (accumulated in registers) in one kernel; nothing for the weight-gradient stream to do
                 # two launches, cut along the critical path: the input-gradient half here, the weight-gradient half (which
                 # needs all 2 x 64 x 256 accumulators) on the weight-gradient stream
-                def mlp_wgrad_fn(dx=dx, s=s, bw=bw, bp=bp):
-                    ops.mlp_bwd_recompute_wgrad(dx, s['xmid'], bw['n2_w'], bw['n2_b'], bw['fc1_w'], bw['fc1_b'],
-                                                bw['fc2_wt'], G(bp + 'mlp.net.0.0.weight'), G(bp + 'mlp.net.0.0.bias'),
-                                                G(bp + 'S2'), G(bp + 'cs2'), g.eps)
-                side.run(mlp_wgrad_fn, dx, s['xmid'])
-                dxmid = ops.mlp_bwd_recompute_dgrad(dx, s['xmid'], bw['n2_w'], bw['n2_b'], bw['fc1_w'], bw['fc1_b'],
-                                                    bw['fc2_wt'], bw['fc1_wt'], dn2w, dn2b, g.eps)
+                # (round 4: ONE launch where the library supports it — the weight-gradient kernel hands dh to two waves that form
+                # dh W1, LayerNorm backward in the staging role; otherwise)
+                if ops.mlp_bwd_both_supported(dt, C):
+                    dxmid = ops.mlp_bwd_recompute_both(dx, s['xmid'], bw['n2_w'], bw['n2_b'], bw['fc1_w'], bw['fc1_b'], bw['fc2_wt'],
+                                                       bw['fc1_wt'], dn2w, dn2b, G(bp + 'mlp.net.0.0.weight'),
+                                                       G(bp + 'mlp.net.0.0.bias'), G(bp + 'S2'), G(bp + 'cs2'), g.eps)
+                else:
+                    def mlp_wgrad_fn(dx=dx, s=s, bw=bw, bp=bp):
+                        ops.mlp_bwd_recompute_wgrad(dx, s['xmid'], bw['n2_w'], bw['n2_b'], bw['fc1_w'], bw['fc1_b'],
+                                                    bw['fc2_wt'], G(bp + 'mlp.net.0.0.weight'), G(bp + 'mlp.net.0.0.bias'),
+                                                    G(bp + 'S2'), G(bp + 'cs2'), g.eps)
+                    side.run(mlp_wgrad_fn, dx, s['xmid'])
+                    dxmid = ops.mlp_bwd_recompute_dgrad(dx, s['xmid'], bw['n2_w'], bw['n2_b'], bw['fc1_w'], bw['fc1_b'],
+                                                        bw['fc2_wt'], bw['fc1_wt'], dn2w, dn2b, g.eps)
             else:
                 def fc2_wgrad_fn(dx=dx, s=s, bp=bp):
                     ops.linear_wgrad(dx, s['hg'], G(bp + 'S2'), gelu_in=s['hpre'], colsum_out=G(bp + 'cs2'))

@@ -6,7 +6,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from rvt_amd import ops, weights
+from rvt_amd import ops, tuning, weights
 from tests.backends import backend  # noqa: F401
 
 DTYPES = [torch.float32, torch.bfloat16]
@@ -618,6 +618,51 @@ def test_mlp_bwd_recompute(backend, dt, M):
     assert torch.equal(dxm2.cpu(), dxm.cpu())
     close(dw1, 2 * w1r.grad, dt, 'mlp_bwd_fused dW1 accumulate', mult=2 * mult)
     close(cs2, 2 * f64(dy).sum(0), dt, 'mlp_bwd_fused cs2 accumulate', mult=mult)
+
+
+@pytest.mark.parametrize('M', [130, 1000, 5000])
+def test_mlp_bwd_recompute_both(backend, M):
+    """rvt_mlp_bwd_recompute_both (bf16, C = 64: weight gradients AND input gradient from one recompute, one launch) vs fp64 autograd
+    and vs the two-launch route (the input gradient passes dh W1 through a bf16 tile: close, not bit-equal)."""
+    C, dt = 64, torch.bfloat16
+    with tuning.override(route_mlp_bwd_both=1, mlp_chain_wgrad=1, mlp_chain=1):
+        if not ops.mlp_bwd_both_supported(dt, C):
+            pytest.skip('chain MLP kernels routed off on this backend')
+        x = rnd((M, C), backend, dt, 1, 1.5)
+        lw, lb = rnd((C,), backend, torch.float32, 2) * 0.3 + 1.0, rnd((C,), backend, torch.float32, 3, 0.2)
+        w1, b1 = rnd((4 * C, C), backend, dt, 4, 0.2), rnd((4 * C,), backend, torch.float32, 5, 0.2)
+        w2 = rnd((C, 4 * C), backend, dt, 6, 0.1)
+        gam = rnd((C,), backend, torch.float32, 8)
+        dy = rnd((M, C), backend, dt, 9)
+        xr = f64(x).requires_grad_(True)
+        lwr, lbr = f64(lw).requires_grad_(True), f64(lb).requires_grad_(True)
+        w1r, b1r = f64(w1).requires_grad_(True), f64(b1).requires_grad_(True)
+        g = F.gelu(F.layer_norm(xr, (C,), lwr, lbr, 1e-5) @ w1r.t() + b1r)
+        (xr + f64(gam) * (g @ f64(w2).t())).backward(f64(dy))
+        w2g_t = (f64(w2) * f64(gam)[:, None]).t().to(dt).contiguous().to(backend)
+        w1_t = f64(w1).t().to(dt).contiguous().to(backend)
+        z = lambda *s: torch.zeros(*s, device=backend)
+        dlw, dlb, dw1, db1, s2, cs2 = z(C), z(C), z(4 * C, C), z(4 * C), z(C, 4 * C), z(C)
+        dxm = ops.mlp_bwd_recompute_both(dy, x, lw, lb, w1, b1, w2g_t, w1_t, dlw, dlb, dw1, db1, s2, cs2, 1e-5)
+        close(dxm, xr.grad, dt, 'mlp_bwd_both dxmid', mult=2.0)
+        close(dlw, lwr.grad, dt, 'mlp_bwd_both dln_w', mult=4.0)
+        close(dlb, lbr.grad, dt, 'mlp_bwd_both dln_b', mult=4.0)
+        close(dw1, w1r.grad, dt, 'mlp_bwd_both dW1', mult=4.0)
+        close(db1, b1r.grad, dt, 'mlp_bwd_both db1', mult=4.0)
+        close(s2, f64(dy).t() @ g.detach(), dt, 'mlp_bwd_both S2', mult=4.0)
+        close(cs2, f64(dy).sum(0), dt, 'mlp_bwd_both cs2', mult=2.0)
+        # against the two-launch route: weight-gradient side identical (same code), input gradient within bf16 rounding
+        dlw2, dlb2, dw12, db12, s22, cs22 = z(C), z(C), z(4 * C, C), z(4 * C), z(C, 4 * C), z(C)
+        d2 = ops.mlp_bwd_recompute_dgrad(dy, x, lw, lb, w1, b1, w2g_t, w1_t, dlw2, dlb2, 1e-5)
+        ops.mlp_bwd_recompute_wgrad(dy, x, lw, lb, w1, b1, w2g_t, dw12, db12, s22, cs22, 1e-5)
+        assert torch.equal(dw1.cpu(), dw12.cpu()) and torch.equal(s2.cpu(), s22.cpu()) and torch.equal(cs2.cpu(), cs22.cpu())
+        err = (dxm.float() - d2.float()).abs().max().item() / d2.float().abs().max().item()
+        assert err <= 2e-2, err
+        # accumulation semantics and run-to-run reproducibility of the input gradient
+        dxm3 = ops.mlp_bwd_recompute_both(dy, x, lw, lb, w1, b1, w2g_t, w1_t, dlw, dlb, dw1, db1, s2, cs2, 1e-5)
+        assert torch.equal(dxm3.cpu(), dxm.cpu())
+        close(dw1, 2 * w1r.grad, dt, 'mlp_bwd_both dW1 accumulate', mult=4.0)
+        close(dlw, 2 * lwr.grad, dt, 'mlp_bwd_both dln_w accumulate', mult=4.0)
 
 
 @pytest.mark.parametrize('dt', DTYPES)
