@@ -74,18 +74,21 @@ def compare(got: Dict[str, np.ndarray], want: Dict[str, np.ndarray], rtol: float
     return worst
 
 
-def oracle_run(name: str, dtype=torch.float32, with_grads=True, with_batch2=True):
+def oracle_run(name: str, dtype=torch.float32, with_grads=True, with_batch2=True, conv_impl: str = 'im2col'):
     """Run the CPU oracle on a case; returns the summarized dict."""
     from oracle import rvt_oracle as O
     c = casegen.CASES[name]
     cfgd = casegen.case_cfg(name)
-    cfg = O.OracleCfg(**{k: (tuple(v) if isinstance(v, (list, tuple)) else v) for k, v in cfgd.items()})
+    cfg = O.OracleCfg(**{k: (tuple(v) if isinstance(v, (list, tuple)) else v) for k, v in cfgd.items()}, conv_impl=conv_impl)
     params = {k: torch.from_numpy(v).to(dtype).requires_grad_(True)
               for k, v in casegen.make_params(cfgd, seed=0, gamma=c['gamma']).items()}
     xs = torch.from_numpy(casegen.make_inputs(name))
     masks = torch.from_numpy(casegen.make_token_masks(name)) if cfgd['enable_masking'] else None
     cots = [torch.from_numpy(a).to(dtype) for a in casegen.make_cotangents(name)]
-    feats_all, states = O.sequence_forward(xs, None, params, cfg, c['in_res'], dtype, masks)
+    try:
+        feats_all, states = O.sequence_forward(xs, None, params, cfg, c['in_res'], dtype, masks)
+    finally:
+        O._ATEN[0] = False
     grads = None
     if with_grads:
         loss = sum((feats_all[t][s + 1] * cots[s][t]).sum() for t in range(c['T']) for s in range(4))
