@@ -302,7 +302,13 @@ def main():
     ap.add_argument('--stream-latency', action='store_true',
                     help='BASELINE configs[4] instead of the training step: T=1 streaming inference with persistent '
                          'ConvLSTM state, batch 64; prints per-step latency percentiles (not the headline metric)')
+    ap.add_argument('--tuning', action='append', default=[], metavar='FIELD=INT',
+                    help='experiment only: override a field of the RvtTuning record (the line then carries config.tuning_overrides)')
     args = ap.parse_args()
+    tuning_overrides = {kv.split('=')[0]: int(kv.split('=')[1]) for kv in args.tuning}
+    if tuning_overrides:
+        from rvt_amd import tuning as _tuning
+        _tuning.use(**tuning_overrides)
 
     if args.cpu_baseline_worker:
         cpu_baseline_worker(args.workload)
@@ -502,7 +508,8 @@ def main():
                        'hipgraph': graph_note, 'eager_ms_per_step': round(eager_ms, 3),
                        'host_enqueue_ms_per_step': round(1e3 * host_one_step, 2),
                        'host_ms_per_step_in_timed_region': round(1e3 * host_enqueue / args.steps, 2),
-                       'upstream_grads': 'random cotangents on stage 2-4 features of all T frames'},
+                       'upstream_grads': 'random cotangents on stage 2-4 features of all T frames',
+                       **({'tuning_overrides': tuning_overrides} if tuning_overrides else {})},
             'mfma_roofline_frac_whole_step': round(path_tflops / peak, 4),
             'algorithmic_tflops_per_gpu': round(path_tflops, 2),
             'roofline': roof,

@@ -65,8 +65,8 @@ typedef struct RvtTuning {
     int route_wgrad_stream;   /* 1: weight-gradient launches on a second HIP stream */
     int lstm_scan_v2;         /* 1: bf16 C = 64 ConvLSTM scans take the T-form kernels of lstm_scan2.hpp (0: lstm_scan.hpp, A/B) */
     int route_stage_driver;   /* 1: the no-grad forward of rvt_amd takes rvt_stage_seq_fwd (one call per stage); 0: the Python host loop */
-    int route_mlp_store_pre;
-    int route_mlp_bwd_both;       /* 1: stage-1 MLP backward = ONE launch (rvt_mlp_bwd_recompute_both) instead of dgrad + wgrad */  /* 1: the LDS-staged fused MLP forward (C = 128) saves the pre-activation h only, not GELU(h) and GELU'(h); default 0: measured slower (GELU on load costs more than the bytes it saves, profiles/r4/microbench_mlp128.txt) */
+    int route_mlp_store_pre;  /* 1: the LDS-staged fused MLP forward (C = 128) saves the pre-activation h only, not GELU(h) and GELU'(h); default 0: measured slower (GELU on load costs more than the bytes it saves, profiles/r4/microbench_mlp128.txt) */
+    int route_mlp_bwd_both;   /* 1: stage-1 MLP backward = ONE launch (rvt_mlp_bwd_recompute_both) instead of dgrad + wgrad */
     int reserved[8];          /* zero */
 } RvtTuning;
 #define RVT_TUNING_DEFAULTS {(int)sizeof(RvtTuning), 0, 1, 0, 512, 8192, 1, 4096, 0, 0, 0, 0, 1, 4, 0, 1, 1, 0, 0, 1, -1, 1, 1, -1, 1, 1, 0, 1, 1, 0, 1, {0}}
