@@ -13,6 +13,17 @@
  *   - `stream` is a hipStream_t; calls are asynchronous, allocate nothing and are graph-capturable;
  *   - return value 0 = ok, non-zero = error (message via rvt_last_error(), thread-local).
  * Channel counts must be multiples of 8; dim_head a multiple of 8 and <= 32; partition size <= 96.
+ *
+ * TWO TIERS (the operator granularity grew with the tuning history).
+ *   Integration surface — what a reference-side maintainer or a non-Python host binds:
+ *       rvt_last_error, rvt_tuning_defaults / rvt_get_tuning / rvt_set_tuning          one record of launch geometry + routing
+ *       rvt_stage_seq_fwd (+ _ws_bytes)                one call per backbone stage and sequence (no-grad forward)
+ *       rvt_stacked_histogram                          event stream -> input tensor (row f4)
+ *       rvt_yolox_decode / rvt_simota_loss (+ _ws_bytes) / rvt_yolox_decode_bwd        detection tail (row f3)
+ *       rvt_pack_table                                 all kernel-side weight layouts of a module, one launch per step
+ *   Operator level — every other entry below: one launch each, what the stage driver sequences and what the Python mirror
+ *       (rvt_amd/stage.py, the training backward) calls directly.  Stable and tested one by one (tests/test_kernels.py), but a host
+ *       that only runs the model needs none of them; the `*_supported` / `*_ws_*` queries say which fused forms exist for a shape.
  */
 #ifndef RVT_HIP_H
 #define RVT_HIP_H
