@@ -183,3 +183,49 @@ def test_head_rejects_what_is_not_built():
     m.decode_in_inference = False
     with pytest.raises(NotImplementedError):
         m.eval()([torch.zeros(1, 32, 4, 4)])
+
+
+@pytest.mark.parametrize('seed,nc,hws,strides,N,G', [
+    (0, 1, ((5, 7),), (8,), 2, 3),                                          # one level, one class
+    (1, 80, ((8, 8), (4, 4), (2, 2)), (8, 16, 32), 2, 9),                   # COCO-sized class vector (padded prediction GEMM columns)
+    (2, 3, ((16, 12), (8, 6), (4, 3), (2, 2)), (4, 8, 16, 32), 3, 40),      # four levels, more boxes than any image fills
+    (3, 2, ((3, 5), (2, 3)), (16, 32), 5, 1),                               # at most one box per image
+])
+def test_simota_tail_random_shapes_vs_oracle(backend, seed, nc, hws, strides, N, G):
+    """Shapes the reference fixtures do not cover, against oracle/head_oracle.py (pinned to the reference above): assignment exact,
+    losses and the gradient into the prediction maps within fp32 round-off."""
+    from oracle import head_oracle as O
+    dev = backend
+    g = torch.Generator().manual_seed(100 + seed)
+    Hi, Wi = hws[0][0] * strides[0], hws[0][1] * strides[0]
+    labels = torch.zeros(N, G, 5)
+    for b in range(N):
+        n = int(torch.randint(0, G + 1, (1,), generator=g))
+        r = torch.rand(n, 5, generator=g)
+        labels[b, :n] = torch.stack([(r[:, 0] * nc).floor(), 1 + r[:, 1] * (Wi - 2), 1 + r[:, 2] * (Hi - 2),
+                                     4 + r[:, 3] * 0.5 * Wi, 4 + r[:, 4] * 0.5 * Hi], 1)
+    ncp = (nc + 7) // 8 * 8
+    maps = []
+    for (h, w) in hws:
+        ro = torch.zeros(N, h, w, 8)
+        ro[..., :5] = torch.randn(N, h, w, 5, generator=g) * torch.tensor([0.5, 0.5, 0.7, 0.7, 2.0])
+        ro[..., 2:4] += 0.8
+        cl = torch.zeros(N, h, w, ncp)
+        cl[..., :nc] = torch.randn(N, h, w, nc, generator=g) * 2.0
+        maps += [ro, cl]
+    mh = [m.clone().to(dev).requires_grad_(True) for m in maps]
+    det, ls, match, piou = H_.simota_loss(mh, labels.to(dev), hws, strides, nc)
+    ls[0].backward()
+    mo = [m.clone().requires_grad_(True) for m in maps]
+    pred = O.decode_train(mo, hws, strides, nc)
+    want, wmatch, wpiou = O.head_losses(pred, labels, hws, strides, nc)
+    want[0].backward()
+    assert np.array_equal(match.cpu().numpy(), wmatch.numpy())
+    assert _rel(piou.cpu().numpy(), wpiou.numpy()) <= 1e-5 or float(wpiou.abs().max()) == 0.0
+    assert float((ls.detach().cpu() - want.detach()).abs().max()) <= 1e-5 * float(want.detach().abs().max())
+    assert _rel(det.cpu().numpy(), O.to_infer(pred).detach().numpy()) <= 1e-5
+    for a, b in zip(mh, mo):
+        if float(b.grad.abs().max()) > 0:
+            assert _rel(a.grad.cpu().numpy(), b.grad.numpy()) <= 2e-4
+        else:
+            assert float(a.grad.abs().max()) == 0.0
