@@ -521,13 +521,14 @@ mlpc_bwd_wgrad_kernel(const bf16* __restrict__ dxout, const bf16* __restrict__ x
     fetch(sa, t0 + 2 * G);
     if (DGRAD) fetch(sla, -1);
     lds_barrier();
-    int k = 0;                                      // tiles started by this workgroup
-    for (int tile = t0; tile < n_tiles + (DGRAD ? 2 * G : 0); tile += 2 * G, k += 2) {
-        if (mfma_first && tile < n_tiles) compute(0);
+    int k = 0;                                      // tile slots started by this workgroup
+    int tile = t0;
+    for (; tile < n_tiles; tile += 2 * G, k += 2) {
+        if (mfma_first) compute(0);
         stash(sb, tile + G, 1, k + 1);
         fetch(sb, tile + 3 * G);
-        if (DGRAD) fetch(slb, tile - G);          // (younger than everything this phase waits for)
-        if (!mfma_first && tile < n_tiles) compute(0);
+        if (DGRAD) fetch(slb, tile - G);            // (younger than everything this phase waits for)
+        if (!mfma_first) compute(0);
         duty(1, tile - G, k - 1);
         lnbwd(sla, 0, tile - 2 * G, k - 2);
         lds_barrier();
@@ -539,6 +540,13 @@ mlpc_bwd_wgrad_kernel(const bf16* __restrict__ dxout, const bf16* __restrict__ x
         duty(0, tile, k);
         lnbwd(slb, 1, tile - G, k - 1);
         lds_barrier();
+    }
+    if (DGRAD) {                                    // drain: the stations of the last two tile slots
+        fetch(slb, tile - G);
+        duty(1, tile - G, k - 1);
+        lnbwd(sla, 0, tile - 2 * G, k - 2);
+        lds_barrier();
+        lnbwd(slb, 1, tile - G, k - 1);
     }
     const size_t nwg = gridDim.x, wg = blockIdx.x;
     float* const p_dw1 = ws + wg * (size_t)(HID * C);
