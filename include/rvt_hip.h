@@ -352,6 +352,10 @@ int rvt_gather_frames(const void* src, const int* idx, void* dst, int n_sel, siz
  *   rvt_bn_act_fwd:        y = act(x * scale + shift)            (y may alias x)
  *   rvt_bn_act_bwd_stats:  dz = dy * act'(x * scale + shift);  dsum[C] += sum dz (= dbeta), dxsum[C] += sum dz * xhat (= dgamma)
  *   rvt_bn_act_bwd_apply:  dx = scale * (dz - dsum / rows - xhat * dxsum / rows)      (training-mode BatchNorm backward) */
+/* Inference: Conv2d(bias=False) + BatchNorm2d (running statistics) + activation in ONE launch — scale / shift from rvt_bn_finalize
+ * (training = 0) applied to the fp32 accumulator in the GEMM epilogue; act 0 = none, 1 = SiLU.  in / w / out as rvt_conv_fwd. */
+int rvt_conv_bn_act_fwd(const void* in, const void* w, const float* scale, const float* shift, void* out, int dtype, int F, int H, int W,
+                        int Cin, int Cout, int k, int stride, int pad, int act, void* stream);
 int rvt_bn_stats(const void* x, float* sum, float* sumsq, int dtype, int rows, int C, void* stream);
 int rvt_bn_finalize(const float* sum, const float* sumsq, int rows, const float* gamma, const float* beta, float eps, float momentum,
                     float* running_mean, float* running_var, float* mean_out, float* rstd_out, float* scale, float* shift, int C,

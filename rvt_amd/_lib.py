@@ -67,6 +67,7 @@ _SIGS = {
     'rvt_bn_act_fwd': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     'rvt_bn_act_bwd_stats': [_vp] * 8 + [_i, _i, _i, _i, _vp],
     'rvt_bn_act_bwd_apply': [_vp] * 9 + [_i, _i, _i, _i, _vp],
+    'rvt_conv_bn_act_fwd': [_vp] * 5 + [_i] * 10 + [_vp],
     'rvt_yolox_decode': [_vp, _vp] + [_i] * 10 + [_vp, _vp, _vp],
     'rvt_yolox_decode_bwd': [_vp] * 5 + [_i] * 10 + [_vp],
     'rvt_simota_loss': [_vp] * 4 + [_i] * 5 + [_vp] * 5 + [ctypes.c_size_t, _vp],

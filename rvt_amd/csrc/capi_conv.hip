@@ -41,6 +41,21 @@ int rvt_conv_fwd(const void* in, const void* w, void* out, int dtype, int F, int
     return check_launch("conv_fwd");
 }
 
+// inference-mode Conv2d + BatchNorm2d + SiLU in ONE launch: the BatchNorm affine (from the running statistics, rvt_bn_finalize with
+// training = 0) and the activation run in the GEMM epilogue on the fp32 accumulator
+int rvt_conv_bn_act_fwd(const void* in, const void* w, const float* scale, const float* shift, void* out, int dtype, int F, int H, int W,
+                        int Cin, int Cout, int k, int stride, int pad, int act, void* stream) {
+    RVT_CHECK(Cin % 8 == 0 && Cout % 8 == 0 && scale && shift && (act == 0 || act == 1), "conv_bn_act_fwd: channels must be multiples of 8, scale / shift required");
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_DTYPE(dtype, {
+        Im2colSrc<T> a = make_im2col<T>(in, F, H, W, Cin, k, stride, pad);
+        PlainSrc<T> b{(const T*)w, a.cols, Cout, a.cols};
+        EpAffineAct<T> ep{(T*)out, Cout, scale, shift, act};
+        DISPATCH_BN(Cout, (launch_gemm<T, BN, false>(a, XfNone(), b, XfNone(), ep, a.rows, Cout, a.cols, 1, st)));
+    });
+    return check_launch("conv_bn_act_fwd");
+}
+
 int rvt_conv_wgrad(const void* in, const void* dy, float* dw, float* ws, int dtype, int F, int H, int W, int Cin, int Cout,
                    int k, int stride, int pad, void* stream) {
     RVT_CHECK(Cin % 8 == 0 && Cout % 8 == 0, "conv_wgrad: channels must be multiples of 8");

@@ -420,6 +420,28 @@ template <class T> struct EpStore {
     }
 };
 
+// out = act(v * scale[n] + shift[n]): inference-mode BatchNorm folded behind a convolution (scale = gamma * rstd of the running
+// statistics, shift = beta - running_mean * scale) + SiLU, applied to the fp32 accumulator (YOLOX BaseConv, network_blocks.py:29-53)
+template <class T> struct EpAffineAct {
+    __device__ __forceinline__ void begin_block(int) {}
+    static constexpr int UNIT = 8;
+    struct Cols { EpColVec<8> sc, sh; };
+    typedef EpNone Aux;
+    T* out; int ld; const float* scale; const float* shift; int act;       // act: 0 none, 1 SiLU
+    __device__ __forceinline__ Cols cols(int n, bool ok) const {
+        Cols c; c.sc = ep_load_cols<8>(scale, n, ok); c.sh = ep_load_cols<8>(shift, n, ok); return c;
+    }
+    __device__ __forceinline__ Aux fetch(int, int) const { return Aux(); }
+    __device__ __forceinline__ void apply(int m, int n, float (&v)[8], const Aux&, const Cols& c) const {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const float z = fmaf(v[i], c.sc.v[i], c.sh.v[i]);
+            v[i] = act == 1 ? z * sigmoid_f(z) : z;
+        }
+        frag_store<T>(out + (size_t)m * ld + n, frag_from_float<T>(v));
+    }
+};
+
 template <class T> struct EpScaleRes {
     __device__ __forceinline__ void begin_block(int) {}         // out = res + gamma * (v + bias)     (LayerScale + residual)
     static constexpr int UNIT = 8;

@@ -44,6 +44,9 @@ class _BaseConvFn(torch.autograd.Function):
         N, H, W, Cin = x.shape
         Cout, k, s, pad = mod.out_channels, mod.ksize, mod.stride, mod.pad
         pk = mod._pk if mod._pk is not None and mod._pk.dtype == dt and mod._pk.cin == Cin else None
+        if not training and pk is not None and pk.fin is not None and not any(ctx.needs_input_grad[:4]):
+            # inference: BatchNorm (running statistics) + SiLU in the convolution's epilogue — one launch per unit
+            return ops.conv_bn_act_fwd(x, pk.wp, pk.fin[2], pk.fin[3], k, s, pad, BN_ACT_SILU)
         wp = pk.wp if pk is not None else weights.pack_conv_fwd(w.detach(), Cin, dt)      # [Cout][k*k*Cin] tap-major
         y0 = ops.conv_fwd(x, wp, k, s, pad)                                               # network_blocks.py:37-45 (bias=False)
         rows = y0.numel() // Cout
@@ -124,11 +127,16 @@ class BaseConv(nn.Module):
 
     def forward(self, x: Tensor) -> Tensor:
         """x: channels-last (N, H, W, Cin) in the compute dtype."""
+        pk = self._pk
+        if not self.training and not torch.is_grad_enabled() and pk is not None and pk.fin is not None and pk.dtype == x.dtype \
+                and pk.cin == x.shape[-1]:
+            # inference fast path: one launch, no autograd node
+            return ops.conv_bn_act_fwd(x.contiguous(), pk.wp, pk.fin[2], pk.fin[3], self.ksize, self.stride, self.pad, BN_ACT_SILU)
         return _BaseConvFn.apply(x.contiguous(), self.conv.weight, self.bn.weight, self.bn.bias, self, self.training, self.training)
 
 
 class _Packed:
-    __slots__ = ('wp', 'wd', 'stats', 'dwp', 'dtype', 'cin')
+    __slots__ = ('wp', 'wd', 'stats', 'dwp', 'dtype', 'cin', 'fin')
 
 
 class ConvPack:
@@ -158,6 +166,20 @@ class ConvPack:
             self.versions = ver
         if training:
             self.stats_all.zero_()
+            self.bn_versions = None
+            for c in self.convs:
+                c._pk.fin = None
+        else:                                            # inference: the BatchNorm affine of every unit, once per parameter / buffer change
+            bnv = tuple(t._version for c in self.convs for t in (c.bn.weight, c.bn.bias, c.bn.running_mean, c.bn.running_var))
+            if bnv != getattr(self, 'bn_versions', None) or any(c._pk.fin is None for c in self.convs):
+                for c in self.convs:
+                    bn, Cout = c.bn, c.out_channels
+                    fin = torch.empty(4, Cout, dtype=torch.float32, device=bn.weight.device)
+                    L.call('rvt_bn_finalize', None, None, 1, L.ptr(bn.weight.detach().float().contiguous()),
+                           L.ptr(bn.bias.detach().float().contiguous()), float(bn.eps), 0.0, L.ptr(bn.running_mean), L.ptr(bn.running_var),
+                           L.ptr(fin[0]), L.ptr(fin[1]), L.ptr(fin[2]), L.ptr(fin[3]), Cout, 0, L.stream_of(fin))
+                    c._pk.fin = fin
+                self.bn_versions = bnv
 
     def _build(self, dtype: torch.dtype, dev) -> None:
         arT, ar32 = weights._Arena(), weights._Arena()
@@ -172,7 +194,7 @@ class ConvPack:
                 st = ar32.take(2, c.out_channels)
                 if second:
                     c._pk = _Packed()
-                    c._pk.stats, c._pk.dtype, c._pk.cin = st, dtype, c.in_channels
+                    c._pk.stats, c._pk.dtype, c._pk.cin, c._pk.fin = st, dtype, c.in_channels, None
             ar32_stats = ar32.n
             for c in self.convs:
                 Cout, Cin, k, s, pad = c.out_channels, c.in_channels, c.ksize, c.stride, c.pad

@@ -60,6 +60,18 @@ def conv_fwd(x: Tensor, w: Tensor, k: int, stride: int, pad: int, out: Optional[
     return y
 
 
+def conv_bn_act_fwd(x: Tensor, w: Tensor, scale: Tensor, shift: Tensor, k: int, stride: int, pad: int, act: int = 1) -> Tensor:
+    """Inference-mode conv + BatchNorm affine + activation in one launch (scale / shift fp32 [Cout])."""
+    F_, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    assert w.shape[1] == k * k * Cin and w.dtype == x.dtype and scale.dtype == torch.float32 and shift.dtype == torch.float32
+    Ho, Wo = conv_out_hw(H, W, k, stride, pad)
+    y = _out(x, (F_, Ho, Wo, Cout))
+    L.call('rvt_conv_bn_act_fwd', L.ptr(x), L.ptr(w), L.ptr(scale), L.ptr(shift), L.ptr(y), L.dtype_code(x.dtype), F_, H, W, Cin, Cout,
+           k, stride, pad, act, L.stream_of(x))
+    return y
+
+
 def stem_supported(src: Tensor, dtype: torch.dtype, Cout: int, k: int, stride: int, pad: int) -> bool:
     """The stem kernels (csrc/stem.hpp) take the loader's uint8 planes; everything else goes prepack + conv + LayerNorm."""
     return bool(L.get_lib().rvt_stem_supported(L.dtype_code(dtype), int(src.dtype == torch.uint8), src.shape[1], Cout, k, stride,

@@ -177,3 +177,24 @@ def test_fpn_syncbn_world2_gloo(tmp_path):
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
                         '--master-port', '29743', str(script), root], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.count('OK') == 2, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 1e-5), (torch.bfloat16, 3e-2)])
+def test_fpn_eval_fused_conv_bn_silu_matches_unfused(backend, dtype, tol):
+    """Inference takes ONE launch per BaseConv (BatchNorm affine + SiLU in the convolution's epilogue, rvt_conv_bn_act_fwd); an input that
+    requires grad takes the three-launch route (conv, finalize, bn_act): same numbers up to the rounding of the intermediate."""
+    dev = backend
+    m, _ = _build('fpn_micro', dev, dtype)
+    m.eval()
+    xs = {s: torch.from_numpy(a).to(dev) for s, a in cg.make_inputs('fpn_micro').items()}
+    with torch.no_grad():
+        fused = m(xs)
+    assert all(c._pk is not None and c._pk.fin is not None for c in m._pack.convs)
+    unfused = m({s: x.clone().requires_grad_(True) for s, x in xs.items()})
+    for a, b in zip(fused, unfused):
+        assert _rel(a.float().cpu().numpy(), b.detach().float().cpu().numpy()) <= tol
+    # a parameter change is picked up (the cached affine is keyed on the BatchNorm tensors' versions)
+    with torch.no_grad():
+        m.lateral_conv0.bn.running_var.mul_(4.0)
+        changed = m(xs)
+    assert _rel(changed[2].float().cpu().numpy(), fused[2].float().cpu().numpy()) > 1e-3
