@@ -176,6 +176,7 @@ class YOLOXHead(nn.Module):
             self.obj_preds.append(nn.Conv2d(hidden, 1, 1, 1, 0))
         self.initialize_biases(prior_prob=0.01)
         self._pack = ConvPack(self)
+        self._pred_cache: Dict[int, tuple] = {}
 
     def initialize_biases(self, prior_prob: float) -> None:
         """Focal-loss prior on the class and objectness biases (yolo_head.py:155-165)."""
@@ -195,14 +196,36 @@ class YOLOXHead(nn.Module):
             cls_feat = self.cls_convs[k](x)
             reg_feat = self.reg_convs[k](x)
             # the three 1x1 convolutions as two 8-row-aligned GEMMs; the padding rows are constants (zero weight, zero bias)
-            w_ro = torch.cat([self.reg_preds[k].weight.reshape(4, hid), self.obj_preds[k].weight.reshape(1, hid),
-                              x.new_zeros(3, hid, dtype=self.reg_preds[k].weight.dtype)])
-            b_ro = torch.cat([self.reg_preds[k].bias, self.obj_preds[k].bias, x.new_zeros(3, dtype=self.reg_preds[k].bias.dtype)])
-            np_ = _pad8(nc)
-            w_cl = torch.cat([self.cls_preds[k].weight.reshape(nc, hid), x.new_zeros(np_ - nc, hid, dtype=self.cls_preds[k].weight.dtype)])
-            b_cl = torch.cat([self.cls_preds[k].bias, x.new_zeros(np_ - nc, dtype=self.cls_preds[k].bias.dtype)])
-            maps += [_PredFn.apply(reg_feat, w_ro, b_ro), _PredFn.apply(cls_feat, w_cl, b_cl)]
+            infer = not self.training and not torch.is_grad_enabled()
+            w_ro, b_ro, w_cl, b_cl = self._pred_weights(k, x, cache=infer)
+            if infer:                                                      # no autograd node, weights already in the compute dtype
+                maps += [ops.linear_fwd(reg_feat, w_ro, b_ro), ops.linear_fwd(cls_feat, w_cl, b_cl)]
+            else:
+                maps += [_PredFn.apply(reg_feat, w_ro, b_ro), _PredFn.apply(cls_feat, w_cl, b_cl)]
         return maps, hws
+
+    def _pred_weights(self, k: int, like: Tensor, cache: bool):
+        """[reg(4) | obj(1) | 0 0 0] and [cls(nc) | 0 ..] weight / bias blocks of level k.  Training: built per call (autograd reaches the
+        three Conv2d parameters through the concatenation); inference: cast to the compute dtype and cached per parameter version."""
+        nc, hid = self.num_classes, self.hidden_dim
+        ps = (self.reg_preds[k].weight, self.reg_preds[k].bias, self.obj_preds[k].weight, self.obj_preds[k].bias,
+              self.cls_preds[k].weight, self.cls_preds[k].bias)
+        key = (like.dtype, like.device, tuple((p.data_ptr(), p._version) for p in ps))
+        if cache:
+            hit = self._pred_cache.get(k)
+            if hit is not None and hit[0] == key:
+                return hit[1]
+        np_ = _pad8(nc)
+        w_ro = torch.cat([ps[0].reshape(4, hid), ps[2].reshape(1, hid), like.new_zeros(3, hid, dtype=ps[0].dtype)])
+        b_ro = torch.cat([ps[1], ps[3], like.new_zeros(3, dtype=ps[1].dtype)])
+        w_cl = torch.cat([ps[4].reshape(nc, hid), like.new_zeros(np_ - nc, hid, dtype=ps[4].dtype)])
+        b_cl = torch.cat([ps[5], like.new_zeros(np_ - nc, dtype=ps[5].dtype)])
+        out = (w_ro, b_ro, w_cl, b_cl)
+        if cache:
+            out = (w_ro.detach().to(like.dtype).contiguous(), b_ro.detach().float().contiguous(),
+                   w_cl.detach().to(like.dtype).contiguous(), b_cl.detach().float().contiguous())
+            self._pred_cache[k] = (key, out)
+        return out
 
     def forward(self, xin: Sequence[Tensor], labels: Optional[Tensor] = None):
         """xin: the FPN maps, (N, C, H, W)-shaped; labels (training): [B][G][5] rows (class, cx, cy, w, h), zero rows pad."""

@@ -229,3 +229,21 @@ def test_simota_tail_random_shapes_vs_oracle(backend, seed, nc, hws, strides, N,
             assert _rel(a.grad.cpu().numpy(), b.grad.numpy()) <= 2e-4
         else:
             assert float(a.grad.abs().max()) == 0.0
+
+
+def test_head_eval_caches_follow_parameter_updates(backend):
+    """Inference caches (padded prediction weights, the BatchNorm affine of every unit) are keyed on the parameters' versions."""
+    dev = backend
+    m, _ = _build('head_micro', dev, torch.float32)
+    m.eval()
+    xs = [torch.from_numpy(a).to(dev) for a in cg.make_inputs('head_micro')]
+    with torch.no_grad():
+        a, _ = m(xs)
+        b, _ = m(xs)
+        assert torch.equal(a, b)
+        m.cls_preds[0].bias.add_(1.0)
+        c, _ = m(xs)
+        assert float((c[:, :240, 5:] - a[:, :240, 5:]).abs().min()) > 0 and torch.equal(c[:, 240:], a[:, 240:])   # level 0 = the first 12 x 20 anchors
+        m.stems[2].bn.weight.mul_(0.5)
+        d, _ = m(xs)
+        assert not torch.equal(d[:, 300:], c[:, 300:]) and torch.equal(d[:, :300], c[:, :300])                     # level 2 = the last 3 x 5 anchors
