@@ -170,7 +170,7 @@ class ConvPack:
             for c in self.convs:
                 c._pk.fin = None
         else:                                            # inference: the BatchNorm affine of every unit, once per parameter / buffer change
-            bnv = tuple(t._version for c in self.convs for t in (c.bn.weight, c.bn.bias, c.bn.running_mean, c.bn.running_var))
+            bnv = tuple((t.data_ptr(), t._version) for c in self.convs for t in (c.bn.weight, c.bn.bias, c.bn.running_mean, c.bn.running_var))
             if bnv != getattr(self, 'bn_versions', None) or any(c._pk.fin is None for c in self.convs):
                 for c in self.convs:
                     bn, Cout = c.bn, c.out_channels
