@@ -271,14 +271,34 @@ def stream_latency(wl, dtype, device, args):
     gpu = sorted(x[1] for x in lat)
     host = sorted(x[2] for x in lat)
     pct = lambda a, q: a[min(len(a) - 1, int(q * len(a)))]
+    # the whole detector step (rows f2 / f3): backbone step + YOLOX PAFPN + head + decode, inference mode, random-init weights
+    from rvt_amd import fpn as _fpn, head as _head
+    dims, strides = model.get_stage_dims((2, 3, 4)), model.get_strides((2, 3, 4))
+    neck = _fpn.YOLOPAFPN(depth=0.67, in_channels=dims, compute_dtype=dtype).to(device).eval()
+    det_head = _head.YOLOXHead(num_classes=3, strides=strides, in_channels=dims, compute_dtype=dtype).to(device).eval()
+    det = []
+    with torch.no_grad():
+        for i in range(args.warmup + 3):
+            feats, states = model(frames[i % 4], states)
+            det_head(neck(feats))
+        torch.cuda.synchronize()
+        for i in range(max(args.steps, 50)):
+            t0 = time.perf_counter()
+            feats, states = model(frames[i % 4], states)
+            out, _ = det_head(neck(feats))
+            torch.cuda.synchronize()
+            det.append(1e3 * (time.perf_counter() - t0))
+    det.sort()
     print(json.dumps({'metric': 'streaming-inference step latency (T=1, persistent ConvLSTM state)', 'unit': 'ms',
                       'batch': Bs, 'dtype': args.dtype, 'config': {'workload': wl['label'].split(',')[0] + f', B={Bs}, T=1'},
                       'wall_p50': round(pct(wall, 0.5), 3), 'wall_p99': round(pct(wall, 0.99), 3),
                       'gpu_p50': round(pct(gpu, 0.5), 3), 'gpu_p99': round(pct(gpu, 0.99), 3),
                       'host_enqueue_p50': round(pct(host, 0.5), 3),
                       'mfma_frac_p50': round(Bs * wl['f_fwd'] / (pct(wall, 0.5) * 1e-3) / (PEAK_TFLOPS[args.dtype] * 1e12), 4),
-                      'event_tensors_per_s_p50': round(Bs / pct(wall, 0.5) * 1e3, 1), 'higher_is_better': False,
-                      'data': 'synthetic'}), flush=True)
+                      'event_tensors_per_s_p50': round(Bs / pct(wall, 0.5) * 1e3, 1),
+                      'detector_wall_p50': round(pct(det, 0.5), 3), 'detector_wall_p99': round(pct(det, 0.99), 3),
+                      'detector_note': 'backbone step + YOLOX PAFPN + head + decode (rvt_amd.fpn / rvt_amd.head, inference mode), same batch',
+                      'higher_is_better': False, 'data': 'synthetic'}), flush=True)
 
 
 def main():
