@@ -361,6 +361,10 @@ int rvt_bn_finalize(const float* sum, const float* sumsq, int rows, const float*
                     float* running_mean, float* running_var, float* mean_out, float* rstd_out, float* scale, float* shift, int C,
                     int training, void* stream);
 int rvt_bn_act_fwd(const void* x, const float* scale, const float* shift, void* y, int dtype, int rows, int C, int act, void* stream);
+/* rvt_bn_finalize (training) + rvt_bn_act_fwd in ONE launch: count = rows the sums cover (the global count under synchronised BatchNorm) */
+int rvt_bn_train_act_fwd(const void* x, const float* sum, const float* sumsq, int count, const float* gamma, const float* beta, float eps,
+                         float momentum, float* running_mean, float* running_var, float* mean_out, float* rstd_out, float* scale_out,
+                         float* shift_out, void* y, int dtype, int rows, int C, int act, void* stream);
 int rvt_bn_act_bwd_stats(const void* dy, const void* x, const float* scale, const float* shift, const float* mean, const float* rstd,
                          float* dsum, float* dxsum, int dtype, int rows, int C, int act, void* stream);
 int rvt_bn_act_bwd_apply(const void* dy, const void* x, const float* scale, const float* shift, const float* mean, const float* rstd,

@@ -65,6 +65,7 @@ _SIGS = {
     'rvt_bn_stats': [_vp, _vp, _vp, _i, _i, _i, _vp],
     'rvt_bn_finalize': [_vp, _vp, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     'rvt_bn_act_fwd': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    'rvt_bn_train_act_fwd': [_vp, _vp, _vp, _i, _vp, _vp, _f, _f] + [_vp] * 7 + [_i, _i, _i, _i, _vp],
     'rvt_bn_act_bwd_stats': [_vp] * 8 + [_i, _i, _i, _i, _vp],
     'rvt_bn_act_bwd_apply': [_vp] * 9 + [_i, _i, _i, _i, _vp],
     'rvt_conv_bn_act_fwd': [_vp] * 5 + [_i] * 10 + [_vp],

@@ -108,6 +108,48 @@ bn_act_fwd_kernel(const T* __restrict__ x, const float* __restrict__ scale, cons
     }
 }
 
+// training forward in one launch: every thread finalizes ITS 8 channels from the (already all-reduced) sums — mean, rstd, scale, shift —
+// and streams rows; the first row lane of workgroup 0 also publishes them (the backward needs them) and updates the running statistics
+// (what bn_finalize_kernel does as a launch of its own)
+template <class T>
+__global__ void __launch_bounds__(256)
+bn_train_act_fwd_kernel(const T* __restrict__ x, const float* __restrict__ sum, const float* __restrict__ sumsq, float count,
+                        const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+                        float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ mean_out,
+                        float* __restrict__ rstd_out, float* __restrict__ scale_out, float* __restrict__ shift_out, T* __restrict__ y,
+                        int rows, int C, int Gp, int act) {
+    const int cg = threadIdx.x % Gp, r0 = threadIdx.x / Gp, nrl = 256 / Gp;
+    if (cg * 8 >= C) return;
+    float sc[8], sh[8];
+    const bool publish = blockIdx.x == 0 && r0 == 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int c = cg * 8 + i;
+        const float mean = sum[c] / count;
+        const float var = fmaxf(sumsq[c] / count - mean * mean, 0.f);
+        const float rstd = 1.0f / sqrtf(var + eps);
+        sc[i] = gamma[c] * rstd;
+        sh[i] = beta[c] - mean * sc[i];
+        if (publish) {
+            mean_out[c] = mean; rstd_out[c] = rstd; scale_out[c] = sc[i]; shift_out[c] = sh[i];
+            if (running_mean != nullptr) {
+                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * (count > 1.f ? count / (count - 1.f) : 1.f);
+            }
+        }
+    }
+    for (int row = blockIdx.x * nrl + r0; row < rows; row += gridDim.x * nrl) {
+        float v[8], o[8];
+        frag_to_float<T>(frag_load<T>(x + (size_t)row * C + cg * 8), v);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const float z = fmaf(v[i], sc[i], sh[i]);
+            o[i] = act == BN_ACT_SILU ? silu_f(z) : z;
+        }
+        frag_store<T>(y + (size_t)row * C + cg * 8, frag_from_float<T>(o));
+    }
+}
+
 template <class T>
 __global__ void __launch_bounds__(256)
 bn_act_bwd_stats_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ scale,

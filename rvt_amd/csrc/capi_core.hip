@@ -258,6 +258,17 @@ int rvt_bn_act_fwd(const void* x, const float* scale, const float* shift, void* 
                                              shift, (T*)y, rows, C, Gp, act));
     return check_launch("bn_act_fwd");
 }
+int rvt_bn_train_act_fwd(const void* x, const float* sum, const float* sumsq, int count, const float* gamma, const float* beta, float eps,
+                         float momentum, float* running_mean, float* running_var, float* mean_out, float* rstd_out, float* scale_out,
+                         float* shift_out, void* y, int dtype, int rows, int C, int act, void* stream) {
+    RVT_CHECK(C % 8 == 0 && C >= 8 && C <= 2048 && rows >= 1 && count >= 1 && (act == 0 || act == 1), "bn_train_act_fwd: bad shape / activation");
+    RVT_CHECK(x && sum && sumsq && gamma && beta && mean_out && rstd_out && scale_out && shift_out && y, "bn_train_act_fwd: null argument");
+    const int Gp = pow2_ge(C / 8);
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_train_act_fwd_kernel<T>), dim3(bn_row_grid(rows, Gp)), dim3(256), 0, (hipStream_t)stream, (const T*)x,
+                                             sum, sumsq, (float)count, gamma, beta, eps, momentum, running_mean, running_var, mean_out, rstd_out,
+                                             scale_out, shift_out, (T*)y, rows, C, Gp, act));
+    return check_launch("bn_train_act_fwd");
+}
 int rvt_bn_act_bwd_stats(const void* dy, const void* x, const float* scale, const float* shift, const float* mean, const float* rstd,
                          float* dsum, float* dxsum, int dtype, int rows, int C, int act, void* stream) {
     RVT_CHECK(C % 8 == 0 && C >= 8 && C <= 1024 && rows >= 1, "bn_act_bwd_stats: C=%d must be a multiple of 8 in [8, 1024]", C);

@@ -65,14 +65,19 @@ class _BaseConvFn(torch.autograd.Function):
         fin = torch.empty(4, Cout, dtype=f32, device=dev)                                 # mean, rstd, scale, shift
         bn = mod.bn
         g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
-        L.call('rvt_bn_finalize', L.ptr(stats[0]), L.ptr(stats[1]), count, L.ptr(g32), L.ptr(b32), float(bn.eps),
-               float(bn.momentum if bn.momentum is not None else 0.1),
-               L.ptr(bn.running_mean) if bn.track_running_stats else None, L.ptr(bn.running_var) if bn.track_running_stats else None,
-               L.ptr(fin[0]), L.ptr(fin[1]), L.ptr(fin[2]), L.ptr(fin[3]), Cout, int(training), st)
-        if training and bn.track_running_stats:
-            bn.num_batches_tracked += 1
         y = torch.empty_like(y0)
-        L.call('rvt_bn_act_fwd', L.ptr(y0), L.ptr(fin[2]), L.ptr(fin[3]), L.ptr(y), L.dtype_code(dt), rows, Cout, BN_ACT_SILU, st)
+        mom = float(bn.momentum if bn.momentum is not None else 0.1)
+        rm, rv = (L.ptr(bn.running_mean), L.ptr(bn.running_var)) if bn.track_running_stats else (None, None)
+        if training:                                                                      # finalize + activation in one launch
+            L.call('rvt_bn_train_act_fwd', L.ptr(y0), L.ptr(stats[0]), L.ptr(stats[1]), count, L.ptr(g32), L.ptr(b32), float(bn.eps), mom,
+                   rm, rv, L.ptr(fin[0]), L.ptr(fin[1]), L.ptr(fin[2]), L.ptr(fin[3]), L.ptr(y), L.dtype_code(dt), rows, Cout,
+                   BN_ACT_SILU, st)
+            if bn.track_running_stats and pk is None:                                     # (with a ConvPack: one batched increment per forward)
+                bn.num_batches_tracked += 1
+        else:
+            L.call('rvt_bn_finalize', L.ptr(stats[0]), L.ptr(stats[1]), count, L.ptr(g32), L.ptr(b32), float(bn.eps), mom, rm, rv,
+                   L.ptr(fin[0]), L.ptr(fin[1]), L.ptr(fin[2]), L.ptr(fin[3]), Cout, 0, st)
+            L.call('rvt_bn_act_fwd', L.ptr(y0), L.ptr(fin[2]), L.ptr(fin[3]), L.ptr(y), L.dtype_code(dt), rows, Cout, BN_ACT_SILU, st)
         ctx.save_for_backward(x, w, y0, fin)
         ctx.mod, ctx.count, ctx.sync, ctx.training = mod, count, sync, training
         return y
@@ -106,7 +111,11 @@ class _BaseConvFn(torch.autograd.Function):
             dx = ops.conv_dgrad(dconv, wd, None, H, W, Cin, k, s, pad)
         dw = None
         if ctx.needs_input_grad[1]:
-            dwp = ctx.pk.dwp.zero_() if ctx.pk is not None else torch.zeros(Cout, k * k * Cin, dtype=torch.float32, device=dev)
+            if ctx.pk is not None:
+                dwp = ctx.pk.dwp if ctx.pk.dwp_clean else ctx.pk.dwp.zero_()          # (zeroed with the whole arena at the top of the forward)
+                ctx.pk.dwp_clean = False
+            else:
+                dwp = torch.zeros(Cout, k * k * Cin, dtype=torch.float32, device=dev)
             ops.conv_wgrad(x, dconv, dwp, k, s, pad)
             dw = weights.unpack_conv_wgrad(dwp, Cin, k).to(w.dtype)
         return dx, dw, ds_local[1].to(w.dtype), ds_local[0].to(w.dtype), None, None, None
@@ -136,7 +145,7 @@ class BaseConv(nn.Module):
 
 
 class _Packed:
-    __slots__ = ('wp', 'wd', 'stats', 'dwp', 'dtype', 'cin', 'fin')
+    __slots__ = ('wp', 'wd', 'stats', 'dwp', 'dtype', 'cin', 'fin', 'dwp_clean')
 
 
 class ConvPack:
@@ -165,10 +174,13 @@ class ConvPack:
             L.call('rvt_pack_table', L.ptr(self.table.dev), len(self.table), self.table.blocks, L.dtype_code(dtype), L.stream_of(self.bufT))
             self.versions = ver
         if training:
-            self.stats_all.zero_()
+            self.buf32.zero_()                           # batch statistics AND raw weight-gradient scratch of every unit: one memset
+            if self.counters:
+                torch._foreach_add_(self.counters, 1)    # num_batches_tracked of every BatchNorm
             self.bn_versions = None
             for c in self.convs:
                 c._pk.fin = None
+                c._pk.dwp_clean = True
         else:                                            # inference: the BatchNorm affine of every unit, once per parameter / buffer change
             bnv = tuple((t.data_ptr(), t._version) for c in self.convs for t in (c.bn.weight, c.bn.bias, c.bn.running_mean, c.bn.running_var))
             if bnv != getattr(self, 'bn_versions', None) or any(c._pk.fin is None for c in self.convs):
@@ -194,7 +206,7 @@ class ConvPack:
                 st = ar32.take(2, c.out_channels)
                 if second:
                     c._pk = _Packed()
-                    c._pk.stats, c._pk.dtype, c._pk.cin, c._pk.fin = st, dtype, c.in_channels, None
+                    c._pk.stats, c._pk.dtype, c._pk.cin, c._pk.fin, c._pk.dwp_clean = st, dtype, c.in_channels, None, False
             ar32_stats = ar32.n
             for c in self.convs:
                 Cout, Cin, k, s, pad = c.out_channels, c.in_channels, c.ksize, c.stride, c.pad
@@ -218,6 +230,7 @@ class ConvPack:
                     c._pk.wp, c._pk.wd, c._pk.dwp = wp, wd, dwp
         self.bufT, self.buf32 = arT.buf, ar32.buf
         self.stats_all = ar32.buf[:n_stats]
+        self.counters = [c.bn.num_batches_tracked for c in self.convs if c.bn.track_running_stats]
         tab.upload(dev)
         self.table = tab
 
