@@ -30,9 +30,10 @@ static bool route_fused_mlp_infer(const RvtStageDesc& d) {
     if (mode == 0 || !rvt_mlp_fused_supported(d.dtype, d.C)) return false;
     return mode == 1 || d.C == 64 || d.C == 128;
 }
-static bool route_lstm_scan(const RvtStageDesc& d) {
+static bool route_lstm_scan(const RvtStageDesc& d, int T) {
     const int mode = tuning().route_lstm_scan;
     if (mode == 0 || !rvt_lstm_scan_supported(d.dtype, d.C)) return false;
+    if (mode == -1 && T == 1) return false;      // one step (streaming inference): the per-step GEMM beats staging the scan's weights (3.69 vs 3.81 ms per step at B = 64)
     return mode == 1 || d.C <= 64 || rvt_lstm_scan_saves_gates(d.dtype, d.C);
 }
 static size_t stage_ws_bytes(const RvtStageDesc& d, int T, int B) {
@@ -130,7 +131,7 @@ int rvt_stage_seq_fwd(const RvtStageDesc* dp, const void* inp, const void* h0, c
     const size_t sN = (size_t)B * H * W * C;             // elements of one state
     const int Ms = B * H * W;
     char* const HallB = (char*)Hall;
-    if (route_lstm_scan(d)) {
+    if (route_lstm_scan(d, T)) {
         if (h0 != nullptr) { if (hipMemcpyAsync(HallB, h0, sN * e, hipMemcpyDeviceToDevice, st) != hipSuccess) { set_last_error("stage_seq_fwd: state copy failed"); return 1; } }
         else if (hipMemsetAsync(HallB, 0, sN * e, st) != hipSuccess) { set_last_error("stage_seq_fwd: memset failed"); return 1; }
         RVT_TRY(rvt_lstm_scan_fwd(x, Hall, c0, c_last, nullptr, d.lstm_wn, d.lstm_bn, nullptr, dt, Ms, C, T, stream));

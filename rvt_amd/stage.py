@@ -56,13 +56,15 @@ def use_attn_block(dtype, C: int, dh: int, n_tok: int, training: bool = False) -
     return tuning.get('route_attn_block') != 0 and ops.attn_block_supported(dtype, C, dh, n_tok)
 
 
-def use_lstm_scan(dtype, C: int, dws) -> bool:
+def use_lstm_scan(dtype, C: int, dws, T: int = 0, save: bool = True) -> bool:
     """ConvLSTM with the time loop inside the kernel (csrc/lstm_scan.hpp) instead of one launch per step: only the 1x1-conv
     cell (dws_conv False — every shipped config); by default where the weights stay resident in LDS (C <= 64), C = 128
     (weights streamed from L2) with tuning.route_lstm_scan = 1 (all supported widths; the parity tests); 0 disables."""
     mode = tuning.get('route_lstm_scan')
     if mode == 0 or dws is not None or not ops.lstm_scan_supported(dtype, C):
         return False
+    if mode == -1 and T == 1 and not save:
+        return False                     # one no-grad step (streaming inference): the per-step GEMM beats staging the scan's weights
     return True if mode == 1 else (C <= 64 or ops.lstm_scan_saves_gates(dtype, C))
 
 
@@ -202,13 +204,13 @@ def stage_seq_forward(sw: StageWeights, g: StageGeom, inp: Tensor, h0: Optional[
     dws = sw.dws
     # a no-grad forward on the per-step route reads the incoming states where they are (streaming inference, T = 1: the two
     # state copies per stage were 5 % of the step); BPTT and the scan kernel want them in slot 0
-    direct0 = (not save) and h0 is not None and not use_lstm_scan(dt, C, dws) and h0.dtype == dt and h0.is_contiguous() \
+    direct0 = (not save) and h0 is not None and not use_lstm_scan(dt, C, dws, T, save) and h0.dtype == dt and h0.is_contiguous() \
         and c0 is not None and c0.dtype == torch.float32 and c0.is_contiguous()
     if h0 is None:
         Hall[0].zero_()                                                           # rnn.py:43-47
     elif not direct0:
         Hall[0].copy_(h0)
-    if use_lstm_scan(dt, C, dws):
+    if use_lstm_scan(dt, C, dws, T, save):
         # all T steps in ONE launch: h / c stay on chip, BPTT keeps only a T-typed copy of the cell states
         c_last = torch.empty((B, H, W, C), dtype=torch.float32, device=dev)
         Csave = torch.empty((T, B, H, W, C), dtype=dt, device=dev) if save else None
