@@ -58,7 +58,7 @@ elif op in ('mlp_fwd', 'mlp_bwd'):
         dy, dlw, dlb = rnd(M, C), torch.zeros(C, device=dev), torch.zeros(C, device=dev)
         w2gt, w1t = w2.t().contiguous(), w1.t().contiguous()
         fn = lambda: ops.mlp_bwd_dgrad(dy, dy4, x, lw, w2gt, w1t, dlw, dlb, 1e-5)
-elif op in ('mlpc_fwd', 'mlpc_dgrad', 'mlpc_wgrad'):      # recompute MLP route (csrc/mlp_chain.hpp unless RVT_MLP_CHAIN=0)
+elif op in ('mlpc_fwd', 'mlpc_dgrad', 'mlpc_wgrad', 'mlpc_both'):      # recompute MLP route (csrc/mlp_chain.hpp unless RVT_MLP_CHAIN=0)
     lw, lb = torch.ones(C, device=dev), torch.zeros(C, device=dev)
     w1, w2 = rnd(4 * C, C) * 0.1, rnd(C, 4 * C) * 0.1
     b1, b2, gam = torch.zeros(4 * C, device=dev), torch.zeros(C, device=dev), torch.ones(C, device=dev)
@@ -71,6 +71,8 @@ elif op in ('mlpc_fwd', 'mlpc_dgrad', 'mlpc_wgrad'):      # recompute MLP route 
         fn = lambda: ops.mlp_fwd(x, lw, lb, w1, b1, w2, b2, gam, 1e-5, want_grad=False)
     elif op == 'mlpc_dgrad':
         fn = lambda: ops.mlp_bwd_recompute_dgrad(dy, x, lw, lb, w1, b1, w2gt, w1t, dlw, dlb, 1e-5)
+    elif op == 'mlpc_both':
+        fn = lambda: ops.mlp_bwd_recompute_both(dy, x, lw, lb, w1, b1, w2gt, w1t, dlw, dlb, dw1, db1, s2, cs2, 1e-5)
     else:
         fn = lambda: ops.mlp_bwd_recompute_wgrad(dy, x, lw, lb, w1, b1, w2gt, dw1, db1, s2, cs2, 1e-5)
 elif op in ('ab_fwd', 'ab_bwd', 'ab_fwd_ln', 'ab_bwd_ln'):      # fused attention half (csrc/attn_block.hpp), stage-1 window block
