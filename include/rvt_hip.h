@@ -78,9 +78,11 @@ typedef struct RvtTuning {
     int route_stage_driver;   /* 1: the no-grad forward of rvt_amd takes rvt_stage_seq_fwd (one call per stage); 0: the Python host loop */
     int route_mlp_store_pre;  /* 1: the LDS-staged fused MLP forward (C = 128) saves the pre-activation h only, not GELU(h) and GELU'(h); default 0: measured slower (GELU on load costs more than the bytes it saves, profiles/r4/microbench_mlp128.txt) */
     int route_mlp_bwd_both;   /* 1: stage-1 MLP backward = ONE launch (rvt_mlp_bwd_recompute_both) instead of dgrad + wgrad */
-    int reserved[8];          /* zero */
+    int mlp_stream;           /* 1 (round 5): C = 128 MLP halves take the streamed-weight chain kernels (mlp_stream.hpp): nothing-saved forward,
+                                 recompute backward (input-gradient + weight-gradient launch); 0: LDS-staged forward that saves GELU / GELU' + op-by-op backward */
+    int reserved[7];          /* zero */
 } RvtTuning;
-#define RVT_TUNING_DEFAULTS {(int)sizeof(RvtTuning), 0, 1, 0, 512, 8192, 1, 4096, 0, 0, 0, 0, 1, 4, 0, 1, 1, 0, 0, 1, -1, 1, 1, -1, 1, 1, 0, 1, 1, 0, 1, {0}}
+#define RVT_TUNING_DEFAULTS {(int)sizeof(RvtTuning), 0, 1, 0, 512, 8192, 1, 4096, 0, 0, 0, 0, 1, 4, 0, 1, 1, 0, 0, 1, -1, 1, 1, -1, 1, 1, 0, 1, 1, 0, 1, 1, {0}}
 void rvt_tuning_defaults(RvtTuning* t);        /* fills *t with the production defaults */
 int rvt_get_tuning(RvtTuning* t);              /* t->struct_bytes must be set by the caller */
 int rvt_set_tuning(const RvtTuning* t);

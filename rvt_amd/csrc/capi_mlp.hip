@@ -4,6 +4,7 @@
 #include "dgrad_ln.hpp"
 #include "mlp.hpp"
 #include "mlp_chain.hpp"
+#include "mlp_stream.hpp"
 
 using namespace rvt;
 
@@ -32,6 +33,18 @@ template <class K> static int mlp_grid(K kernel, int M, int tm) {
 static bool mlp_chain_on(int dtype, int C) {
     const int off = !tuning().mlp_chain;
     return !off && C == 64 && (dtype == RVT_BF16 || dtype == RVT_F32);
+}
+// streamed-weight chain kernels (csrc/mlp_stream.hpp): C == 128; tuning.mlp_stream = 0 falls back to mlp.hpp / the op-by-op backward
+static bool mlp_stream_on(int dtype, int C) {
+    return tuning().mlp_stream != 0 && tuning().mlp_chain != 0 && C == 128 && (dtype == RVT_BF16 || dtype == RVT_F32);
+}
+template <class T> struct MsWaves { static constexpr int V = sizeof(T) == 2 ? 8 : 4, MINW = sizeof(T) == 2 ? 2 : 1; };
+// one workgroup per CU (two 32-KiB weight stages + tables); every wave of a workgroup walks the same number of tiles
+template <class K> static int ms_grid(K kernel, int threads, int M, int wpb) {
+    const int resident_override = tuning().chain_resident;
+    const int per_cu = resident_per_cu(kernel, threads, 1);
+    const int want = ((M + 31) / 32 + wpb - 1) / wpb;
+    return imax(1, imin(want, resident_override > 0 ? resident_override : 256 * per_cu));
 }
 #ifndef MC_FWD_WPB
 #define MC_FWD_WPB 8      // (6 waves x 3 per SIMD at <= 168 registers spills inside the chunk loop: 2.0 ms against 1.42)
@@ -72,9 +85,19 @@ int rvt_linear_dgrad_ln(const void* dy, const void* w, const void* x, const void
 int rvt_mlp_fwd(const void* xmid, void* xout, void* g_out, void* gp_out, void* v2_out, const float* ln_w, const float* ln_b,
                 const void* w1, const float* b1, const void* w2, const float* b2, const float* gamma, int dtype, int M,
                 int C, float eps, void* stream) {
-    RVT_CHECK(rvt_mlp_fused_supported(dtype, C), "mlp_fwd: fused MLP not built for dtype=%d C=%d", dtype, C);
     RVT_CHECK(gp_out == nullptr || g_out != nullptr, "mlp_fwd: gp_out needs g_out (g_out alone = the pre-activation h)");
     hipStream_t st = (hipStream_t)stream;
+    if (g_out == nullptr && v2_out == nullptr && mlp_stream_on(dtype, C)) {
+        // nothing to save, C = 128: the chain kernel with streamed weights (csrc/mlp_stream.hpp)
+        DISPATCH_DTYPE(dtype, {
+            constexpr int WPB = MsWaves<T>::V;
+            auto k = mlps_fwd_kernel<T, 128, WPB, MsWaves<T>::MINW>;
+            hipLaunchKernelGGL(k, dim3(ms_grid(k, 64 * WPB, M, WPB)), dim3(64 * WPB), 0, st, (const T*)xmid, (T*)xout, ln_w, ln_b,
+                               (const T*)w1, b1, (const T*)w2, b2, gamma, M, eps);
+        });
+        return check_launch("mlp_fwd(stream)");
+    }
+    RVT_CHECK(rvt_mlp_fused_supported(dtype, C), "mlp_fwd: fused MLP not built for dtype=%d C=%d", dtype, C);
     if (g_out == nullptr && v2_out == nullptr && mlp_chain_on(dtype, C)) {
         // nothing to save: the register-chained kernel (csrc/mlp_chain.hpp)
         DISPATCH_DTYPE(dtype, {
@@ -152,8 +175,18 @@ size_t rvt_mlp_bwd_fused_ws_floats(int dtype, int C, int M) {
 int rvt_mlp_bwd_recompute_dgrad(const void* dxout, const void* xmid, void* dxmid, const float* ln_w, const float* ln_b,
                                 const void* w1, const float* b1, const void* w2g_t, const void* w1_t, float* dln_w,
                                 float* dln_b, int dtype, int M, int C, float eps, void* stream) {
-    RVT_CHECK(rvt_mlp_bwd_fused_supported(dtype, C), "mlp_bwd_recompute_dgrad: not built for dtype=%d C=%d", dtype, C);
     hipStream_t st = (hipStream_t)stream;
+    if (mlp_stream_on(dtype, C)) {
+        // C = 128: the chain kernel with streamed weights (csrc/mlp_stream.hpp); w1_t unused (W1^T fragments = transposing reads of W1)
+        DISPATCH_DTYPE(dtype, {
+            constexpr int WPB = MsWaves<T>::V;
+            auto k = mlps_bwd_dgrad_kernel<T, 128, WPB, MsWaves<T>::MINW>;
+            hipLaunchKernelGGL(k, dim3(ms_grid(k, 64 * WPB, M, WPB)), dim3(64 * WPB), 0, st, (const T*)dxout, (const T*)xmid,
+                               (T*)dxmid, ln_w, ln_b, (const T*)w1, b1, (const T*)w2g_t, dln_w, dln_b, M, eps);
+        });
+        return check_launch("mlp_bwd_recompute_dgrad(stream)");
+    }
+    RVT_CHECK(rvt_mlp_bwd_fused_supported(dtype, C), "mlp_bwd_recompute_dgrad: not built for dtype=%d C=%d", dtype, C);
     if (mlp_chain_on(dtype, C)) {
         DISPATCH_DTYPE(dtype, {
             constexpr int WPB = McWaves<T>::V;

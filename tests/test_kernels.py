@@ -677,3 +677,62 @@ def test_gather_frames(backend, dt):
     want = torch.zeros_like(frames.detach()).cpu()
     want[idx.cpu().long()] = cot.cpu()
     assert torch.equal(frames.grad.cpu(), want)
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+@pytest.mark.parametrize('M,resident', [(1000, 2), (300, 0), (2049, 3)])
+def test_mlp_stream_fwd(backend, dt, M, resident):
+    """Streamed-weight chain forward of the MLP half at C = 128 (csrc/mlp_stream.hpp: weights by LDS-DMA in hidden chunks, nothing
+    saved) vs fp64 autograd and vs the LDS-staged kernel it replaces; `resident` workgroups so that a workgroup walks several
+    tiles (deferred row stores, weight stream across tile boundaries) and the last tile is ragged."""
+    C = 128
+    x = rnd((M, C), backend, dt, 1, 1.5)
+    lw, lb = rnd((C,), backend, torch.float32, 2) * 0.3 + 1.0, rnd((C,), backend, torch.float32, 3, 0.2)
+    w1, b1 = rnd((4 * C, C), backend, dt, 4, 0.2), rnd((4 * C,), backend, torch.float32, 5, 0.2)
+    w2, b2 = rnd((C, 4 * C), backend, dt, 6, 0.1), rnd((C,), backend, torch.float32, 7, 0.2)
+    gam = rnd((C,), backend, torch.float32, 8)
+    with tuning.override(mlp_stream=1, chain_resident=resident):
+        y = ops.mlp_fwd(x, lw, lb, w1, b1, w2, b2, gam, 1e-5, want_grad=False)[0]
+    v2 = F.layer_norm(f64(x), (C,), f64(lw), f64(lb), 1e-5)
+    want = f64(x) + f64(gam) * (F.gelu(v2 @ f64(w1).t() + f64(b1)) @ f64(w2).t() + f64(b2))
+    mult = 1.0 if dt == torch.float32 else 2.0
+    close(y, want, dt, 'mlp_fwd streamed', mult=mult)
+    if dt == torch.bfloat16:
+        with tuning.override(mlp_stream=0):
+            y0 = ops.mlp_fwd(x, lw, lb, w1, b1, w2, b2, gam, 1e-5, want_grad=False)[0]
+        close(y, y0.double(), dt, 'mlp_fwd streamed vs LDS-staged', mult=mult)
+
+
+def _mlp_case(backend, dt, M, C=128):
+    x = rnd((M, C), backend, dt, 1, 1.5)
+    lw, lb = rnd((C,), backend, torch.float32, 2) * 0.3 + 1.0, rnd((C,), backend, torch.float32, 3, 0.2)
+    w1, b1 = rnd((4 * C, C), backend, dt, 4, 0.2), rnd((4 * C,), backend, torch.float32, 5, 0.2)
+    w2, b2 = rnd((C, 4 * C), backend, dt, 6, 0.1), rnd((C,), backend, torch.float32, 7, 0.2)
+    gam = rnd((C,), backend, torch.float32, 8) * 0.5 + 1.0
+    dy = rnd((M, C), backend, dt, 9)
+    xr = f64(x).requires_grad_(True)
+    lwr, lbr = f64(lw).requires_grad_(True), f64(lb).requires_grad_(True)
+    w1r, b1r = f64(w1).requires_grad_(True), f64(b1).requires_grad_(True)
+    v2 = F.layer_norm(xr, (C,), lwr, lbr, 1e-5)
+    g = F.gelu(v2 @ w1r.t() + b1r)
+    want = xr + f64(gam) * (g @ f64(w2).t() + f64(b2))
+    want.backward(f64(dy))
+    w2g_t = (f64(w2) * f64(gam)[:, None]).t().to(dt).contiguous().to(backend)
+    w1_t = f64(w1).t().to(dt).contiguous().to(backend)
+    return dict(x=x, lw=lw, lb=lb, w1=w1, b1=b1, w2=w2, b2=b2, gam=gam, dy=dy, w2g_t=w2g_t, w1_t=w1_t, xr=xr, lwr=lwr, lbr=lbr,
+                w1r=w1r, b1r=b1r, g=g.detach(), want=want.detach())
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+@pytest.mark.parametrize('M,resident', [(1000, 2), (300, 0), (2049, 3)])
+def test_mlp_stream_bwd_dgrad(backend, dt, M, resident):
+    """Streamed-weight recompute backward of the MLP half at C = 128, input-gradient kernel (csrc/mlp_stream.hpp) vs fp64 autograd."""
+    c = _mlp_case(backend, dt, M)
+    C = 128
+    dlw, dlb = torch.zeros(C, device=backend), torch.zeros(C, device=backend)
+    with tuning.override(mlp_stream=1, chain_resident=resident):
+        dxm = ops.mlp_bwd_recompute_dgrad(c['dy'], c['x'], c['lw'], c['lb'], c['w1'], c['b1'], c['w2g_t'], c['w1_t'], dlw, dlb, 1e-5)
+    mult = 1.0 if dt == torch.float32 else 2.0
+    close(dxm, c['xr'].grad, dt, 'mlp_stream dxmid', mult=mult)
+    close(dlw, c['lwr'].grad, dt, 'mlp_stream dln_w', mult=2 * mult)
+    close(dlb, c['lbr'].grad, dt, 'mlp_stream dln_b', mult=2 * mult)
