@@ -144,6 +144,7 @@ int rvt_mlp_bwd_dgrad(const void* dxout, const void* gp, const void* xmid, void*
 // and the weight gradients from (dxout, xmid) alone.  Built where the whole set of weight-gradient accumulators fits
 // the register file of one workgroup: C == 64.
 int rvt_mlp_bwd_fused_supported(int dtype, int C) {
+    if (C == 128) return dtype == RVT_BF16 && mlp_stream_on(dtype, C);      // streamed-weight kernels (csrc/mlp_stream.hpp); fp32: forward + input gradient only
     return (dtype == RVT_BF16 || dtype == RVT_F32) && C == 64;
 }
 }  // extern "C"
@@ -164,9 +165,15 @@ static void mlp_fold_partials(const float* ws, int grid, int C, float* dw1, floa
     p += (size_t)2 * grid * 4 * C;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(reduce_grid((size_t)C)), dim3(256), 0, st, p, cs2, grid, (size_t)C, 0);
 }
+// tile streams of mlps_bwd_wgrad_kernel: two workgroups (hidden halves) per stream, one workgroup per CU
+static int msw_streams(int M) {
+    const int n_tiles = (M + 31) / 32;
+    return imax(1, imin(2 * n_tiles, one_per_cu_grid(2 * n_tiles)) / 2);
+}
 extern "C" {
 size_t rvt_mlp_bwd_fused_ws_floats(int dtype, int C, int M) {
     if (!rvt_mlp_bwd_fused_supported(dtype, C)) return 0;
+    if (C == 128) return (size_t)msw_streams(M) * ((size_t)2 * 4 * C * C + 2 * 4 * C + C);
     size_t grid = dtype == RVT_BF16 ? mlp_bwd_fused_grid<bf16, 2>(M) : mlp_bwd_fused_grid<float, 2>(M);
     if (grid < 256) grid = 256;                          // mlpc_bwd_wgrad_kernel: one workgroup per CU
     return grid * ((size_t)2 * 4 * C * C + 2 * 4 * C + C);
@@ -210,6 +217,13 @@ int rvt_mlp_bwd_recompute_wgrad(const void* dxout, const void* xmid, const float
     RVT_CHECK(rvt_mlp_bwd_fused_supported(dtype, C), "mlp_bwd_recompute_wgrad: not built for dtype=%d C=%d", dtype, C);
     RVT_CHECK(ws != nullptr && M >= 1, "mlp_bwd_recompute_wgrad: workspace required");
     hipStream_t st = (hipStream_t)stream;
+    if (C == 128) {
+        const int S = msw_streams(M);
+        hipLaunchKernelGGL(mlps_bwd_wgrad_kernel<0>, dim3(16 * ((S + 7) / 8)), dim3(512), 0, st, (const bf16*)dxout, (const bf16*)xmid, ln_w, ln_b,
+                           (const bf16*)w1, b1, (const bf16*)w2g_t, ws, M, eps, S);
+        mlp_fold_partials(ws, S, C, dw1, db1, s2, cs2, st);
+        return check_launch("mlp_bwd_recompute_wgrad(stream)");
+    }
     int grid = 0;
     const int chain_wgrad = tuning().mlp_chain_wgrad;
     if (chain_wgrad && dtype == RVT_BF16 && mlp_chain_on(dtype, C)) {

@@ -563,4 +563,251 @@ mlps_bwd_dgrad_kernel(const T* __restrict__ dxout, const T* __restrict__ xmid, T
     }
 }
 
+// =========================================================================== backward: weight gradients (bf16, C = 128)
+//   dW1[j][c] = sum_t dh[t][j] v2[t][c],  db1[j] = sum_t dh[t][j],  S2[c][j] = sum_t dxout[t][c] g[t][j],  cs2[c] = sum_t dxout[t][c]
+//   with v2 = LN2(xmid), h = v2 W1^T + b1, g = GELU(h), dh = (dxout (gamma W2)) GELU'(h)      (everything recomputed)
+// Weight-stationary like mlpc_bwd_wgrad_kernel (mlp_chain.hpp): wave w of a workgroup owns 32 hidden columns and their
+// 2 x [32][128] fp32 accumulators (128 registers); a workgroup covers HALF of the hidden axis (256 columns; the two halves of
+// a tile stream run as neighbours on one XCD and write disjoint halves of the same partial record).  What changes at C = 128 is
+// where everything else lives, because 128 accumulators + 2 x 32 weight-fragment registers leave a wave nothing to work with:
+//   * the wave's rows of W1 stay in registers (B operands of h); the workgroup's 256 rows of (gamma W2)^T sit in LDS (68 KiB,
+//     row pitch 272 B) and are read as B operands of dg;
+//   * token tiles arrive by LDS-DMA (no staging registers): xmid / dxout rows of tile i+2 are requested while tile i is multiplied,
+//     into a ring of three [32][256 B] tiles each (16-byte chunk index XOR row & 15, applied to the source address); LayerNorm runs
+//     IN PLACE on the landed xmid tile one phase ahead of its use (16 threads per row, DPP row sums); ONE barrier per tile;
+//   * GELU / GELU': Phi from the 32-KiB nearest-entry table, the density term of GELU' = Phi + x phi(x) from one v_exp (a
+//     {Phi, GELU'} pair table as in the C = 64 kernel does not fit beside the weight image).
+// Partial results per tile stream in `ws`, laid out as mlp_fold_partials expects with grid = number of streams:
+// [dW1: S x 4C x C][S2: S x C x 4C][db1: 2 S x 4C][cs2: S x C].
+struct MswGeom {
+    static constexpr int C = 128, HID = 512, HB = 256, KS = 8, NCB = 4;
+    static constexpr int TILE = 32 * 256;                 // [32 tokens][128 channels] bf16, pitch 256 B, swizzled
+    static constexpr int W2P = 272, W2IMG = HB * W2P;
+    static constexpr int OFF_XV = 0, OFF_DX = 3 * TILE, OFF_W2 = 6 * TILE, OFF_LUT = OFF_W2 + W2IMG, OFF_K = OFF_LUT + GELU_NLUT_BYTES;
+    static constexpr int SMEM = OFF_K + 2 * C * 4;
+};
+__device__ __forceinline__ int msw_tile_off(int row, int chunk) { return row * 256 + ((chunk ^ (row & 15)) << 4); }
+
+template <int TAG>
+__global__ void __launch_bounds__(512, 2)
+mlps_bwd_wgrad_kernel(const bf16* __restrict__ dxout, const bf16* __restrict__ xmid, const float* __restrict__ ln_w,
+                      const float* __restrict__ ln_b, const bf16* __restrict__ W1, const float* __restrict__ b1,
+                      const bf16* __restrict__ W2gT, float* __restrict__ ws, int M, float eps, int nstreams) {
+    typedef bf16 T;
+    typedef MswGeom G;
+    constexpr int C = G::C, KS = G::KS, NCB = G::NCB, HID = G::HID, TILE = G::TILE;
+    __shared__ __attribute__((aligned(16))) char smem[G::SMEM];
+    float* const lut = reinterpret_cast<float*>(smem + G::OFF_LUT);
+    float* const kst = reinterpret_cast<float*>(smem + G::OFF_K);          // ln_w | ln_b
+    const int tid = threadIdx.x, lane_ = tid & 63;
+    const int wave = wave_uniform(tid >> 6);
+    // workgroup -> (tile stream, hidden half): ids b and b + 8 are the two halves of one stream (same XCD, dispatched together)
+    const int bid = blockIdx.x;
+    const int hb = (bid >> 3) & 1, stream = (bid >> 4) * 8 + (bid & 7);
+    if (stream >= nstreams) return;
+    const int n_tiles = (M + 31) / 32;
+    const int count = stream < n_tiles ? (n_tiles - stream + nstreams - 1) / nstreams : 0;     // tiles stream, stream + S, ...
+
+    gelu_nlut_fill<false>(lut, tid, 512);
+    for (int i = tid; i < C; i += 512) { kst[i] = ln_w[i]; kst[C + i] = ln_b[i]; }
+    for (int f = tid; f < G::HB * 16; f += 512) {         // the workgroup's rows of (gamma W2)^T
+        const int r = f >> 4, c = f & 15;
+        *reinterpret_cast<u32x4*>(smem + G::OFF_W2 + r * G::W2P + c * 16) =
+            *reinterpret_cast<const u32x4*>(W2gT + (size_t)(hb * G::HB + r) * C + c * 8);
+    }
+    // this wave's rows j = 256 hb + 32 wave + li of W1, as B operands (k-step ks: channels 16 ks + 8 half ..)
+    const int jrow = hb * G::HB + 32 * wave + (lane_ & 31);
+    frag_t<T> w1f[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) w1f[ks] = frag_load<T>(W1 + (size_t)jrow * C + 16 * ks + 8 * (lane_ >> 5));
+    const float b1v = b1[jrow];
+
+    f32x16 dw1[NCB], s2[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) { acc_zero(dw1[cb]); acc_zero(s2[cb]); }
+    float db1 = 0.f;
+    // column sums of dxout: wave w sums the eight tokens of ONE transposed dxout fragment per tile - channel block w & 3, token group
+    // w >> 2 - that it reads anyway (lane = channel): one accumulator register per wave (the staging role kept eight per thread)
+    float cs1 = 0.f;
+    const int cs_cb = wave & 3, cs_q = wave >> 2;
+
+    // ---- tile stream: piece `wave` of the xmid tile and of the dxout tile (4 rows x 256 B each) per wave
+    auto issue = [&](int k, int buf) __attribute__((always_inline)) {
+        int lane = lane_;
+        opaque_vgpr(lane);
+        const int tile = stream + k * nstreams;
+        const int rows = tile < n_tiles ? (M - tile * 32 < 32 ? M - tile * 32 : 32) : 0;
+        const pp_rsrc rx = pp_make_rsrc(xmid + (size_t)(rows ? tile : 0) * 32 * C, (unsigned)(rows * C * 2));
+        const pp_rsrc rd = pp_make_rsrc(dxout + (size_t)(rows ? tile : 0) * 32 * C, (unsigned)(rows * C * 2));
+        const int r = 4 * wave + (lane >> 4), c = (lane & 15) ^ (r & 15);
+        const int voff = r * 256 + c * 16;
+        pp_glds16(rx, smem, G::OFF_XV + buf * TILE + wave * 1024, voff, 0);
+        pp_glds16(rd, smem, G::OFF_DX + buf * TILE + wave * 1024, voff, 0);
+    };
+    // ---- staging role: LayerNorm of tile k+1 in place (16 threads per row, 8 channels each)
+    auto layernorm = [&](int buf, bool live) __attribute__((always_inline)) {
+        if (!live) return;
+        int t = tid;
+        opaque_vgpr(t);                                   // (the per-thread tile offset is recomputed per tile: kept across the loop it was spilled,
+        const int srow = t >> 4, spc = t & 15;            //  and a scratch reload waits with vmcnt(0) = for the tile stream)
+        char* const px = smem + G::OFF_XV + buf * TILE + msw_tile_off(srow, spc);
+        const bf16x8 xb = *reinterpret_cast<const bf16x8*>(px);
+        float x[8], s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { x[i] = (float)xb[i]; s += x[i]; }
+        const float mean = row16_sum(s) * (1.0f / C);
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { x[i] -= mean; ss += x[i] * x[i]; }
+        const float rstd = 1.0f / sqrtf(row16_sum(ss) * (1.0f / C) + eps);
+        float w[8], bb[8];
+        load_cols<8>(kst, 8 * spc, w);
+        load_cols<8>(kst + C, 8 * spc, bb);
+        bf16x8 v;
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = (T)fmaf(x[i] * rstd, w[i], bb[i]);
+        *reinterpret_cast<bf16x8*>(px) = v;
+    };
+    // ---- compute role
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+        int lane = lane_;
+        opaque_vgpr(lane);
+        const int li = lane & 31, half = lane >> 5;
+        const char* const v2t = smem + G::OFF_XV + buf * TILE;
+        const char* const dxt = smem + G::OFF_DX + buf * TILE;
+        const int arow = li * 256 + ((half ^ (li & 15)) << 4);                   // token row li, chunk (2 ks + half): ^ (ks << 5)
+        const int wrow = G::OFF_W2 + (32 * wave + li) * G::W2P + half * 16;      // + ks * 32
+        // accumulator column = hidden j (this lane), registers = the tile's tokens
+        f32x16 h, dg;
+#pragma unroll
+        for (int r = 0; r < 16; r++) h[r] = b1v;
+        acc_zero(dg);
+        // (fragment reads in two groups of four: all eight in flight at once cost the registers a spilled W1 fragment needs)
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            if (ks == KS / 2) sched_fence();
+            mma32(h, *reinterpret_cast<const frag_t<T>*>(v2t + (arow ^ (ks << 5))), w1f[ks]);
+        }
+        sched_fence();
+        // transposed-operand addresses: token rows 16 q + rl (+ 8), channel block cb: base ^ (cb << 6) + q * 4096
+        const int rl = 4 * half + ((lane & 15) >> 2), c3 = 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1), sub = 8 * (lane & 1);
+        const int t_lo = rl * 256 + ((c3 ^ rl) << 4) + sub, t_hi = (rl + 8) * 256 + ((c3 ^ rl ^ 8) << 4) + sub;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            if (ks % 2 == 0 && ks) sched_fence();
+            mma32(dg, *reinterpret_cast<const frag_t<T>*>(dxt + (arow ^ (ks << 5))), *reinterpret_cast<const frag_t<T>*>(smem + wrow + ks * 32));
+        }
+        sched_fence();
+        frag_t<T> gf[2], dhf[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {                     // eight values at a time (registers): slot q of the operands = accumulator registers 8q .. 8q+7
+            int idx[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) idx[e] = gelu_nlut_index(h[8 * q + e]);
+            sched_fence();
+            float ph[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) ph[e] = lut[idx[e]];
+            sched_fence();
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float x = h[8 * q + e];
+                const float ex = fast_exp2(x * x * -0.72134752044448170f);       // exp(-x^2 / 2)
+                const float gpv = fmaf(x * 0.3989422804014327f, ex, ph[e]);      // GELU'(x) = Phi(x) + x phi(x)
+                const float d = mul_nopack(dg[8 * q + e], gpv, e);
+                db1 += d;
+                gf[q][e] = (T)mul_nopack(x, ph[e], e);                           // GELU(x)
+                dhf[q][e] = (T)d;
+            }
+        }
+        // dW1 / S2: contraction over the tokens (transposing reads issued as assembly: LDS-DMA is in flight, see ms_tr_frag)
+#ifdef RVT_EMU
+        const char* const vb = v2t;
+        const char* const db_ = dxt;
+#else
+        const int vb = (int)(size_t)(__attribute__((address_space(3))) const char*)(v2t);
+        const int db_ = (int)(size_t)(__attribute__((address_space(3))) const char*)(dxt);
+#endif
+        ms_static_for<NCB>([&](auto cb_c) {
+            constexpr int CB = decltype(cb_c)::value;
+            const int alo = t_lo ^ (CB << 6), ahi = t_hi ^ (CB << 6);
+            frag_t<T> vT[2], dT[2];
+            ms_static_for<2>([&](auto q_c) {
+                constexpr int Q = decltype(q_c)::value;
+#ifdef RVT_EMU
+                vT[Q] = frag_from_tr<T>(reinterpret_cast<const bf16*>(vb + alo + Q * 4096), reinterpret_cast<const bf16*>(vb + ahi + Q * 4096));
+                dT[Q] = frag_from_tr<T>(reinterpret_cast<const bf16*>(db_ + alo + Q * 4096), reinterpret_cast<const bf16*>(db_ + ahi + Q * 4096));
+#else
+                typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+                u32x2_t a0, a1, b0, b1_;
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(a0) : "v"(vb + alo), "n"(Q * 4096));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(a1) : "v"(vb + ahi), "n"(Q * 4096));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(b0) : "v"(db_ + alo), "n"(Q * 4096));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(b1_) : "v"(db_ + ahi), "n"(Q * 4096));
+                const u32x4 va = {a0[0], a0[1], a1[0], a1[1]}, vd = {b0[0], b0[1], b1_[0], b1_[1]};
+                __builtin_memcpy(&vT[Q], &va, 16);
+                __builtin_memcpy(&dT[Q], &vd, 16);
+#endif
+            });
+            ms_lgkm_wait();
+            if (CB == cs_cb) {                          // (wave-uniform)
+                const frag_t<T> dq = cs_q ? dT[1] : dT[0];
+#pragma unroll
+                for (int e = 0; e < 8; e++) cs1 += (float)dq[e];
+            }
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                mma32(dw1[CB], dhf[q], vT[q]);          // rows j, columns c
+                mma32(s2[CB], dT[q], gf[q]);            // rows c, columns j
+            }
+        });
+    };
+
+    const bool mfma_first = wave < 4;
+    issue(0, 0);
+    issue(1, 1);
+    pp_wait_vm<2>();                                      // this wave's pieces of tile 0 (table / W2 image stores are LDS writes: barrier)
+    __syncthreads();
+    layernorm(0, count > 0);
+    for (int k = 0; k < count; k++) {
+        // tile k+1 has landed (this wave's pieces: vmcnt; everybody's: barrier); LayerNorm of tile k is visible; tile k-1 is done with
+        pp_wait_vm<0>();
+        lds_barrier();
+        issue(k + 2, (k + 2) % 3);
+        const int buf = k % 3, nbuf = (k + 1) % 3;
+        if (mfma_first) compute(buf);
+        layernorm(nbuf, k + 1 < count);
+        if (!mfma_first) compute(buf);
+    }
+    pp_wait_vm<0>();                                      // (trailing pieces still write LDS)
+
+    const int lane = lane_, li = lane & 31;
+    const size_t nwg = nstreams, wg = stream;
+    float* const p_dw1 = ws + wg * (size_t)(HID * C);
+    float* const p_s2 = ws + nwg * (size_t)(HID * C) + wg * (size_t)(C * HID);
+    float* const p_db1 = ws + 2 * nwg * (size_t)(HID * C) + (wg * 2) * (size_t)HID;
+    float* const p_cs2 = ws + 2 * nwg * (size_t)(HID * C) + 2 * nwg * (size_t)HID + wg * (size_t)C;
+    const int j0 = hb * G::HB + 32 * wave;
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            p_dw1[(size_t)(j0 + acc_row(r, lane)) * C + 32 * cb + li] = dw1[cb][r];
+            p_s2[(size_t)(32 * cb + acc_row(r, lane)) * HID + j0 + li] = s2[cb][r];
+        }
+    db1 += __shfl_xor(db1, 32);
+    if (lane < 32) {
+        p_db1[j0 + li] = db1;
+        p_db1[HID + j0 + li] = 0.f;
+    }
+    // column sums of dxout: lane = channel 32 (w & 3) + li, the two lane halves and the two waves of a channel block hold disjoint
+    // token subsets: fold through LDS (the tiles are done with); the first hidden half's copy is the record
+    float* const red = reinterpret_cast<float*>(smem);
+    __syncthreads();
+    cs1 += __shfl_xor(cs1, 32);
+    if (lane < 32) red[cs_q * C + 32 * cs_cb + li] = cs1;
+    __syncthreads();
+    if (hb == 0 && tid < C) p_cs2[tid] = red[tid] + red[C + tid];
+}
+
 }  // namespace rvt
