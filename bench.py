@@ -99,7 +99,8 @@ def group_roofline(key, recs, dtype_name, mfma_peak=None):
     fb = [opmodel.model(n, r[2]) for r in recs]
     if any(x is None for x in fb):
         return None
-    rec = opmodel.roofline_entry(n, sum(x[0] for x in fb), sum(x[1] for x in fb), ms, len(recs), dtype_name, mfma_peak)
+    rec = opmodel.roofline_entry(n, sum(x[0] for x in fb), sum(x[1] for x in fb), ms, len(recs), dtype_name, mfma_peak,
+                                 executed_flops=sum(opmodel.executed(n, r[2]) for r in recs))
     rec['shape'] = list(shp)
     return rec
 
@@ -116,11 +117,11 @@ def traffic_lookup(workload_key, key):
     elif n == 'rvt_lstm_scan_fwd':
         subs = ['lstm_scan_fwd_kernel', f'DF16bLi{shp[-3]}E']
     elif n == 'rvt_mlp_fwd':
-        subs = ['mlpc_fwd_kernel' if shp[-1] == 64 else 'mlp_fwd_kernel', f'DF16bLi{shp[-1]}E']
+        subs = ['mlpc_fwd_kernel' if shp[2] == 64 else 'mlps_fwd_kernel', f'DF16bLi{shp[2]}E']      # (dtype, M, C[, stream 0])
     elif n == 'rvt_mlp_bwd_recompute_dgrad':
-        subs = ['mlpc_bwd_dgrad_kernel']
+        subs = ['mlpc_bwd_dgrad_kernel' if shp[2] == 64 else 'mlps_bwd_dgrad_kernel', 'DF16b']
     elif n in ('rvt_mlp_bwd_recompute_wgrad', 'rvt_mlp_bwd_recompute_both'):
-        subs = ['mlpc_bwd_wgrad_kernel']
+        subs = ['mlpc_bwd_wgrad_kernel' if shp[2] == 64 else 'mlps_bwd_wgrad_kernel']
     elif n == 'rvt_stem_fwd':
         subs = ['stem_fwd_kernel']
     elif n == 'rvt_stem_wgrad':
@@ -221,7 +222,7 @@ def cpu_baseline_worker(workload: str):
             ratio = json.load(f)['port_over_reference']
     except Exception:
         pass
-    out = dict(value=round(B * T / best, 3), unit='event-tensors/s', cores=ncores, kind='port',
+    out = dict(value=round(B * T / best, 3), unit='event-tensors/s', cores=ncores, kind='port', estimate=True,
                sample=f'{wl["label"].split(",")[0]} at the same resolution, B={B}, T={T}, fp32, fwd+bwd, best of {passes} '
                       f'({best:.2f} s per pass), {ncores} torch CPU threads; oracle in its ATen-op timing mode '
                       f'(F.conv2d / F.layer_norm / F.gelu, as the reference calls them)')
@@ -231,6 +232,26 @@ def cpu_baseline_worker(workload: str):
         out['reference_provenance'] = ('the unmodified reference cannot run on the GPU box; in the authoring container (8 vCPUs) the same '
                                        'B=2, T=3 probe ran the reference and the port side by side: profiles/r4/port_vs_reference.json; '
                                        'survey-time reference probe: 6.2 event-tensors/s on 8 vCPUs (BASELINE.md section 3)')
+    # BASELINE.json configs[0] as well (RVT-Tiny, Gen1 shape, T=5, batch=2, CPU-only forward - the reference's own plumbing case)
+    try:
+        wl0 = WORKLOADS['tiny_gen1']
+        cfg0d = backbone_config(wl0['size'], wl0['dataset'])
+        cfg0 = O.OracleCfg(embed_dim=cfg0d.embed_dim, dim_head=cfg0d.stage.attention.dim_head,
+                           partition_size=tuple(cfg0d.stage.attention.partition_size), conv_impl='aten')
+        m0 = build_model(wl0, torch.float32, 'cpu')
+        p0 = {k: v.detach().clone() for k, v in m0.state_dict().items()}
+        x0 = torch.randint(0, 11, (5, 2, 20, *wl0['hw']), generator=g, dtype=torch.uint8)
+        b0 = float('inf')
+        with torch.no_grad():
+            for _ in range(3):
+                t0 = time.perf_counter()
+                O.sequence_forward(x0, None, p0, cfg0, tuple(cfg0d.in_res_hw))
+                b0 = min(b0, time.perf_counter() - t0)
+        out['configs0'] = dict(value=round(10 / b0, 2), unit='event-tensors/s', kind='port', estimate=True,
+                               sample=f'BASELINE configs[0]: RVT-Tiny, Gen1 20x240x304, T=5, batch=2, fp32 forward only, best of 3 ({b0:.3f} s), '
+                                      f'{ncores} torch CPU threads (survey-time probe of the unmodified reference: 84.6 event-tensors/s on 8 vCPUs)')
+    except Exception as e:
+        out['configs0'] = dict(value=None, note=f'{type(e).__name__}: {e}'[:200])
     print(json.dumps(out))
 
 
@@ -357,6 +378,8 @@ def main():
     opt = None if args.no_optimizer else torch.optim.AdamW(params, lr=2e-4, fused=True, capturable=use_graph)
     from rvt_amd.dist import StageGradReducer
     reducer = StageGradReducer(force=args.force_reducer).attach(model) if (world > 1 or args.force_reducer) else None
+    if reducer is not None:
+        reducer.record_tail = True
 
     xs = make_batch(wl, device, seed=1 + rank)
     T, B = wl['T'], wl['B']
@@ -400,11 +423,15 @@ def main():
                   key=lambda k: sum(a.elapsed_time(b) for a, b, _ in groups[k]))
     dominant = dom_key[0]
     step_ms_instrumented = sum(v['total_ms'] for v in prof.values())
+    algorithmic_bytes_step = sum((opmodel.model(n, r[2]) or (0.0, 0.0))[1] for n, recs in timer.records.items() for r in recs)
+    algorithmic_flops_step = sum((opmodel.model(n, r[2]) or (0.0, 0.0))[0] for n, recs in timer.records.items() for r in recs)
+    executed_flops_step = sum((opmodel.executed(n, r[2]) or 0.0) for n, recs in timer.records.items() for r in recs)
     by_entry = {}
     for r in table:
-        e = by_entry.setdefault(r['kernel'], [0.0, 0.0, 0.0, 0])
+        e = by_entry.setdefault(r['kernel'], [0.0, 0.0, 0.0, 0, 0.0])
         e[0] += r['ms']; e[1] += r['algorithmic_gflop']; e[2] += r['algorithmic_gbyte']; e[3] += r['launches']
-    entry_table = [opmodel.roofline_entry(n, e[1] * 1e9, e[2] * 1e9, e[0], e[3], args.dtype) for n, e in
+        e[4] += r.get('executed_gflop', r['algorithmic_gflop'])
+    entry_table = [opmodel.roofline_entry(n, e[1] * 1e9, e[2] * 1e9, e[0], e[3], args.dtype, executed_flops=e[4] * 1e9) for n, e in
                    sorted(by_entry.items(), key=lambda kv: -kv[1][0])[:10]]
     if args.op_breakdown and rank == 0:
         with open(args.op_breakdown, 'w') as f:
@@ -468,8 +495,11 @@ def main():
 
     # eager pass: EXACTLY K steps with HIP events around every launch of the dominant entry point, on the stream it is
     # launched on.  This is the `roofline` measurement, and the headline timing too unless the graph replay below runs.
+    if reducer is not None:
+        reducer.tail_ms()                             # (drop the warm-up steps' records)
     wall, host_enqueue, per_step = timed_region(step)
     eager_ms = 1e3 * wall / args.steps
+    tails = reducer.tail_ms() if reducer is not None else []
     timer.uninstall()
     graph_note = 'off'
     if use_graph:
@@ -492,6 +522,18 @@ def main():
               f'where the host blocks on a full queue) eager_ms_per_step={eager_ms:.1f} '
               f'graph={graph_note}', file=sys.stderr, flush=True)
     timer.uninstall()
+    dist_info = None
+    if world > 1 or args.force_reducer:
+        # what RCCL itself sees, every rank's own clock, and the part of the gradient exchange the backward did not hide
+        mine = torch.tensor([1e3 * wall / args.steps, (sum(tails) / len(tails)) if tails else 0.0], device=device, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(allr, mine)
+        dist_info = {'world_size_rccl': dist.get_world_size(), 'backend': dist.get_backend(),
+                     'per_rank_ms_per_step': [round(float(t[0]), 3) for t in allr],
+                     'allreduce_tail_ms_per_rank': [round(float(t[1]), 3) for t in allr],
+                     'allreduce_tail_note': 'HIP-event time from the launch of the LAST stage bucket (stage 1, the end of the backbone '
+                                            'backward) to the completion of every bucket all-reduce of that step: the communication the '
+                                            'backward did not hide (buckets of stages 4..2 are launched while stages 3..1 still compute)'}
     if world > 1:
         tmax = torch.tensor([wall], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -539,12 +581,22 @@ def main():
             'roofline_entry_points': entry_table,
             'instrumented_step_ms': round(step_ms_instrumented, 3),
             'hbm_traffic_per_step': {'measured_bytes': step_traffic(wkey), 'source': 'profiles/latest_traffic.json (rocprofv3 FETCH_SIZE x2 + '
-                                     'WRITE_SIZE passes of this command), null when no pass of THIS workload is committed'},
+                                     'WRITE_SIZE passes of this command), null when no pass of THIS workload is committed',
+                                     # what the launches of one step move if every operand / result crosses HBM exactly once (opmodel.py, sum
+                                     # over the instrumented step) and what a fully fused stage-by-stage path would (19.4 MB per
+                                     # event tensor forward, x3 for forward + backward)
+                                     'algorithmic_gbyte_per_step': round(algorithmic_bytes_step / 1e9, 2),
+                                     'fused_minimum_gbyte_per_step': round(19.4e6 * B * T * 3 / 1e9, 2) if args.workload == 'base_1mpx' else None},
+            'flops_per_step': {'algorithmic_gflop_of_the_launches': round(algorithmic_flops_step / 1e9, 1),
+                               'executed_gflop_incl_recompute': round(executed_flops_step / 1e9, 1),
+                               'survey_8d_gflop': round(wl['f_fwdbwd'] * B * T / 1e9, 1)},
             'mfma_peak_sustained': None if not sustained else {
                 'tflops': round(sustained, 1), 'implied_clock_ghz': round(sustained * 1e12 / (256 * 4096) / 1e9, 3),
                 'whole_step_frac_of_sustained': round(path_tflops / sustained, 4),
                 'method': 'rvt_probe_mfma: 4096 workgroups of nothing but independent v_mfma_f32_32x32x16_bf16, HIP-event timed'},
         }
+        if dist_info is not None:
+            out['distributed'] = dist_info
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.workload)
         print(json.dumps(out), flush=True)

@@ -4,9 +4,12 @@ MEASUREMENT INFRASTRUCTURE (not part of the product path).  Round 3's bench coul
 `roofline` could never name the worst kernels.  `model(name, args)` returns, from the launch's own
 arguments (positions per include/rvt_hip.h):
 
-  flops  MFMA-side work the OPERATOR is defined to do, 2*MAC, including the products a recompute-style backward re-does by
-         design (e.g. the reverse ConvLSTM scan = gate recompute 16 + input gradient 16 + weight gradient 16 = 48 C^2 per
-         token-step; the judge's constant).  Element-wise work (LayerNorm, softmax, GELU, gates) is not counted.
+  flops  ALGORITHMIC MFMA-side work of the operator, 2*MAC: the products the reference's forward / autograd
+         performs for the same result - e.g. 16 M C^2 for each of {MLP forward, its input gradients, its weight gradients}.
+         Products a recompute-style backward re-does (fc1 / GELU recomputed from xmid, q / k / v / P recomputed from the block
+         input, ConvLSTM gates recomputed in the reverse scan) are NOT counted here: `executed(name, args)` returns the
+         recompute-inclusive figure separately (round 5; the round-4 line priced the recompute as algorithmic work and
+         printed 0.20 where 0.16 was right).  Element-wise work (LayerNorm, softmax, GELU, gates) is not counted.
   bytes  algorithmic HBM bytes: every operand and result tensor crosses HBM exactly once (weights once per launch);
          intermediates that the operator's definition keeps on chip are not counted.
   Roof: arithmetic intensity flops/bytes against the ridge peak_flops / 8 TB/s decides which roof bounds the launch.
@@ -88,31 +91,31 @@ def model(name: str, a) -> Optional[Tuple[float, float]]:
     if name == 'rvt_mlp_bwd_dgrad':                      # fc2 dgrad * gp -> dh (stored) -> fc1 dgrad -> LN2' + residual
         e, M, C = _elt(a[10]), a[11], a[12]
         return 16.0 * M * C * C, (11.0 * M * C + 8 * C * C) * e
-    if name == 'rvt_mlp_bwd_recompute_dgrad':            # recompute fc1 (8) + both input gradients (16)
+    if name == 'rvt_mlp_bwd_recompute_dgrad':            # both input gradients (16); executed: + recompute of fc1 (8)
         e, M, C = _elt(a[11]), a[12], a[13]
-        return 24.0 * M * C * C, (3.0 * M * C + 12 * C * C) * e
-    if name == 'rvt_mlp_bwd_recompute_wgrad':            # recompute fc1 (8) + fc2 dgrad for dh (8) + both weight gradients (16)
+        return 16.0 * M * C * C, (3.0 * M * C + 12 * C * C) * e
+    if name == 'rvt_mlp_bwd_recompute_wgrad':            # both weight gradients (16); executed: + recompute of fc1 (8) + fc2 dgrad for dh (8)
         e, M, C = _elt(a[12]), a[13], a[14]
-        return 32.0 * M * C * C, 2.0 * M * C * e + 8.0 * C * C * (e + 4)
-    if name == 'rvt_mlp_bwd_recompute_both':             # recompute fc1 (8) + fc2 dgrad for dh (8) + both weight gradients (16) + fc1 dgrad (8)
+        return 16.0 * M * C * C, 2.0 * M * C * e + 8.0 * C * C * (e + 4)
+    if name == 'rvt_mlp_bwd_recompute_both':             # input + weight gradients (32); executed: + recompute of fc1 (8)
         e, M, C = _elt(a[16]), a[17], a[18]
-        return 40.0 * M * C * C, 3.0 * M * C * e + 8.0 * C * C * (e + 4)
+        return 32.0 * M * C * C, 3.0 * M * C * e + 8.0 * C * C * (e + 4)
     if name == 'rvt_attn_fwd':
         e, F, H, W, C, dh, ph, pw = _elt(a[2]), *a[3:10]
         M, L = F * H * W, ph * pw
         return 4.0 * M * L * C, 4.0 * M * C * e
-    if name == 'rvt_attn_bwd':                           # recompute S (2) + dV, dP, dQ, dK (8)
+    if name == 'rvt_attn_bwd':                           # dV, dP, dQ, dK (8 L C); executed: + recompute of S (2)
         e, F, H, W, C, dh, ph, pw = _elt(a[3]), *a[4:11]
         M, L = F * H * W, ph * pw
-        return 10.0 * M * L * C, 7.0 * M * C * e
+        return 8.0 * M * L * C, 7.0 * M * C * e
     if name == 'rvt_attn_block_fwd':                     # LN1 -> qkv (6C^2) -> attention (4LC) -> proj (2C^2) -> gamma + residual
         e, F, H, W, C, dh, ph, pw = _elt(a[10]), *a[11:18]
         M, L = F * H * W, ph * pw
         return M * (8.0 * C * C + 4.0 * L * C), ((2.0 + (1 if P(2) else 0)) * M * C + 4 * C * C) * e
-    if name == 'rvt_attn_block_bwd':                     # recompute qkv (6C^2) + S (2LC); dproj (2C^2), core (8LC), du (6C^2)
+    if name == 'rvt_attn_block_bwd':                     # dproj (2C^2), core (8LC), du (6C^2); executed: + recompute of qkv (6C^2) + S (2LC)
         e, F, H, W, C, dh, ph, pw = _elt(a[12]), *a[13:20]
         M, L = F * H * W, ph * pw
-        return M * (14.0 * C * C + 10.0 * L * C), ((6.0 + (1 if P(4) else 0)) * M * C + 7 * C * C) * e
+        return M * (8.0 * C * C + 8.0 * L * C), ((6.0 + (1 if P(4) else 0)) * M * C + 7 * C * C) * e
     if name == 'rvt_lstm_fwd':
         e, M, C = _elt(a[8]), a[9], a[10]
         return 16.0 * M * C * C, 1.0 * M * C * (3 * e + 8 + (4 * e if P(7) else 0)) + 8.0 * C * C * e
@@ -132,7 +135,7 @@ def model(name: str, a) -> Optional[Tuple[float, float]]:
     if name == 'rvt_lstm_scan_bwd':
         e, M, C, T = _elt(a[17]), a[18], a[19], a[20]
         saved_gates, wgrad, dz = P(16), P(13), P(10)
-        fl = (16.0 if saved_gates else 32.0) + (16.0 if wgrad else 0.0)      # gate recompute + dgrad (+ in-kernel weight gradient)
+        fl = 16.0 + (16.0 if wgrad else 0.0)                                 # dgrad (+ in-kernel weight gradient); executed: + gate recompute (16) unless the gates were saved
         rows = (2 + 4 if saved_gates else 4) + 1 + (4 if dz else 0)          # (c, dH, gates | x, h, c, dH) in, dx out (+ dz out)
         return fl * M * C * C * T, 1.0 * rows * M * C * T * e + 16.0 * M * C + 16 * C * C * e
     if name == 'rvt_dwconv_fwd':
@@ -170,8 +173,36 @@ def model(name: str, a) -> Optional[Tuple[float, float]]:
     return None
 
 
-def roofline_entry(name: str, flops: float, bytes_: float, ms: float, launches: int, dtype: str, mfma_peak_tflops: float = None):
-    """One roofline record for `launches` launches that took `ms` in total."""
+def executed(name: str, a) -> Optional[float]:
+    """MFMA-side FLOPs the launch actually EXECUTES: model()'s algorithmic figure plus the products a recompute-style backward
+    re-does by design.  Equal to the algorithmic figure for every other entry point."""
+    m = model(name, a)
+    if m is None:
+        return None
+    fl = m[0]
+    P = lambda i: a[i] is not None
+    if name == 'rvt_mlp_bwd_recompute_dgrad':
+        return fl + 8.0 * a[12] * a[13] * a[13]
+    if name == 'rvt_mlp_bwd_recompute_wgrad':
+        return fl + 16.0 * a[13] * a[14] * a[14]
+    if name == 'rvt_mlp_bwd_recompute_both':
+        return fl + 8.0 * a[17] * a[18] * a[18]
+    if name == 'rvt_attn_bwd':
+        F, H, W, C, dh, ph, pw = a[4:11]
+        return fl + 2.0 * F * H * W * ph * pw * C
+    if name == 'rvt_attn_block_bwd':
+        F, H, W, C, dh, ph, pw = a[13:20]
+        return fl + F * H * W * (6.0 * C * C + 2.0 * ph * pw * C)
+    if name == 'rvt_lstm_scan_bwd' and not P(16):
+        M, C, T = a[18], a[19], a[20]
+        return fl + 16.0 * M * C * C * T
+    return fl
+
+
+def roofline_entry(name: str, flops: float, bytes_: float, ms: float, launches: int, dtype: str, mfma_peak_tflops: float = None,
+                   executed_flops: float = None):
+    """One roofline record for `launches` launches that took `ms` in total.  `flops` = ALGORITHMIC (what `frac` is computed from);
+    `executed_flops` (optional) = recompute-inclusive, reported beside it."""
     peak = mfma_peak_tflops or PEAK_TFLOPS[dtype]
     tfl = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     gbs = bytes_ / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
@@ -183,6 +214,9 @@ def roofline_entry(name: str, flops: float, bytes_: float, ms: float, launches: 
            'arithmetic_intensity_flop_per_byte': round(ai, 1) if ai != float('inf') else None,
            'hbm_gbs': round(gbs, 1), 'hbm_frac': round(gbs / HBM_PEAK_GBS, 4),
            'mfma_tflops': round(tfl, 2), 'mfma_frac': round(tfl / peak, 4)}
+    if executed_flops is not None and executed_flops != flops:
+        rec['executed_gflop'] = round(executed_flops / 1e9, 2)
+        rec['executed_mfma_tflops'] = round(executed_flops / (ms * 1e-3) / 1e12, 2) if ms > 0 else 0.0
     if bound == 'hbm':
         rec.update(achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(gbs / HBM_PEAK_GBS, 4))
     else:

@@ -174,6 +174,22 @@ elif op in ('scan_fwd_s1', 'scan_bwd_s1', 'scan_fwd_s1_v1', 'scan_bwd_s1_v1'):  
         wt = wl.t().contiguous()
         dw, db = torch.zeros(4 * Cc, 2 * Cc, device=dev), torch.zeros(4 * Cc, device=dev)
         fn = lambda: ops.lstm_scan_bwd(xa, Hall, Cs, None, dH, None, wl, wt, bl, dxa, None, dh0, dc0, dw=dw, db=db)
+elif op in ('mlps_fwd', 'mlps_dgrad', 'mlps_wgrad'):       # round 5: streamed-weight MLP kernels at the stage-2 shape (csrc/mlp_stream.hpp)
+    del x, dy4
+    Ms, Cs_ = 1935360, 128
+    xs, dys = rnd(Ms, Cs_), rnd(Ms, Cs_)
+    lw, lb = torch.ones(Cs_, device=dev), torch.zeros(Cs_, device=dev)
+    w1, w2 = rnd(4 * Cs_, Cs_) * 0.1, rnd(Cs_, 4 * Cs_) * 0.1
+    b1, b2, gam = torch.zeros(4 * Cs_, device=dev), torch.zeros(Cs_, device=dev), torch.ones(Cs_, device=dev)
+    w2gt, w1t = w2.t().contiguous(), w1.t().contiguous()
+    z = lambda *s: torch.zeros(*s, device=dev)
+    dlw, dlb, dw1, db1, s2, cs2 = z(Cs_), z(Cs_), z(4 * Cs_, Cs_), z(4 * Cs_), z(Cs_, 4 * Cs_), z(Cs_)
+    if op == 'mlps_fwd':
+        fn = lambda: ops.mlp_fwd(xs, lw, lb, w1, b1, w2, b2, gam, 1e-5, want_grad=False)
+    elif op == 'mlps_dgrad':
+        fn = lambda: ops.mlp_bwd_recompute_dgrad(dys, xs, lw, lb, w1, b1, w2gt, w1t, dlw, dlb, 1e-5)
+    else:
+        fn = lambda: ops.mlp_bwd_recompute_wgrad(dys, xs, lw, lb, w1, b1, w2gt, dw1, db1, s2, cs2, 1e-5)
 for _ in range(3):
     fn()
 torch.cuda.synchronize()

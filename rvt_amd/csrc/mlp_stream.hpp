@@ -88,7 +88,9 @@ __device__ __forceinline__ void ms_piece_offsets(int (&v)[NPW], int wave, int la
 }
 
 // ===================================================================================================== forward
-template <class T, int C, int WPB, int MINW>
+// ABL: ablation bits for profiles/probes/mlps_probe.hip (0 in the library): 1 no weight stream after the first two chunks (no LDS-DMA,
+// no vmcnt wait), 2 no workgroup barrier, 4 GELU replaced by a multiply (no table gather), 8 no row loads / stores inside the tile loop
+template <class T, int C, int WPB, int MINW, int ABL = 0>
 __global__ void __launch_bounds__(64 * WPB, MINW)
 mlps_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, const float* __restrict__ ln_w, const float* __restrict__ ln_b,
                 const T* __restrict__ W1, const float* __restrict__ b1, const T* __restrict__ W2, const float* __restrict__ b2,
@@ -131,6 +133,7 @@ mlps_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, const float* _
     const int n_wg = (n_tiles + WPB - 1) / WPB;           // tiles of the workgroup: every wave walks the same count (barriers)
     char* const pf_dummy = smem + 2 * G::STAGE + G::NCONST * 4 + GeluTab<T>::BYTES;      // 1 KiB per wave: landing zone of the L2 warm-up
     issue(0, 0);
+    if (ABL & 1) { issue(1, 1); pp_wait_vm<0>(); __syncthreads(); }
 
     // Register plan (two waves per SIMD = 256 registers): a tile's raw rows are dead after the LayerNorm (the residual is read
     // again, from L2, during the LAST chunk); the next tile's rows are NOT prefetched into registers but pulled into L2 by
@@ -162,8 +165,9 @@ mlps_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, const float* _
         for (int cb = 0; cb < NCB; cb++) acc_zero(oacc[cb]);
         auto boundary = [&](int ch, int stage_next) __attribute__((always_inline)) {
             // chunk ch has landed (this wave's pieces: vmcnt; everybody's: barrier) and every wave is done with the other stage
-            pp_wait_vm<0>();
-            pp_barrier();
+            if (!(ABL & 1)) pp_wait_vm<0>();
+            if (!(ABL & 2)) pp_barrier();
+            if (ABL & 1) return;
             if (ch + 1 < NCH) issue(ch + 1, stage_next);
             else if (more) issue(0, stage_next);
         };
@@ -178,7 +182,12 @@ mlps_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, const float* _
 #pragma unroll
                 for (int ks = 0; ks < KS; ks++) mma32(h, ms_load_frag<T>(W1s + 32 * jj * 128, G::HC, rb1, 2 * ks), uf[ks]);
                 float g[16];
-                GeluTab<T>::eval16(lut, h, g);
+                if (ABL & 4) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) g[r] = 0.5f;
+                } else {
+                    GeluTab<T>::eval16(lut, h, g);
+                }
 #pragma unroll
                 for (int r = 0; r < 16; r++) g[r] = mul_nopack(g[r], h[r], r);
                 frag_t<T> gf[2];

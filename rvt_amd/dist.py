@@ -28,6 +28,11 @@ class StageGradReducer:
         self.average = average
         self.force = force          # run the collective even at world_size 1 (single-GPU smoke of the RCCL path)
         self._pending: List = []
+        # observability of the overlap claim (bench.py --gpus N): HIP events on the compute stream at the launch of the LAST bucket
+        # of a backward and behind the waits of finish(); their distance is the communication the backward did NOT hide
+        self.record_tail = False
+        self._tail_events: List = []
+        self._ev_last_launch = None
 
     def attach(self, model) -> 'StageGradReducer':
         model._stage_grad_hook = self.on_stage_done
@@ -61,8 +66,25 @@ class StageGradReducer:
             else:
                 bucket.div_(ws)
         self._pending.append(dist.all_reduce(bucket, op=op, group=self.pg, async_op=True))
+        if self.record_tail and bucket.is_cuda:
+            self._ev_last_launch = torch.cuda.Event(enable_timing=True)
+            self._ev_last_launch.record()
 
     def finish(self) -> None:
+        had = bool(self._pending)
         for w in self._pending:
             w.wait()
         self._pending.clear()
+        if had and self.record_tail and self._ev_last_launch is not None:
+            done = torch.cuda.Event(enable_timing=True)
+            done.record()
+            self._tail_events.append((self._ev_last_launch, done))
+            self._ev_last_launch = None
+
+    def tail_ms(self) -> List[float]:
+        """Per backward since the last call: GPU time between the launch of the last stage bucket's all-reduce (in stream order:
+        the end of the backbone backward) and the point where every collective of that backward has completed."""
+        torch.cuda.synchronize()
+        out = [a.elapsed_time(b) for a, b in self._tail_events]
+        self._tail_events.clear()
+        return out

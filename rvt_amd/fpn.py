@@ -58,15 +58,20 @@ class _BaseConvFn(torch.autograd.Function):
         if training:
             L.call('rvt_bn_stats', L.ptr(y0), L.ptr(stats[0]), L.ptr(stats[1]), L.dtype_code(dt), rows, Cout, st)
             if sync:
-                cnt = torch.tensor([float(rows)], device=dev)
-                _bn_reduce(stats)
-                _bn_reduce(cnt)
-                count = int(cnt.item())
+                # ONE exchange of [sum x | sum x^2 | rows] (the 2 C + 1 values torch's SyncBatchNorm gathers); the global row count comes
+                # back to the host because the finalize kernel takes it by value (ranks may hold different numbers of labelled frames)
+                packed = torch.cat([stats.reshape(-1), torch.tensor([float(rows)], device=dev)])
+                _bn_reduce(packed)
+                stats.copy_(packed[:2 * Cout].view(2, Cout))
+                count = int(packed[2 * Cout].item())
         fin = torch.empty(4, Cout, dtype=f32, device=dev)                                 # mean, rstd, scale, shift
         bn = mod.bn
         g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
         y = torch.empty_like(y0)
-        mom = float(bn.momentum if bn.momentum is not None else 0.1)
+        if bn.momentum is None or not bn.track_running_stats:
+            raise NotImplementedError('rvt_amd.fpn.BaseConv: BatchNorm2d with momentum=None (cumulative average) or '
+                                      'track_running_stats=False is not built (no shipped config uses either)')
+        mom = float(bn.momentum)
         rm, rv = (L.ptr(bn.running_mean), L.ptr(bn.running_var)) if bn.track_running_stats else (None, None)
         if training:                                                                      # finalize + activation in one launch
             L.call('rvt_bn_train_act_fwd', L.ptr(y0), L.ptr(stats[0]), L.ptr(stats[1]), count, L.ptr(g32), L.ptr(b32), float(bn.eps), mom,
@@ -118,6 +123,11 @@ class _BaseConvFn(torch.autograd.Function):
                 dwp = torch.zeros(Cout, k * k * Cin, dtype=torch.float32, device=dev)
             ops.conv_wgrad(x, dconv, dwp, k, s, pad)
             dw = weights.unpack_conv_wgrad(dwp, Cin, k).to(w.dtype)
+            if ctx.pk is not None and dw.untyped_storage().data_ptr() == dwp.untyped_storage().data_ptr():
+                # 1 x 1 convolutions: the unpack is a view of the ConvPack arena.  AccumulateGrad would adopt it as .grad, and the
+                # arena is zeroed / rewritten by the next forward / backward (gradient accumulation, zero_grad(set_to_none=False),
+                # retain_graph): hand autograd a tensor of its own
+                dw = dw.clone()
         return dx, dw, ds_local[1].to(w.dtype), ds_local[0].to(w.dtype), None, None, None
 
 

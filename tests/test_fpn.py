@@ -198,3 +198,32 @@ def test_fpn_eval_fused_conv_bn_silu_matches_unfused(backend, dtype, tol):
         m.lateral_conv0.bn.running_var.mul_(4.0)
         changed = m(xs)
     assert _rel(changed[2].float().cpu().numpy(), fused[2].float().cpu().numpy()) > 1e-3
+
+
+def test_fpn_gradient_accumulation_over_micro_batches(backend):
+    """Two backward passes without zeroing in between must ADD (the weight gradient of a 1 x 1 BaseConv was a view of the
+    ConvPack scratch arena that the next forward zeroes - the accumulated .grad was wiped and the second pass counted twice)."""
+    dev = backend
+    m, _ = _build('fpn_micro', dev, torch.float32)
+    m.train()
+    xs = {s: torch.from_numpy(a).to(dev) for s, a in cg.make_inputs('fpn_micro').items()}
+    cots = [torch.from_numpy(a).to(dev) for a in cg.make_cotangents('fpn_micro')]
+
+    def run(scale):
+        outs = m({s: x * scale for s, x in xs.items()})
+        sum((o.float() * ct).sum() for o, ct in zip(outs, cots)).backward()
+    single = []
+    for scale in (1.0, 0.5):
+        m.zero_grad(set_to_none=True)
+        run(scale)
+        single.append({k: p.grad.clone() for k, p in m.named_parameters()})
+    m.zero_grad(set_to_none=True)
+    run(1.0)
+    run(0.5)                                            # accumulates into the existing .grad tensors
+    for k, p in m.named_parameters():
+        want = single[0][k] + single[1][k]
+        assert _rel(p.grad.cpu().numpy(), want.cpu().numpy()) <= 1e-5, k
+    m.zero_grad(set_to_none=False)                      # in-place zero, then one more pass: must equal that pass alone
+    run(1.0)
+    for k, p in m.named_parameters():
+        assert _rel(p.grad.cpu().numpy(), single[0][k].cpu().numpy()) <= 1e-5, k
