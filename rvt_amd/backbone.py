@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 
 from . import ops, tuning
-from .stage import SideStream, StageGeom, stage_seq_backward, stage_seq_forward
+from .stage import SideStream, StageGeom, stage_seq_backward, stage_seq_forward, use_lstm_scan
 from .weights import ModelWeights, param_signature, param_versions, round8
 
 Tensor = torch.Tensor
@@ -369,8 +369,23 @@ class _BackboneSeqFn(torch.autograd.Function):
         # the end of backward is slower — 162 vs 145 ms/step — the caching allocator cannot recycle the operands the side
         # stream still holds and the extra resident work competes with the next stage's critical path)
         side = SideStream(ctx.svs[ns - 1].y0)
+        held_hooks: List[int] = []      # deferred mode: stages whose weight gradients are still queued / running on the side stream
+
+        def call_hook(sj: int) -> None:
+            if hook is None:
+                return
+            try:                        # e.g. rvt_amd.dist.StageGradReducer: start this stage's all-reduce now
+                hook(sj, mw.grads[sj].param_region, accumulated=accumulate[sj])
+            except TypeError as e:      # a user-installed two-argument hook (the pre-round-3 signature)
+                if 'accumulated' not in str(e):
+                    raise
+                hook(sj, mw.grads[sj].param_region)
         for si in range(ns - 1, -1, -1):
             g = geoms[si]
+            # deferred weight gradients (tuning.route_wgrad_stream = 2): those of the stage above start now, beside this stage's reverse
+            # scan; this stage queues its own iff the stage below scans per step (a chip-filling scan kernel leaves nothing to fill)
+            side.flush()
+            side.deferring = side.defer_mode and si > 0 and not use_lstm_scan(dt, geoms[si - 1].C, mw.stages[si - 1].dws, T, True)
             dF, dC = gout[2 * si], gout[2 * si + 1]
             if si == ns - 1:
                 dH = None if dF is None else _to_cl(dF, dt)
@@ -386,17 +401,21 @@ class _BackboneSeqFn(torch.autograd.Function):
                                                 mw.grads[si], f'stages.{si}.', side=side,
                                                 finalize=lambda si=si: mw.finalize_stage_grads(si))
             d_from_above = d_in
-            if hook is not None:          # e.g. rvt_amd.dist.StageGradReducer: start this stage's all-reduce now
-                try:
-                    hook(si, mw.grads[si].param_region, accumulated=accumulate[si])
-                except TypeError as e:      # a user-installed two-argument hook (the pre-round-3 signature)
-                    if 'accumulated' not in str(e):
-                        raise
-                    hook(si, mw.grads[si].param_region)
+            for sj in held_hooks:         # (stage_seq_backward ended with side.join(): the stage above is complete now)
+                call_hook(sj)
+            held_hooks = []
+            if side.deferring:
+                held_hooks.append(si)
+            else:
+                call_hook(si)
             if ctx.needs_input_grad[4 + 2 * si]:
                 state_grads[2 * si] = dh0.permute(0, 3, 1, 2)
                 state_grads[2 * si + 1] = dc0.permute(0, 3, 1, 2)
             ctx.svs[si] = None
+        if side.flush():                  # (cannot happen with the rule above - stage 1 never defers - but a queue must never be dropped)
+            side.join()
+        for sj in held_hooks:
+            call_hook(sj)
         finish = getattr(mod, '_stage_grad_finish', None)
         if finish is not None:            # data parallel: order everything downstream after the per-stage all-reduces
             finish()

@@ -81,8 +81,16 @@ class SideStream:
     def __init__(self, like: Tensor):
         # off by default since round 2: with the fused stage-1 kernels the step on ONE stream costs exactly the sum of its
         # kernels' isolated times (98.6 ms, profiles/r2/op_breakdown_serial_r2i.txt) and the second stream only adds
-        # contention (100.7 ms); tuning.route_wgrad_stream = 1 re-enables it
-        self.enabled = like.is_cuda and tuning.get('route_wgrad_stream') == 1
+        # contention (100.7 ms); tuning.route_wgrad_stream = 1 re-enables it.
+        # route_wgrad_stream = 2 (round 5): DEFERRED - the weight-gradient launches of a stage whose successor in the backward
+        # order opens with a per-step reverse ConvLSTM scan (42 launches of 23 - 90 tiles on 256 CUs) are queued and start on
+        # the side stream when that scan starts, i.e. they fill a chip that is two thirds idle instead of competing with full grids.
+        mode = tuning.get('route_wgrad_stream') if like.is_cuda else 0
+        self.enabled = mode in (1, 2)
+        self.defer_mode = mode == 2
+        self.deferring = False          # set per stage by the backward driver (rvt_amd/backbone.py)
+        self._queue = []
+        self._flushed = False
         self._keep = []
         if self.enabled:
             key = like.device.index
@@ -94,6 +102,12 @@ class SideStream:
     def run(self, fn, *operands):
         if not self.enabled:
             return fn()
+        if self.defer_mode:
+            if not self.deferring:
+                return fn()
+            self._queue.append(fn)
+            self._keep.extend(t for t in operands if t is not None)
+            return None
         ev = torch.cuda.Event()
         ev.record(self.main)
         self._keep.extend(t for t in operands if t is not None)
@@ -101,10 +115,32 @@ class SideStream:
             self.stream.wait_event(ev)
             return fn()
 
+    def flush(self) -> bool:
+        """Deferred mode: start the queued launches on the side stream, ordered after everything the main stream has issued."""
+        if not (self.enabled and self.defer_mode and self._queue):
+            return False
+        ev = torch.cuda.Event()
+        ev.record(self.main)
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ev)
+            for fn in self._queue:
+                fn()
+        self._queue = []
+        self._flushed = True
+        return True
+
     def join(self):
-        if self.enabled:
-            self.main.wait_stream(self.stream)
-            self._keep.clear()
+        if not self.enabled:
+            return
+        if self.defer_mode:
+            if self._flushed:
+                self.main.wait_stream(self.stream)
+                self._flushed = False
+                if not self._queue:
+                    self._keep.clear()
+            return
+        self.main.wait_stream(self.stream)
+        self._keep.clear()
 
 
 @dataclass
@@ -315,7 +351,7 @@ def stage_seq_backward(sw: StageWeights, g: StageGeom, sv: StageSaved, dH: Optio
         side = SideStream(dx)
     h_seg = sv.Hall[:T].reshape(F_, H, W, C) if dws is None else sv.hconv.view(F_, H, W, C)
 
-    def lstm_wgrad_fn():
+    def lstm_wgrad_fn(dz=dz, h_seg=h_seg):          # (bound now: `dz` is deleted below and the launch may be deferred)
         ops.lstm_wgrad(dz.view(F_, H, W, 4 * C), sv.xin_lstm, h_seg, G(pre + 'lstm.conv1x1.weight').view(4 * C, 2 * C),
                        G(pre + 'lstm.conv1x1.bias'))
     if not lstm_wgrad_done:
@@ -429,7 +465,7 @@ def stage_seq_backward(sw: StageWeights, g: StageGeom, sv: StageSaved, dH: Optio
         ops.token_mask_bwd(dx, sv.mask, G(pre + 'mask_token').view(C))            # also zeroes dx on masked tokens
     dy0 = ops.layernorm_bwd(sv.y0, sw.ln_w, dx, None, G(pre + 'downsample_cf2cl.norm.weight'),
                             G(pre + 'downsample_cf2cl.norm.bias'), g.eps)
-    def conv_wgrad_fn():
+    def conv_wgrad_fn(dy0=dy0):
         if sv.inp.dtype == torch.uint8:
             ops.stem_wgrad(sv.inp, dy0, G('raw/conv'), g.H_in, g.W_in)
         else:

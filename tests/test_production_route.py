@@ -274,3 +274,29 @@ def test_simota_tail_at_1mpx_batch_vs_oracle(production_route):
     assert float((piou.cpu() - wpiou).abs().max()) <= 1e-5
     assert float((ls.detach().cpu() - want).abs().max()) <= 1e-4 * float(want.abs().max())
     assert float((det.cpu() - O.to_infer(pred)).abs().max()) <= 1e-3 * float(pred.abs().max())
+
+
+def test_deferred_weight_gradient_stream_gives_identical_gradients():
+    """tuning.route_wgrad_stream = 2 (round 5): the weight-gradient launches of stage 4 are queued and start on a second stream beside
+    the per-step reverse scan of stage 3.  Same kernels, same operands, same launch geometry: every gradient must equal the one-stream
+    route up to the order of the fp32 atomics that fold the LayerNorm parameter gradients (and the per-stage hooks must still see
+    complete buckets)."""
+    from rvt_amd import tuning as tn
+    res = {}
+    for mode in (0, 2):
+        with tn.override(route_wgrad_stream=mode):
+            m = _bench_model(torch.bfloat16, 'tiny', 'gen1')
+            seen = []
+            m._stage_grad_hook = lambda si, bucket, accumulated=False: seen.append((si, float(bucket.abs().sum())))
+            g = torch.Generator(device=DEV).manual_seed(3)
+            xs = torch.randint(0, 11, (4, 2, 20, 240, 304), generator=g, dtype=torch.uint8, device=DEV)
+            feats, _ = m.forward_sequence(xs, None)
+            torch.autograd.backward([feats[s] for s in (2, 3, 4)], [torch.ones_like(feats[s]) for s in (2, 3, 4)])
+            torch.cuda.synchronize()
+            res[mode] = ({k: p.grad.clone() for k, p in m.named_parameters()}, sorted(seen))
+    assert [s for s, _ in res[2][1]] == [0, 1, 2, 3]
+    for (s0, v0), (s2, v2) in zip(res[0][1], res[2][1]):
+        assert abs(v0 - v2) <= 1e-5 * abs(v0), (s0, v0, v2)
+    for k, a in res[0][0].items():
+        b = res[2][0][k]
+        assert float((a - b).abs().max()) <= 1e-5 * max(float(a.abs().max()), 1e-30), k
