@@ -61,6 +61,10 @@ int main(int argc, char** argv) {
         {"no table gather (4)", run_fwd<4>(b, 10)},
         {"no stream, no barrier, no gather (7)", run_fwd<7>(b, 10)},
         {"forward, full kernel (again)", run_fwd<0>(b, 10)},
+        {"v1: 7 + no fragment reads (15)", run_fwd<15>(b, 10)},
+        {"v1: no fragment reads only (8)", run_fwd<8>(b, 10)},
+        {"v1: 15 + split fc1 chain (31)", run_fwd<31>(b, 10)},
+        {"v1: split fc1 chain only (16)", run_fwd<16>(b, 10)},
     };
     printf("mlps forward M = %d (%.1f GFLOP)\n", M, fl * 1e-9);
     for (auto& x : r) printf("  %-40s %8.3f ms   %7.1f TFLOP/s\n", x.name, x.ms, fl / x.ms * 1e-9);

@@ -179,8 +179,20 @@ mlps_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, const float* _
             for (int jj = 0; jj < JPC; jj++) {
                 f32x16 h;
                 acc_load_rows(h, kst + G::K_B1 + ch * G::HC + 32 * jj, half);    // fc1 bias = initial value of the accumulator
+                if (ABL & 16) {                           // (probe: two accumulator chains of four instead of one of eight)
+                    f32x16 h2;
+                    acc_zero(h2);
 #pragma unroll
-                for (int ks = 0; ks < KS; ks++) mma32(h, ms_load_frag<T>(W1s + 32 * jj * 128, G::HC, rb1, 2 * ks), uf[ks]);
+                    for (int ks = 0; ks < KS; ks += 2) {
+                        mma32(h, (ABL & 8) ? uf[(ks + 1) % KS] : ms_load_frag<T>(W1s + 32 * jj * 128, G::HC, rb1, 2 * ks), uf[ks]);
+                        mma32(h2, (ABL & 8) ? uf[(ks + 2) % KS] : ms_load_frag<T>(W1s + 32 * jj * 128, G::HC, rb1, 2 * ks + 2), uf[ks + 1]);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; r++) h[r] += h2[r];
+                } else {
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) mma32(h, (ABL & 8) ? uf[(ks + 1) % KS] : ms_load_frag<T>(W1s + 32 * jj * 128, G::HC, rb1, 2 * ks), uf[ks]);
+                }
                 float g[16];
                 if (ABL & 4) {
 #pragma unroll
@@ -197,7 +209,7 @@ mlps_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, const float* _
                 for (int cb = 0; cb < NCB; cb++)
 #pragma unroll
                     for (int q = 0; q < 2; q++)
-                        mma32(oacc[cb], ms_load_frag<T>(W2s + cb * 32 * 128, C, rb2, (G::HC / 8 / JPC) * jj + 2 * q), gf[q]);
+                        mma32(oacc[cb], (ABL & 8) ? uf[cb + q] : ms_load_frag<T>(W2s + cb * 32 * 128, C, rb2, (G::HC / 8 / JPC) * jj + 2 * q), gf[q]);
             }
         };
         // ---- chunk 0: the previous tile's rows leave behind the barrier
@@ -259,6 +271,13 @@ mlps_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, const float* _
         for (int ks = 0; ks < KS; ks++) frag_store<T>(xout + (size_t)prow * C + (2 * ks + half) * 8, orow[ks]);
     }
 }
+
+// (Round 5, measured and not kept - profiles/probes/mlps_probe.hip, profiles/r5/mlps_probe.txt: a three-stage ring with the fc1 product of
+//  hidden block j+1 issued before the GELU of block j (two pre-activation accumulators), and the same ring with the eight W1 / W2
+//  fragments of a product requested one product ahead in explicit register sets: 0.74 ms both, against 0.75 ms for the kernel above.
+//  Ablations of the kernel above at 1.94 M tokens: no weight stream 0.73, no barrier 0.67, neither 0.62, no table gather 0.61, none of
+//  the three 0.52, and additionally no fragment reads at all 0.49 ms = 1.03 PFLOP/s: the floor is the two-waves-per-SIMD MFMA / VALU
+//  alternation itself, not LDS latency.)
 
 // ============================================================================ backward: input-gradient chain
 // dh[m][j] = (dxout (W2 gamma))[m][j] * GELU'(h[m][j]);  dv2 = dh W1;  dxmid = dxout + LN2'(dv2; xmid);  dln_w / dln_b += .
