@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.argv = ['bench.py']
 import bench
 
-wl = dict(bench.WORKLOADS['base_1mpx']); wl['B'] = int(os.environ.get('HP_B', wl['B']))
+wl = dict(bench.WORKLOADS[os.environ.get('HP_WL', 'base_1mpx')]); wl['B'] = int(os.environ.get('HP_B', wl['B']))
 dev = torch.device('cuda', 0)
 model = bench.build_model(wl, torch.bfloat16, dev)
 params = list(model.parameters())

@@ -144,7 +144,7 @@ int rvt_mlp_bwd_dgrad(const void* dxout, const void* gp, const void* xmid, void*
 // and the weight gradients from (dxout, xmid) alone.  Built where the whole set of weight-gradient accumulators fits
 // the register file of one workgroup: C == 64.
 int rvt_mlp_bwd_fused_supported(int dtype, int C) {
-    if (C == 128) return dtype == RVT_BF16 && mlp_stream_on(dtype, C);      // streamed-weight kernels (csrc/mlp_stream.hpp); fp32: forward + input gradient only
+    if (C == 128) return mlp_stream_on(dtype, C);      // streamed-weight kernels (csrc/mlp_stream.hpp); fp32 (parity twin): weight gradients op by op
     return (dtype == RVT_BF16 || dtype == RVT_F32) && C == 64;
 }
 }  // extern "C"
@@ -173,7 +173,11 @@ static int msw_streams(int M) {
 extern "C" {
 size_t rvt_mlp_bwd_fused_ws_floats(int dtype, int C, int M) {
     if (!rvt_mlp_bwd_fused_supported(dtype, C)) return 0;
-    if (C == 128) return (size_t)msw_streams(M) * ((size_t)2 * 4 * C * C + 2 * 4 * C + C);
+    if (C == 128 && dtype == RVT_BF16) return (size_t)msw_streams(M) * ((size_t)2 * 4 * C * C + 2 * 4 * C + C);
+    if (C == 128) {       // fp32: LN2 output + GELU + GELU' + dh recomputed into the workspace, then the split-K scratch of the larger weight gradient
+        const size_t a = rvt_wgrad_workspace_floats(dtype, C, 4 * C, M, 1), b = rvt_wgrad_workspace_floats(dtype, 4 * C, C, M, 1);
+        return (size_t)13 * M * C + (a > b ? a : b);
+    }
     size_t grid = dtype == RVT_BF16 ? mlp_bwd_fused_grid<bf16, 2>(M) : mlp_bwd_fused_grid<float, 2>(M);
     if (grid < 256) grid = 256;                          // mlpc_bwd_wgrad_kernel: one workgroup per CU
     return grid * ((size_t)2 * 4 * C * C + 2 * 4 * C + C);
@@ -217,6 +221,18 @@ int rvt_mlp_bwd_recompute_wgrad(const void* dxout, const void* xmid, const float
     RVT_CHECK(rvt_mlp_bwd_fused_supported(dtype, C), "mlp_bwd_recompute_wgrad: not built for dtype=%d C=%d", dtype, C);
     RVT_CHECK(ws != nullptr && M >= 1, "mlp_bwd_recompute_wgrad: workspace required");
     hipStream_t st = (hipStream_t)stream;
+    if (C == 128 && dtype == RVT_F32) {
+        // fp32 parity twin of the streamed route: the forward and the input-gradient kernel are the fp32 instantiations of
+        // mlp_stream.hpp; the weight gradients recompute LN2 / fc1 / GELU / GELU' / dh with the op-by-op entry points (the
+        // weight-stationary kernel is bf16-only: transposing LDS reads, 2-byte tiles)
+        const size_t MC = (size_t)M * C;
+        float* v2 = ws; float* g = v2 + MC; float* gp = g + 4 * MC; float* dhd = gp + 4 * MC; float* wsk = dhd + 4 * MC;
+        if (rvt_layernorm_fwd(xmid, ln_w, ln_b, v2, dtype, M, C, eps, stream)) return 1;
+        if (rvt_linear_gelu_fwd(v2, w1, b1, g, gp, dtype, M, 4 * C, C, stream)) return 1;
+        if (rvt_linear_dgrad(dxout, w2g_t, nullptr, nullptr, gp, dhd, dtype, M, C, 4 * C, stream)) return 1;
+        if (rvt_linear_wgrad(dxout, g, s2, cs2, wsk, dtype, M, C, 4 * C, 0, stream)) return 1;
+        return rvt_linear_wgrad(dhd, v2, dw1, db1, wsk, dtype, M, 4 * C, C, 0, stream);
+    }
     if (C == 128) {
         const int S = msw_streams(M);
         hipLaunchKernelGGL(mlps_bwd_wgrad_kernel<0>, dim3(16 * ((S + 7) / 8)), dim3(512), 0, st, (const bf16*)dxout, (const bf16*)xmid, ln_w, ln_b,

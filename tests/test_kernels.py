@@ -738,12 +738,14 @@ def test_mlp_stream_bwd_dgrad(backend, dt, M, resident):
     close(dlb, c['lbr'].grad, dt, 'mlp_stream dln_b', mult=2 * mult)
 
 
+@pytest.mark.parametrize('dt', DTYPES)
 @pytest.mark.parametrize('M,grid', [(1000, 6), (300, 0), (2049, 4), (33, 0)])
-def test_mlp_stream_bwd_wgrad(backend, M, grid):
+def test_mlp_stream_bwd_wgrad(backend, dt, M, grid):
     """Streamed recompute backward of the MLP half at C = 128, weight-gradient kernel (csrc/mlp_stream.hpp: weight-stationary, two
     workgroups = hidden halves per tile stream, tiles by LDS-DMA, LayerNorm in place) vs fp64 autograd; `grid` = one_per_cu_grid
-    (2 workgroups per stream) so that a stream walks several tiles; accumulation into existing buffers."""
-    dt, C = torch.bfloat16, 128
+    (2 workgroups per stream) so that a stream walks several tiles; accumulation into existing buffers.  fp32 (parity twin of the
+    route): the same entry point recomputes LN2 / fc1 / GELU / GELU' / dh with the op-by-op kernels."""
+    C = 128
     c = _mlp_case(backend, dt, M)
     with tuning.override(mlp_stream=1, one_per_cu_grid=grid):
         assert ops.mlp_bwd_fused_supported(dt, C)
@@ -751,7 +753,7 @@ def test_mlp_stream_bwd_wgrad(backend, M, grid):
         s2, cs2 = torch.zeros(C, 4 * C, device=backend), torch.zeros(C, device=backend)
         for _ in range(2):
             ops.mlp_bwd_recompute_wgrad(c['dy'], c['x'], c['lw'], c['lb'], c['w1'], c['b1'], c['w2g_t'], dw1, db1, s2, cs2, 1e-5)
-    mult = 2.0
+    mult = 1.0 if dt == torch.float32 else 2.0
     close(dw1, 2 * c['w1r'].grad, dt, 'mlp_stream dW1', mult=2 * mult)
     close(db1, 2 * c['b1r'].grad, dt, 'mlp_stream db1', mult=2 * mult)
     close(s2, 2 * f64(c['dy']).t() @ c['g'], dt, 'mlp_stream S2', mult=2 * mult)
