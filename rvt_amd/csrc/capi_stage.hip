@@ -27,6 +27,8 @@ static bool route_attn_block(const RvtStageDesc& d) {
 }
 static bool route_fused_mlp_infer(const RvtStageDesc& d) {
     const int mode = tuning().route_fused_mlp;
+    // the widths whose backward recomputes from the block input run the same nothing-saved forward when training
+    if (mode != 0 && tuning().route_mlp_bwd_fused != 0 && rvt_mlp_bwd_fused_supported(d.dtype, d.C)) return true;
     if (mode == 0 || !rvt_mlp_fused_supported(d.dtype, d.C)) return false;
     return mode == 1 || d.C == 64 || d.C == 128;
 }

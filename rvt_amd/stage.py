@@ -212,8 +212,9 @@ def stage_seq_forward(sw: StageWeights, g: StageGeom, inp: Tensor, h0: Optional[
                 xmid = ops.linear_scale_res_fwd(a, bw['proj_w'], bw['proj_b'], bw['g1'], x)        # :353, :268
             v2 = None
             hpre = False
-            if save and use_fused_mlp(dt, C, 'bwd_fused'):
-                # the backward recomputes everything from xmid: inference-flavoured forward, nothing else kept
+            if use_fused_mlp(dt, C, 'bwd_fused'):
+                # the backward recomputes everything from xmid: inference-flavoured forward, nothing else kept (the no-grad
+                # forward takes the same kernel, so eval and training outputs are bit-identical)
                 xout, hg, hgp = ops.mlp_fwd(xmid, bw['n2_w'], bw['n2_b'], bw['fc1_w'], bw['fc1_b'], bw['fc2_w'], bw['fc2_b'],
                                             bw['g2'], g.eps, want_grad=False)
             elif use_fused_mlp(dt, C, 'fwd_train' if save else 'fwd_infer'):
