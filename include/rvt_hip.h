@@ -80,9 +80,11 @@ typedef struct RvtTuning {
     int route_mlp_bwd_both;   /* 1: stage-1 MLP backward = ONE launch (rvt_mlp_bwd_recompute_both) instead of dgrad + wgrad */
     int mlp_stream;           /* 1 (round 5): C = 128 MLP halves take the streamed-weight chain kernels (mlp_stream.hpp): nothing-saved forward,
                                  recompute backward (input-gradient + weight-gradient launch); 0: LDS-staged forward that saves GELU / GELU' + op-by-op backward */
-    int reserved[7];          /* zero */
+    int ln_linear;            /* 1 (round 5): LayerNorm + qkv projection of a C = 128 block in one launch (ln_linear.hpp) where rvt_ln_linear_supported */
+    int conv_wgrad_tn;        /* 1 (round 5): conv weight gradients with Cout % 256 == 0 and k*k*Cin % 256 == 0 take ppgemm_tn.hpp (im2col gather by LDS-DMA) */
+    int reserved[5];          /* zero */
 } RvtTuning;
-#define RVT_TUNING_DEFAULTS {(int)sizeof(RvtTuning), 0, 1, 0, 512, 8192, 1, 4096, 0, 0, 0, 0, 1, 4, 0, 1, 1, 0, 0, 1, -1, 1, 1, -1, 1, 1, 0, 1, 1, 0, 1, 1, {0}}
+#define RVT_TUNING_DEFAULTS {(int)sizeof(RvtTuning), 0, 1, 0, 512, 8192, 1, 4096, 0, 0, 0, 0, 1, 4, 0, 1, 1, 0, 0, 1, -1, 1, 1, -1, 1, 1, 0, 1, 1, 0, 1, 1, 1, 1, {0}}
 void rvt_tuning_defaults(RvtTuning* t);        /* fills *t with the production defaults */
 int rvt_get_tuning(RvtTuning* t);              /* t->struct_bytes must be set by the caller */
 int rvt_set_tuning(const RvtTuning* t);
@@ -169,6 +171,14 @@ int rvt_linear_dgrad(const void* dy, const void* wt, const void* gelu_pre, const
 int rvt_linear_dgrad_ln_supported(int dtype, int C, int K);
 int rvt_linear_dgrad_ln(const void* dy, const void* w, const void* x, const void* add, void* dx, const float* ln_w,
                         float* dln_w, float* dln_b, int dtype, int M, int C, int K, float eps, void* stream);
+
+/* u = LN(x; ln_w, ln_b), y = u W^T + bias in one launch (csrc/ln_linear.hpp; replaces rvt_layernorm_fwd + rvt_linear_fwd for
+ * `self.qkv(self.norm1(x))`, reference maxvit.py:268 -> :347).  W [N][C] row-major, bias may be NULL, u may be NULL (no-grad
+ * forward: the normalised rows are not kept); ln_w = ln_b = NULL: no LayerNorm (the first block behind a down-sampling conv,
+ * maxvit.py:229-236), u is not written.  rvt_ln_linear_supported: bf16, C = 128, N = 384 (tuning.ln_linear = 0: no). */
+int rvt_ln_linear_supported(int dtype, int C, int N);
+int rvt_ln_linear_fwd(const void* x, const float* ln_w, const float* ln_b, const void* w, const float* bias, void* u, void* y,
+                      int dtype, int M, int C, int N, float eps, void* stream);
 
 /* dw[N][K] (float32) += dy[M][N]^T f(x)[M][K];  if dy_colsum != NULL also dy_colsum[N] += column sums of dy
  * (the bias gradient), computed from the tiles the kernel streams anyway. */

@@ -68,6 +68,9 @@ def model(name: str, a) -> Optional[Tuple[float, float]]:
     if name == 'rvt_linear_fwd':
         e, M, N, K = _elt(a[4]), a[5], a[6], a[7]
         return 2.0 * M * N * K, (1.0 * M * (N + K) + N * K) * e
+    if name == 'rvt_ln_linear_fwd':                      # u = LN(x), y = u w^T + bias
+        e, M, C, N = _elt(a[7]), a[8], a[9], a[10]
+        return 2.0 * M * N * C, (1.0 * M * (C * (2 if P(5) and P(1) else 1) + N) + N * C) * e
     if name == 'rvt_linear_gelu_fwd':
         e, M, N, K = _elt(a[5]), a[6], a[7], a[8]
         return 2.0 * M * N * K, (1.0 * M * (N * (2 if P(4) else 1) + K) + N * K) * e

@@ -37,6 +37,7 @@ _SIGS = {
     'rvt_linear_scale_res_fwd': [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     'rvt_linear_dgrad': [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     'rvt_linear_dgrad_ln': [_vp] * 8 + [_i, _i, _i, _i, _f, _vp],
+    'rvt_ln_linear_fwd': [_vp] * 7 + [_i, _i, _i, _i, _f, _vp],
     'rvt_linear_gelu_fwd': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     'rvt_linear_wgrad': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     'rvt_mlp_fwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
@@ -77,7 +78,7 @@ EXPORTS = sorted(list(_SIGS) + ['rvt_last_error', 'rvt_is_emulator', 'rvt_wgrad_
                                'rvt_mlp_fused_supported', 'rvt_lstm_scan_supported', 'rvt_mlp_bwd_fused_supported',
                                'rvt_mlp_bwd_fused_ws_floats', 'rvt_attn_block_supported', 'rvt_lstm_scan_bwd_ws_floats',
                                'rvt_lstm_scan_saves_gates', 'rvt_stem_supported', 'rvt_stem_wgrad_ws_floats', 'rvt_conv_dgrad4_supported',
-                               'rvt_linear_dgrad_ln_supported', 'rvt_tuning_defaults', 'rvt_get_tuning', 'rvt_set_tuning', 'rvt_probe_mfma',
+                               'rvt_linear_dgrad_ln_supported', 'rvt_ln_linear_supported', 'rvt_tuning_defaults', 'rvt_get_tuning', 'rvt_set_tuning', 'rvt_probe_mfma',
                                'rvt_stage_seq_fwd', 'rvt_stage_seq_fwd_ws_bytes', 'rvt_simota_ws_bytes', 'rvt_mlp_bwd_both_supported'])
 
 
@@ -108,6 +109,8 @@ def _bind(lib: ctypes.CDLL) -> ctypes.CDLL:
     lib.rvt_lstm_scan_supported.argtypes = [_i, _i]
     lib.rvt_linear_dgrad_ln_supported.restype = ctypes.c_int
     lib.rvt_linear_dgrad_ln_supported.argtypes = [_i, _i, _i]
+    lib.rvt_ln_linear_supported.restype = ctypes.c_int
+    lib.rvt_ln_linear_supported.argtypes = [_i, _i, _i]
     lib.rvt_conv_dgrad4_supported.restype = ctypes.c_int
     lib.rvt_conv_dgrad4_supported.argtypes = [_i] * 9
     lib.rvt_stem_supported.restype = ctypes.c_int

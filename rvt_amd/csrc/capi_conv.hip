@@ -6,6 +6,10 @@ size_t rvt_wgrad_workspace_floats(int dtype, int out_rows, int out_cols, int tok
     size_t pp = 0;
     if (use_ppgemm_tn(dtype, tokens, out_rows, out_cols, out_rows, out_cols, out_cols))
         pp = ppgemm_tn_ws_floats(tokens, out_rows, out_cols, want_colsum);     // (an upper bound is all the callers need)
+    if (tuning().ppgemm != 0 && dtype == RVT_BF16 && out_rows % 256 == 0 && out_cols % 64 == 0 && out_cols >= 256) {
+        const size_t pc = ppgemm_tn_conv_ws_floats(tokens, out_rows, out_cols);  // rvt_conv_wgrad on the same kernel (K a multiple of 64 only)
+        if (pc > pp) pp = pc;
+    }
     int bn = wgrad_bn(out_cols);
     int bk = dtype == RVT_F32 ? TileGeom<float>::BK : TileGeom<bf16>::BK;
     size_t n = wgrad_ws_floats(out_rows, out_cols, tokens, bn, bk, want_colsum);
@@ -16,6 +20,10 @@ size_t rvt_wgrad_workspace_floats(int dtype, int out_rows, int out_cols, int tok
     return n > pp ? n : pp;
 }
 }  // extern "C"
+// conv weight gradients that take the 256-wide token-contraction kernel (bf16, Cout % 256 == 0, k*k*Cin % 256 == 0, Cin % 64 == 0)
+static bool conv_wgrad_tn(int dtype, int F, int H, int W, int Cin, int Cout, int k, int stride, int pad) {
+    return tuning().ppgemm != 0 && tuning().conv_wgrad_tn != 0 && dtype == RVT_BF16 && ppgemm_tn_conv_shape_ok(F, H, W, Cin, Cout, k, stride, pad);
+}
 template <class T>
 static Im2colSrc<T> make_im2col(const void* in, int F, int H, int W, int Cin, int k, int stride, int pad) {
     Im2colSrc<T> s;
@@ -60,6 +68,11 @@ int rvt_conv_wgrad(const void* in, const void* dy, float* dw, float* ws, int dty
                    int k, int stride, int pad, void* stream) {
     RVT_CHECK(Cin % 8 == 0 && Cout % 8 == 0, "conv_wgrad: channels must be multiples of 8");
     hipStream_t st = (hipStream_t)stream;
+    if (conv_wgrad_tn(dtype, F, H, W, Cin, Cout, k, stride, pad) && ws != nullptr) {
+        // 256 x 256 tiles, both operands by LDS-DMA, im2col as a per-lane source address (ppgemm_tn.hpp, CONV)
+        launch_ppgemm_tn_conv((const bf16*)dy, (const bf16*)in, dw, ws, F, H, W, Cin, Cout, k, stride, pad, st);
+        return check_launch("conv_wgrad");
+    }
     DISPATCH_DTYPE(dtype, {
         Im2colSrc<T> b = make_im2col<T>(in, F, H, W, Cin, k, stride, pad);
         PlainSrc<T> a{(const T*)dy, Cout, b.rows, Cout};

@@ -5,6 +5,7 @@
 #include "mlp.hpp"
 #include "mlp_chain.hpp"
 #include "mlp_stream.hpp"
+#include "ln_linear.hpp"
 
 using namespace rvt;
 
@@ -80,6 +81,20 @@ int rvt_linear_dgrad_ln(const void* dy, const void* w, const void* x, const void
     else { if (four) RVT_DGL(64, 4); else RVT_DGL(64, 2); }
 #undef RVT_DGL
     return check_launch("linear_dgrad_ln");
+}
+
+// u = LN(x), y = u W^T + bias in one launch (csrc/ln_linear.hpp): the qkv projection of a C = 128 block.  tuning.ln_linear = 0 disables.
+int rvt_ln_linear_supported(int dtype, int C, int N) {
+    return tuning().ln_linear != 0 && dtype == RVT_BF16 && C == 128 && N == 384;
+}
+int rvt_ln_linear_fwd(const void* x, const float* ln_w, const float* ln_b, const void* w, const float* bias, void* u, void* y,
+                      int dtype, int M, int C, int N, float eps, void* stream) {
+    RVT_CHECK(rvt_ln_linear_supported(dtype, C, N), "ln_linear_fwd: not built for dtype=%d C=%d N=%d", dtype, C, N);
+    RVT_CHECK(M >= 1 && (ln_w == nullptr) == (ln_b == nullptr) && y != nullptr, "ln_linear_fwd: LayerNorm weight and bias go together; the output is required");
+    auto k = lnlin_fwd_kernel<bf16, 128, 384, 8, 2>;
+    hipLaunchKernelGGL(k, dim3(mc_grid(k, 512, M, 8)), dim3(512), 0, (hipStream_t)stream, (const bf16*)x, ln_w, ln_b, (const bf16*)w, bias,
+                       (bf16*)u, (bf16*)y, M, eps);
+    return check_launch("ln_linear_fwd");
 }
 
 int rvt_mlp_fwd(const void* xmid, void* xout, void* g_out, void* gp_out, void* v2_out, const float* ln_w, const float* ln_b,

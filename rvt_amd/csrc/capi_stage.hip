@@ -112,8 +112,12 @@ int rvt_stage_seq_fwd(const RvtStageDesc* dp, const void* inp, const void* h0, c
                                        d.dim_head, d.ph, d.pw, window, d.eps, stream));
         } else {
             const void* uu = xin;
-            if (bw.n1_w != nullptr) { RVT_TRY(rvt_layernorm_fwd(xin, bw.n1_w, bw.n1_b, u, dt, M, C, d.eps, stream)); uu = u; }
-            RVT_TRY(rvt_linear_fwd(uu, bw.qkv_w, bw.qkv_b, qkv, dt, M, 3 * C, C, 0, stream));
+            if (rvt_ln_linear_supported(dt, C, 3 * C)) {
+                RVT_TRY(rvt_ln_linear_fwd(xin, bw.n1_w, bw.n1_b, bw.qkv_w, bw.qkv_b, nullptr, qkv, dt, M, C, 3 * C, d.eps, stream));
+            } else {
+                if (bw.n1_w != nullptr) { RVT_TRY(rvt_layernorm_fwd(xin, bw.n1_w, bw.n1_b, u, dt, M, C, d.eps, stream)); uu = u; }
+                RVT_TRY(rvt_linear_fwd(uu, bw.qkv_w, bw.qkv_b, qkv, dt, M, 3 * C, C, 0, stream));
+            }
             RVT_TRY(rvt_attn_fwd(qkv, a_, dt, F, H, W, C, d.dim_head, d.ph, d.pw, window, stream));
             RVT_TRY(rvt_linear_scale_res_fwd(a_, bw.proj_w, bw.proj_b, bw.g1, xin, xmid, dt, M, C, C, 0, stream));
         }

@@ -32,21 +32,33 @@ struct PPTnGeom {
     static constexpr int SMEM = 2 * STAGE > 8 * T_BYTES ? 2 * STAGE : 8 * T_BYTES;
 };
 
-template <int ABL = 0>
+// CONV: the X operand is im2col(in) of a k x k / stride / pad convolution over in[F][H][W][Cin] (reference maxvit.py:160-177, the
+// down-sampling convs, and the PAFPN convs), never materialised: token m = output pixel (f, oy, ox) in raster order, column
+// (tap, ci) = in[f][oy * stride + tap / k - pad][ox * stride + tap % k - pad][ci].  A load-stream unit is 64 columns = one tap and
+// a 64-channel slab of it (Cin % 64 == 0), so only the per-lane SOURCE address of the X-side pieces changes: pixel offset of the
+// lane's token for the unit's tap, or an out-of-range offset (the buffer returns zeros) for padding pixels and tokens beyond the slice.
+struct PPTnConv {
+    int H, W, Cin, Ho, Wo, k, stride, pad;
+    unsigned in_bytes;                                 // F * H * W * Cin * 2 (< 2^31)
+};
+
+template <int ABL = 0, bool CONV = false>
 __global__ void __launch_bounds__(512, 2)
 ppgemm_tn_kernel(const bf16* __restrict__ dY, int ldy, const bf16* __restrict__ X, const bf16* __restrict__ X2, int kcut, int ldx,
                  float* __restrict__ ws, float* __restrict__ ws_cs, int M, int N, int K, int n_tiles, int k_tiles,
-                 int tokens_per_slice) {
+                 int tokens_per_slice, PPTnConv cv) {
     typedef PPTnGeom G;
     __shared__ __attribute__((aligned(16))) char smem[G::SMEM];
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = wave_uniform(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
-    // item of this workgroup.  The output tiles of one token slice read the same dY / X rows: slice s belongs to XCD s % 8
-    // (workgroup id % 8 - the dispatcher deals workgroups round-robin over the XCDs), so that its tiles share an L2.
+    // item of this workgroup.  The output tiles of one token slice read the same dY / X rows at the same pace: the items are laid
+    // out slice-major and XCD x (workgroup id % 8 - the dispatcher deals workgroups round-robin over the XCDs) takes the x-th
+    // run of gridDim / 8 consecutive items, so that a slice's tiles share an L2 (a slice straddles at most two XCDs) whatever the
+    // tile count per slice (18 tiles per slice, 14 slices = 252 items: the earlier "slice s on XCD s % 8" dealt 8 slices = 144).
     const int tiles = n_tiles * k_tiles;
-    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
-    const int slice = (jx / tiles) * 8 + xcd, tile = jx - (jx / tiles) * tiles;
+    const int item = (blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);
+    const int slice = item / tiles, tile = item - slice * tiles;
     const int nt = tile % n_tiles, kt = tile / n_tiles;
     if (slice * tokens_per_slice >= M) return;
     const int tok0 = slice * tokens_per_slice;
@@ -65,7 +77,26 @@ ppgemm_tn_kernel(const bf16* __restrict__ dY, int ldy, const bf16* __restrict__ 
     const bf16* const ybase = dY + (size_t)nt * 256;
     // the X side may be two matrices side by side ([x_t | h_{t-1}] of the ConvLSTM, rnn.py:52): k tiles never straddle the cut
     const bf16* const xbase = kt * 256 < kcut ? X + (size_t)kt * 256 : X2 + (size_t)(kt * 256 - kcut);
-    struct Desc { pp_rsrc ry, rx; };
+    struct Desc { pp_rsrc ry, rx; int vx[CONV ? 4 : 1]; };
+    // CONV: the four X units of this k tile = (tap, 64-channel slab) pairs, fixed per workgroup; (f, oy, ox) of the lane's token of
+    // the NEXT step to be described, advanced by 64 tokens per step
+    int c_dy[4], c_dx[4], c_off[4], c_f = 0, c_by = 0, c_bx = 0;
+    pp_rsrc rx_all = pp_make_rsrc(X, 0u);
+    if constexpr (CONV) {
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int col = kt * 256 + g * 64, tap = col / cv.Cin;
+            const int tdy = tap / cv.k;
+            c_dx[g] = tap - tdy * cv.k;
+            c_off[g] = col < K ? ((tdy * cv.W + c_dx[g]) * cv.Cin + (col - tap * cv.Cin)) * 2 : 0;
+            c_dy[g] = col < K ? tdy : 1 << 20;                          // (the last k tile may be partly beyond K: rows of zeros)
+        }
+        const int idx = tok0 + t_l, q = idx / cv.Wo;
+        c_f = q / cv.Ho;
+        c_by = (q - c_f * cv.Ho) * cv.stride - cv.pad;               // input row of tap (0, 0)
+        c_bx = (idx - q * cv.Wo) * cv.stride - cv.pad;
+        rx_all = pp_make_rsrc(X, cv.in_bytes);
+    }
     int lstep = 0;
     auto next_desc = [&]() __attribute__((always_inline)) -> Desc {
         Desc d;
@@ -74,9 +105,23 @@ ppgemm_tn_kernel(const bf16* __restrict__ dY, int ldy, const bf16* __restrict__ 
             const int rows = tok1 - t0 < 64 ? tok1 - t0 : 64;
             // the last token row of the buffer ends at its last tile column: row stride ld, tile width 256 columns
             d.ry = pp_make_rsrc(ybase + (size_t)t0 * ldy, (unsigned)(((rows - 1) * ldy + 256) * 2));
-            d.rx = pp_make_rsrc(xbase + (size_t)t0 * ldx, (unsigned)(((rows - 1) * ldx + 256) * 2));
+            if constexpr (!CONV) d.rx = pp_make_rsrc(xbase + (size_t)t0 * ldx, (unsigned)(((rows - 1) * ldx + 256) * 2));
         } else {
-            d.ry = pp_make_rsrc(dY, 0u); d.rx = pp_make_rsrc(X, 0u);
+            d.ry = pp_make_rsrc(dY, 0u);
+            if constexpr (!CONV) d.rx = pp_make_rsrc(X, 0u);
+        }
+        if constexpr (CONV) {
+            d.rx = rx_all;
+            const bool in = lstep < nsteps && t0 + t_l < tok1;
+            const int base = ((c_f * cv.H + c_by) * cv.W + c_bx) * cv.Cin * 2 + cpos * 16;
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const bool ok = in && (unsigned)(c_by + c_dy[g]) < (unsigned)cv.H && (unsigned)(c_bx + c_dx[g]) < (unsigned)cv.W;
+                d.vx[g] = ok ? base + c_off[g] : 0x7ffffff0;
+            }
+            c_bx += 64 * cv.stride;
+            while (c_bx >= cv.Wo * cv.stride - cv.pad) { c_bx -= cv.Wo * cv.stride; c_by += cv.stride; }
+            while (c_by >= cv.Ho * cv.stride - cv.pad) { c_by -= cv.Ho * cv.stride; c_f++; }
         }
         lstep++;
         return d;
@@ -85,7 +130,9 @@ ppgemm_tn_kernel(const bf16* __restrict__ dY, int ldy, const bf16* __restrict__ 
         if (!(ABL & 1) && !(ABL & 32)) pp_glds16(d.ry, smem, stage * G::STAGE + i * G::UNIT + lds0, vy0 + i * 128, 0);
     };
     auto issue_x = [&](const Desc& d, int stage, int g) __attribute__((always_inline)) {
-        if (!(ABL & 1) && !(ABL & 64)) pp_glds16(d.rx, smem, stage * G::STAGE + G::OFF_W + g * G::UNIT + lds0, vx0 + g * 128, 0);
+        int v = vx0 + g * 128;
+        if constexpr (CONV) v = d.vx[g];
+        if (!(ABL & 1) && !(ABL & 64)) pp_glds16(d.rx, smem, stage * G::STAGE + G::OFF_W + g * G::UNIT + lds0, v, 0);
     };
 
     // ---- fragment reads (transposing): lane -> token 16 ks + 8 hi + (lane % 16) / 4 (+ 4), 4 columns 16 ((lane / 16) % 2) + 4 (lane % 4) ----
@@ -217,9 +264,10 @@ ppgemm_tn_kernel(const bf16* __restrict__ dY, int ldy, const bf16* __restrict__ 
     // ---- epilogue: accumulator block (rows n = 8 g + 4 hi + w, column k = lane % 32) -> LDS [k][n] -> 512-byte rows of ws[slice][K][N] ----
     char* const tb = smem + wave * G::T_BYTES;
     float* const wout = ws + (size_t)slice * K * N + (size_t)(kt * 256 + wc * 64) * N + nt * 256 + wr * 32;
+    const bool k_in = kt * 256 + wc * 64 < K;         // (CONV: K is a multiple of 64, not of 256)
 #pragma unroll
     for (int j = 0; j < 2; j++) {
-        if (!(ABL & 16)) {
+        if (!(ABL & 16) && k_in) {
 #pragma unroll
             for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -257,9 +305,7 @@ inline bool ppgemm_tn_shape_ok(int M, int N, int K, int ldy, int ldx, int kcut) 
 inline int ppgemm_tn_slices(int M, int N, int K) {
     const int items_override = g_tuning.ppgemm_tn_items;     // (tests: small)
     const int tiles = (N / 256) * (K / 256);
-    // slice s runs on XCD s % 8 (32 CUs each): a multiple of 8 slices with no more than 32 items per XCD, or the surplus
-    // items of the fuller XCDs run as a second round (measured on dW[1536][512]: 21 slices = 0.38 ms, 16 slices = see profiles/r3)
-    int ns = items_override > 0 ? items_override / tiles : (tiles <= 32 ? 8 * (32 / tiles) : 8);
+    int ns = (items_override > 0 ? items_override : 256) / tiles;
     if (ns < 1) ns = 1;
     const int max_ns = (M + 255) / 256;
     return ns > max_ns ? max_ns : ns;
@@ -276,13 +322,38 @@ inline void launch_ppgemm_tn(const bf16* dY, int ldy, const bf16* X, const bf16*
     const int ns_eff = (M + tps - 1) / tps;
     const int n_tiles = N / 256, k_tiles = K / 256;
     float* ws_cs = colsum_out ? ws + (size_t)ns * N * K : nullptr;
-    hipLaunchKernelGGL((ppgemm_tn_kernel<0>), dim3(8 * n_tiles * k_tiles * ((ns_eff + 7) / 8)), dim3(512), 0, st, dY, ldy, X, X2, kcut, ldx, ws, ws_cs, M, N,
-                       K, n_tiles, k_tiles, tps);
+    hipLaunchKernelGGL((ppgemm_tn_kernel<0>), dim3(8 * ((n_tiles * k_tiles * ns_eff + 7) / 8)), dim3(512), 0, st, dY, ldy, X, X2, kcut, ldx, ws, ws_cs, M, N,
+                       K, n_tiles, k_tiles, tps, PPTnConv{});
     const size_t elems = (size_t)N * K;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(reduce_grid(elems)), dim3(256), 0, st, (const float*)ws, out, ns_eff, elems, N);
     if (colsum_out) {
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(reduce_grid((size_t)N)), dim3(256), 0, st, (const float*)ws_cs, colsum_out, ns_eff * 8, (size_t)N, 0);
     }
+}
+
+// conv weight gradient dw[Cout][k*k*Cin] += dy^T im2col(in) on the same kernel (CONV): the shapes that fit
+inline bool ppgemm_tn_conv_shape_ok(long long F, int H, int W, int Cin, int Cout, int k, int stride, int pad) {
+    const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+    const long long M = F * Ho * Wo;
+    return Cin % 64 == 0 && Cout % 256 == 0 && k * k * Cin >= 256 && pad < k && M >= g_tuning.ppgemm_min_m &&
+           F * H * W * Cin * 2 < 0x7ffffff0ll && M * Cout * 2 < (1ll << 40) && (size_t)64 * Cout * 2 + 512 < (1ull << 31);
+}
+inline size_t ppgemm_tn_conv_ws_floats(int M, int N, int K) { return (size_t)ppgemm_tn_slices(M, N, (K + 255) / 256 * 256) * N * K; }
+inline void launch_ppgemm_tn_conv(const bf16* dY, const bf16* in, float* out, float* ws, int F, int H, int W, int Cin, int Cout, int k,
+                                  int stride, int pad, hipStream_t st) {
+    PPTnConv cv;
+    cv.H = H; cv.W = W; cv.Cin = Cin; cv.k = k; cv.stride = stride; cv.pad = pad;
+    cv.Ho = (H + 2 * pad - k) / stride + 1; cv.Wo = (W + 2 * pad - k) / stride + 1;
+    cv.in_bytes = (unsigned)((size_t)F * H * W * Cin * 2);
+    const int M = F * cv.Ho * cv.Wo, N = Cout, K = k * k * Cin, k_tiles = (K + 255) / 256;
+    const int ns = ppgemm_tn_slices(M, N, k_tiles * 256);
+    const int tps = (((M + ns - 1) / ns) + 63) / 64 * 64;
+    const int ns_eff = (M + tps - 1) / tps;
+    const int n_tiles = N / 256;
+    hipLaunchKernelGGL((ppgemm_tn_kernel<0, true>), dim3(8 * ((n_tiles * k_tiles * ns_eff + 7) / 8)), dim3(512), 0, st, dY, N, in, in, 1 << 30, 0, ws,
+                       (float*)nullptr, M, N, K, n_tiles, k_tiles, tps, cv);
+    const size_t elems = (size_t)N * K;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(reduce_grid(elems)), dim3(256), 0, st, (const float*)ws, out, ns_eff, elems, N);
 }
 
 }  // namespace rvt

@@ -159,6 +159,23 @@ def layernorm_bwd(x: Tensor, w: Tensor, dy: Tensor, dres: Optional[Tensor], dw: 
     return dx
 
 
+def ln_linear_supported(dtype: torch.dtype, C: int, N: int) -> bool:
+    return dtype in L._DT and bool(L.get_lib().rvt_ln_linear_supported(L.dtype_code(dtype), C, N))
+
+
+def ln_linear_fwd(x: Tensor, ln_w: Tensor, ln_b: Tensor, w: Tensor, bias: Optional[Tensor], eps: float, want_u: bool = True):
+    """(u, y) = (LN(x), LN(x) @ w.T + bias) in one launch (csrc/ln_linear.hpp; reference maxvit.py:268 -> :347, `qkv(norm1(x))`);
+    u is None when want_u is False (no-grad forward) or when there is no LayerNorm (ln_w = ln_b = None: y = x @ w.T + bias)."""
+    C = x.shape[-1]
+    N = w.shape[0]
+    rows = x.numel() // C
+    u = _out(x, x.shape) if want_u and ln_w is not None else None
+    y = _out(x, x.shape[:-1] + (N,))
+    L.call('rvt_ln_linear_fwd', L.ptr(x), L.ptr(ln_w), L.ptr(ln_b), L.ptr(w), L.ptr(bias), L.ptr(u), L.ptr(y),
+           L.dtype_code(x.dtype), rows, C, N, float(eps), L.stream_of(x))
+    return u, y
+
+
 def linear_dgrad_ln_supported(dtype: torch.dtype, C: int, K: int) -> bool:
     return dtype in L._DT and bool(L.get_lib().rvt_linear_dgrad_ln_supported(L.dtype_code(dtype), C, K))
 

@@ -206,8 +206,14 @@ def stage_seq_forward(sw: StageWeights, g: StageGeom, inp: Tensor, h0: Optional[
                                              bw['g1'], F_, H, W, C, g.dim_head, g.ph, g.pw, window, g.eps, want_a=save)
                 u = qkv = None
             else:
-                u = x if bw['n1_w'] is None else ops.layernorm_fwd(x, bw['n1_w'], bw['n1_b'], g.eps)
-                qkv = ops.linear_fwd(u, bw['qkv_w'], bw['qkv_b'])                     # maxvit.py:347
+                if ops.ln_linear_supported(dt, C, 3 * C):
+                    # norm1 + qkv in one launch (csrc/ln_linear.hpp; C = 128); u is kept for the qkv weight gradient
+                    u, qkv = ops.ln_linear_fwd(x, bw['n1_w'], bw['n1_b'], bw['qkv_w'], bw['qkv_b'], g.eps, want_u=save)
+                    if bw['n1_w'] is None:
+                        u = x
+                else:
+                    u = x if bw['n1_w'] is None else ops.layernorm_fwd(x, bw['n1_w'], bw['n1_b'], g.eps)
+                    qkv = ops.linear_fwd(u, bw['qkv_w'], bw['qkv_b'])                 # maxvit.py:347
                 a = ops.attn_fwd(qkv, F_, H, W, C, g.dim_head, g.ph, g.pw, window)    # maxvit.py:349-352
                 xmid = ops.linear_scale_res_fwd(a, bw['proj_w'], bw['proj_b'], bw['g1'], x)        # :353, :268
             v2 = None

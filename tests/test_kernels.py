@@ -542,6 +542,38 @@ def test_conv_dgrad4(backend, case):
     close(ops.conv_dgrad4(dy, wd4, add, H, W, Cin), f64(old), dt, 'conv_dgrad4 vs parity-class route', mult=0.5)
 
 
+CONV_WGRAD_TN_CASES = [  # F, H, W, Cin, Cout, k, stride, pad
+    (3, 24, 40, 128, 256, 3, 2, 1),      # stage-3 down-sampling conv: K = 1152 = 4.5 k tiles (the last one half beyond K), two taps per tile
+    (5, 12, 20, 256, 512, 3, 2, 1),      # stage 4: one tap per k tile, two n tiles, Wo = 10 (a 64-token step spans 6 image rows and frames)
+    (2, 16, 24, 64, 256, 3, 1, 1),       # PAFPN 3x3 / 1: four taps per tile, K = 576 (2.25 tiles)
+    (2, 18, 22, 256, 256, 1, 1, 0),      # 1x1: a plain token contraction through the gather path
+    (3, 26, 38, 64, 256, 2, 2, 0),       # non-overlapping 2x2 / 2 (overlap = False configs), odd-sized remainder rows
+]
+
+
+@pytest.mark.parametrize('case', CONV_WGRAD_TN_CASES)
+def test_conv_wgrad_tn(backend, case):
+    """Conv weight gradient on the 256-wide token-contraction kernel with im2col as the LDS-DMA source address (csrc/ppgemm_tn.hpp,
+    CONV) vs fp64 autograd and vs the split-K im2col engine: image borders, token slices that end inside an image row, a last k
+    tile partly beyond K, accumulation into a non-zero dw."""
+    Fr, H, W, Cin, Cout, k, s, p = case
+    dt = torch.bfloat16
+    x = rnd((Fr, H, W, Cin), backend, dt, 1)
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    dy = rnd((Fr, Ho, Wo, Cout), backend, dt, 3)
+    wr = torch.zeros(Cout, Cin, k, k, dtype=torch.float64, requires_grad=True)
+    F.conv2d(f64(x).permute(0, 3, 1, 2), wr, None, s, p).backward(f64(dy).permute(0, 3, 1, 2))
+    dw = torch.zeros(Cout, k * k * Cin, device=backend)
+    ops.conv_wgrad(x, dy, dw, k, s, p)
+    close(weights.unpack_conv_wgrad(dw, Cin, k), wr.grad, dt, 'conv_wgrad (ppgemm_tn)')
+    with tuning.override(conv_wgrad_tn=0):
+        dw0 = torch.zeros(Cout, k * k * Cin, device=backend)
+        ops.conv_wgrad(x, dy, dw0, k, s, p)
+    close(dw, dw0.double(), dt, 'conv_wgrad ppgemm_tn vs split-K engine', mult=0.5)
+    ops.conv_wgrad(x, dy, dw, k, s, p)                    # accumulates
+    close(weights.unpack_conv_wgrad(dw, Cin, k), 2 * wr.grad, dt, 'conv_wgrad (ppgemm_tn) accumulate', mult=2.0)
+
+
 @pytest.mark.parametrize('dt', DTYPES)
 @pytest.mark.parametrize('N,H,W,C', [(2, 5, 7, 16), (1, 6, 4, 48), (3, 3, 3, 8)])
 def test_dwconv(backend, dt, N, H, W, C):
@@ -701,6 +733,40 @@ def test_mlp_stream_fwd(backend, dt, M, resident):
         with tuning.override(mlp_stream=0):
             y0 = ops.mlp_fwd(x, lw, lb, w1, b1, w2, b2, gam, 1e-5, want_grad=False)[0]
         close(y, y0.double(), dt, 'mlp_fwd streamed vs LDS-staged', mult=mult)
+
+
+@pytest.mark.parametrize('M,resident,want_u', [(1000, 2, True), (300, 0, True), (2049, 3, False), (31, 0, True)])
+def test_ln_linear_fwd(backend, M, resident, want_u):
+    """norm1 + qkv projection of a C = 128 block in one launch (csrc/ln_linear.hpp, bf16) vs fp64 and vs the two launches it
+    replaces; `resident` workgroups so that a wave walks several tiles (row prefetch across tiles) and the last tile is ragged;
+    want_u = False is the no-grad forward (u not kept) and must give the same y bit for bit."""
+    C, N, dt = 128, 384, torch.bfloat16
+    assert ops.ln_linear_supported(dt, C, N) and not ops.ln_linear_supported(torch.float32, C, N)
+    x = rnd((M, C), backend, dt, 1, 1.5)
+    lw, lb = rnd((C,), backend, torch.float32, 2) * 0.3 + 1.0, rnd((C,), backend, torch.float32, 3, 0.2)
+    w, b = rnd((N, C), backend, dt, 4, 0.2), rnd((N,), backend, torch.float32, 5, 0.2)
+    with tuning.override(chain_resident=resident):
+        u, y = ops.ln_linear_fwd(x, lw, lb, w, b, 1e-5, want_u=want_u)
+        y_again = ops.ln_linear_fwd(x, lw, lb, w, b, 1e-5, want_u=not want_u)[1]
+    assert torch.equal(y.cpu(), y_again.cpu())
+    u0 = ops.layernorm_fwd(x, lw, lb, 1e-5)
+    y0 = ops.linear_fwd(u0, w, b)
+    if want_u:
+        close(u, F.layer_norm(f64(x), (C,), f64(lw), f64(lb), 1e-5), dt, 'ln_linear u')
+        assert (u.float() - u0.float()).abs().max().item() <= 2 ** -6 * u0.float().abs().max().item()      # one bf16 ulp
+    else:
+        assert u is None
+    # y against the fp64 product of the ROUNDED u (what both routes multiply), then against the op-by-op route
+    ur = f64(u if want_u else u0)
+    close(y, ur @ f64(w).t() + f64(b), dt, 'ln_linear y')
+    close(y, y0.double(), dt, 'ln_linear y vs layernorm_fwd + linear_fwd', mult=2.0)
+    # no LayerNorm (first block of a stage): the plain product through the same kernel
+    un, yn = ops.ln_linear_fwd(x, None, None, w, b, 1e-5, want_u=want_u)
+    assert un is None
+    close(yn, f64(x) @ f64(w).t() + f64(b), dt, 'ln_linear y (no LayerNorm)')
+    close(yn, ops.linear_fwd(x, w, b).double(), dt, 'ln_linear y (no LayerNorm) vs linear_fwd', mult=2.0)
+    with tuning.override(ln_linear=0):
+        assert not ops.ln_linear_supported(dt, C, N)
 
 
 def _mlp_case(backend, dt, M, C=128):
