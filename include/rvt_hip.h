@@ -80,7 +80,7 @@ typedef struct RvtTuning {
     int route_mlp_bwd_both;   /* 1: stage-1 MLP backward = ONE launch (rvt_mlp_bwd_recompute_both) instead of dgrad + wgrad */
     int mlp_stream;           /* 1 (round 5): C = 128 MLP halves take the streamed-weight chain kernels (mlp_stream.hpp): nothing-saved forward,
                                  recompute backward (input-gradient + weight-gradient launch); 0: LDS-staged forward that saves GELU / GELU' + op-by-op backward */
-    int ln_linear;            /* 1 (round 5): LayerNorm + qkv projection of a C = 128 block in one launch (ln_linear.hpp) where rvt_ln_linear_supported */
+    int ln_linear;            /* 1 (round 5): LayerNorm + qkv projection of a C = 128 block in one launch where rvt_ln_linear_supported, and fc1 + GELU at K = 256, N = 1024 on the weight-stationary kernel (both ln_linear.hpp) */
     int conv_wgrad_tn;        /* 1 (round 5): conv weight gradients with Cout % 256 == 0 and k*k*Cin % 256 == 0 take ppgemm_tn.hpp (im2col gather by LDS-DMA) */
     int reserved[5];          /* zero */
 } RvtTuning;

@@ -39,3 +39,16 @@ for res in (128, 512):
     with tuning.override(chain_resident=res):
         t = timeit(lambda: ops.ln_linear_fwd(x, lw, lb, w, b, 1e-5, want_u=True))
     print(f'   chain_resident={res}: {t[0]:.3f} ms')
+
+# fc1 + GELU (+ GELU') at K = 256, N = 1024 (stage 3 of RVT-Base: 484 k tokens): weight-stationary column groups against the GEMM engine
+C2, N2, M2 = 256, 1024, 483840
+u2 = (torch.randn(M2, C2, device=dev, generator=g)).to(dt)
+w2, b2 = (torch.randn(N2, C2, device=dev, generator=g) * 0.1).to(dt), torch.randn(N2, device=dev, generator=g) * 0.1
+t_new = timeit(lambda: ops.linear_gelu_fwd(u2, w2, b2, want_grad=True))
+t_newi = timeit(lambda: ops.linear_gelu_fwd(u2, w2, b2, want_grad=False))
+with tuning.override(ln_linear=0):
+    t_old = timeit(lambda: ops.linear_gelu_fwd(u2, w2, b2, want_grad=True))
+    t_oldi = timeit(lambda: ops.linear_gelu_fwd(u2, w2, b2, want_grad=False))
+gb2 = (M2 * C2 + 2 * M2 * N2) * 2e-9
+print(f'linear_gelu_fwd K={C2} N={N2} M={M2}: weight-stationary (g, gp) {t_new[0]:.3f} (min {t_new[1]:.3f}) ms = {gb2 / t_new[0]:.2f} TB/s of rows, '
+      f'g only {t_newi[0]:.3f} ms | GEMM engine {t_old[0]:.3f} ms, g only {t_oldi[0]:.3f} ms')

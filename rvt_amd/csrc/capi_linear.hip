@@ -1,5 +1,6 @@
 // extern "C" entry points, part 3 of 8: linear layers (forward / input gradient / weight gradient) on the GEMM engines.
 #include "gemm_host.hpp"
+#include "ln_linear.hpp"
 
 extern "C" {
 // -------------------------------------------------------------------------------------------- linear
@@ -28,6 +29,22 @@ int rvt_linear_gelu_fwd(const void* x, const void* w, const float* bias, void* g
                         void* stream) {
     RVT_CHECK(N % 8 == 0 && K % 8 == 0 && bias, "linear_gelu_fwd: N=%d K=%d must be multiples of 8, bias required", N, K);
     hipStream_t st = (hipStream_t)stream;
+    if (dtype == RVT_BF16 && K == 256 && N == 1024 && tuning().ln_linear != 0) {
+        // fc1 of a C = 256 block: weight-stationary column groups (csrc/ln_linear.hpp), 8 groups x token streams, one workgroup per CU
+        const int resident_override = tuning().chain_resident;
+        const int total = resident_override > 0 ? resident_override : 256;
+        int streams = imax(1, total / 8);
+        const int want = ((M + 31) / 32 + 7) / 8;        // token streams that still get a tile per wave
+        if (streams > want) streams = want;
+        if (streams >= 8) streams -= streams % 8;        // (the XCD-aware placement wants a multiple of 8)
+        if (gp != nullptr)
+            hipLaunchKernelGGL((lin_gelu_ws_kernel<bf16, 256, 1024, 8, true>), dim3(8 * streams), dim3(512), 0, st, (const bf16*)x, (const bf16*)w, bias,
+                               (bf16*)g, (bf16*)gp, M);
+        else
+            hipLaunchKernelGGL((lin_gelu_ws_kernel<bf16, 256, 1024, 8, false>), dim3(8 * streams), dim3(512), 0, st, (const bf16*)x, (const bf16*)w, bias,
+                               (bf16*)g, (bf16*)nullptr, M);
+        return check_launch("linear_gelu_fwd");
+    }
     if (K >= pp_min_k(512) && use_ppgemm(dtype, M, N, K, K, K, K)) {        // (measured: 0.51 vs 0.58 ms at K = 512, 0.87 vs 0.76 at K = 256)
         launch_ppgemm<PP_GELU_DUAL>(PPMat{(const bf16*)x, (const bf16*)x, K, K}, PPMat{(const bf16*)w, (const bf16*)w, K, K},
                                     PPEpArgs{(bf16*)g, (bf16*)gp, nullptr, bias, nullptr, N}, M, N, K, st);

@@ -769,6 +769,33 @@ def test_ln_linear_fwd(backend, M, resident, want_u):
         assert not ops.ln_linear_supported(dt, C, N)
 
 
+@pytest.mark.parametrize('M,resident,save', [(700, 16, True), (300, 0, True), (1031, 24, False), (31, 0, True), (2500, 64, True)])
+def test_linear_gelu_weight_stationary(backend, M, resident, save):
+    """fc1 + GELU (+ GELU') of a C = 256 block on the weight-stationary kernel (csrc/ln_linear.hpp lin_gelu_ws_kernel, bf16, behind
+    rvt_linear_gelu_fwd at K = 256, N = 1024) vs fp64 and vs the GEMM engine it replaces; `resident` workgroups = 8 column groups x
+    token streams (2, 3 and 8 streams: both workgroup -> (group, stream) mappings), several tiles per wave, ragged last tile;
+    save = False is the no-grad forward (gp not kept, same g bit for bit)."""
+    K, N, dt = 256, 1024, torch.bfloat16
+    x = rnd((M, K), backend, dt, 1, 1.0)
+    w, b = rnd((N, K), backend, dt, 4, 0.15), rnd((N,), backend, torch.float32, 5, 0.2)
+    with tuning.override(chain_resident=resident, ln_linear=1):
+        g, gp = ops.linear_gelu_fwd(x, w, b, want_grad=save)
+        g_again = ops.linear_gelu_fwd(x, w, b, want_grad=not save)[0]
+    assert torch.equal(g.cpu(), g_again.cpu())
+    with tuning.override(ln_linear=0):
+        g0, gp0 = ops.linear_gelu_fwd(x, w, b, want_grad=True)
+    h = f64(x) @ f64(w).t() + f64(b)
+    close(g, F.gelu(h), dt, 'linear_gelu (weight-stationary) g')
+    close(g, g0.double(), dt, 'linear_gelu (weight-stationary) g vs GEMM engine', mult=2.0)
+    if save:
+        hr = h.clone().requires_grad_(True)
+        F.gelu(hr).sum().backward()
+        close(gp, hr.grad, dt, "linear_gelu (weight-stationary) gp")
+        close(gp, gp0.double(), dt, "linear_gelu (weight-stationary) gp vs GEMM engine", mult=2.0)
+    else:
+        assert gp is None
+
+
 def _mlp_case(backend, dt, M, C=128):
     x = rnd((M, C), backend, dt, 1, 1.5)
     lw, lb = rnd((C,), backend, torch.float32, 2) * 0.3 + 1.0, rnd((C,), backend, torch.float32, 3, 0.2)
