@@ -24,21 +24,24 @@ __device__ __forceinline__ void wave_rendezvous() {
 // different lines; with that pattern three different kernels for fc1 + GELU (GEMM engine, streamed weights, weight-stationary) all
 // sat at 2.7 - 2.9 TB/s (a contiguous fill reaches 6.7 TB/s on this part) and the first cut of lnlin_fwd_kernel at 4.6.  The pieces of a
 // 64-column group (one line per token) bounce through a 2-KiB per-wave LDS tile, 16 tokens at a time, and come back as
-// lane = (token lane / 8, 16-byte piece lane % 8): one store instruction = 8 whole lines.
-struct LineBounce {
-    static constexpr int BYTES = 16 * 128;               // per wave: [16 tokens][128 B], piece position ^ (token & 7)
+// lane = (token lane / 8, 16-byte piece lane % 8): one store instruction = 8 whole lines.  It pays where the kernel is bound by the
+// memory system (ln_linear 0.54 -> 0.46 ms, fc1 + GELU 0.82 -> 0.55, stem forward 1.56 -> 1.45); in the VALU-bound fused attention
+// forward the same bounce (row indices sent to the storing lanes by a wave shuffle) COST 0.1 ms per launch and was removed again.
+template <int TOK = 16> struct LineBounceT {              // TOK tokens per phase: 16 (2 KiB per wave) or 8 (1 KiB, where LDS is short)
+    static_assert(TOK == 8 || TOK == 16, "8 or 16 tokens per phase");
+    static constexpr int BYTES = TOK * 128;              // per wave: [TOK tokens][128 B], piece position ^ (token & 7)
     char* scr;
     int li, half, wr, wr_sw, rd_t, rd_q;
     __device__ __forceinline__ void init(char* s, int lane) {
         scr = s; li = lane & 31; half = lane >> 5;
-        wr = (li & 15) * 128; wr_sw = li & 7;
+        wr = (li % TOK) * 128; wr_sw = li & 7;
         rd_t = lane >> 3; rd_q = lane & 7;
     }
     // pc[j][m] = this lane's token, columns 32 j + 16 m + 8 half .. + 7 of the group; the group starts col_bytes into a row of row_bytes
     __device__ __forceinline__ void flush(const pp_rsrc& dst, const u32x4 (&pc)[2][2], int row_bytes, int col_bytes) const {
 #pragma unroll
-        for (int ph = 0; ph < 2; ph++) {                   // tokens 16 ph .. 16 ph + 15
-            if ((li >> 4) == ph) {
+        for (int ph = 0; ph < 32 / TOK; ph++) {            // tokens TOK ph .. TOK ph + TOK - 1
+            if (li / TOK == ph) {
 #pragma unroll
                 for (int j = 0; j < 2; j++)
 #pragma unroll
@@ -46,15 +49,16 @@ struct LineBounce {
             }
             wave_rendezvous();
 #pragma unroll
-            for (int it = 0; it < 2; it++) {
+            for (int it = 0; it < TOK / 8; it++) {
                 const int t = rd_t + 8 * it;
                 const u32x4 v = *reinterpret_cast<const u32x4*>(scr + t * 128 + ((rd_q ^ (t & 7)) << 4));
-                pp_store16(dst, (16 * ph + t) * row_bytes + col_bytes + rd_q * 16, v);
+                pp_store16(dst, (TOK * ph + t) * row_bytes + col_bytes + rd_q * 16, v);
             }
             wave_rendezvous();
         }
     }
 };
+typedef LineBounceT<16> LineBounce;
 
 // rows of tile t that exist (0 .. 32), in a scalar register (hipcc clamps with a VALU med3, and a resource word in a vector register
 // costs a waterfall loop per access)

@@ -25,6 +25,7 @@
 // order differs.  bf16 only (the fp32 parity mode keeps the GEMM route).
 #pragma once
 #include "common.hpp"
+#include "line_bounce.hpp"
 #include "attn_block.hpp"
 
 namespace rvt {
@@ -141,7 +142,8 @@ __global__ void __launch_bounds__(512)
 stem_fwd_kernel(const uint8_t* __restrict__ src, const bf16* __restrict__ wp, const float* __restrict__ ln_w,
                 const float* __restrict__ ln_b, bf16* __restrict__ y0, bf16* __restrict__ xo, StemGeom g, float eps) {
     typedef bf16 T;
-    __shared__ __attribute__((aligned(16))) char smem[STEM_KSP_MAX * 2048 + 2 * STEM_CO * 4];
+    constexpr int OFF_SCR = STEM_KSP_MAX * 2048 + 2 * STEM_CO * 4;
+    __shared__ __attribute__((aligned(16))) char smem[OFF_SCR + 8 * LineBounceT<8>::BYTES];      // (144 KB of weights: room for the 8-token bounce only)
     char* const Wl = smem;
     float* const kst = reinterpret_cast<float*>(smem + STEM_KSP_MAX * 2048);
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, half = lane >> 5, wave = tid >> 6;
@@ -224,20 +226,27 @@ stem_fwd_kernel(const uint8_t* __restrict__ src, const bf16* __restrict__ wp, co
                     for (int e = 0; e < 8; e++) { const float dlt = v[nb][m][e] - mean; ss += dlt * dlt; }
             ss += __shfl_xor(ss, 32);
             const float rstd = 1.0f / sqrtf(ss * (1.0f / STEM_CO) + eps);
-            if (colok && oy < g.Ho) {
-                const size_t row = (((size_t)f * g.Ho + oy) * g.Wo + ox) * STEM_CO;
+            // rows leave as full 128-byte lines (line_bounce.hpp): a lane owns a pixel, so 16-byte pieces stored directly are 32 bytes
+            // of 32 different lines per instruction; the 32 pixels of the segment are 4 KiB of consecutive memory
+            u32x4 pcy[2][2], pcx[2][2];
 #pragma unroll
-                for (int nb = 0; nb < 2; nb++)
+            for (int nb = 0; nb < 2; nb++)
 #pragma unroll
-                    for (int m = 0; m < 2; m++) {
-                        const int c0 = 32 * nb + 16 * m + 8 * half;
-                        float o[8];
+                for (int m = 0; m < 2; m++) {
+                    const int c0 = 32 * nb + 16 * m + 8 * half;
+                    float o[8];
 #pragma unroll
-                        for (int e = 0; e < 8; e++) o[e] = fmaf((v[nb][m][e] - mean) * rstd, kst[c0 + e], kst[STEM_CO + c0 + e]);
-                        frag_store<T>(y0 + row + c0, yb[nb][m]);
-                        frag_store<T>(xo + row + c0, frag_from_float<T>(o));
-                    }
-            }
+                    for (int e = 0; e < 8; e++) o[e] = fmaf((v[nb][m][e] - mean) * rstd, kst[c0 + e], kst[STEM_CO + c0 + e]);
+                    pcy[nb][m] = __builtin_bit_cast(u32x4, yb[nb][m]);
+                    pcx[nb][m] = __builtin_bit_cast(u32x4, frag_from_float<T>(o));
+                }
+            const int px0 = 32 * (int)xs;
+            const int npx = wave_uniform(oy < g.Ho ? (g.Wo - px0 < 32 ? g.Wo - px0 : 32) : 0);      // existing pixels of the segment (>= 1 unless the row is past Ho)
+            const size_t pbase = (((size_t)f * g.Ho + (oy < g.Ho ? oy : 0)) * g.Wo + px0) * STEM_CO;
+            LineBounceT<8> lb;
+            lb.init(smem + OFF_SCR + wv * LineBounceT<8>::BYTES, lane);
+            lb.flush(pp_make_rsrc(y0 + pbase, (unsigned)(npx * STEM_CO * 2)), pcy, STEM_CO * 2, 0);
+            lb.flush(pp_make_rsrc(xo + pbase, (unsigned)(npx * STEM_CO * 2)), pcx, STEM_CO * 2, 0);
         }
     }
 }
