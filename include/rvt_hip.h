@@ -82,9 +82,10 @@ typedef struct RvtTuning {
                                  recompute backward (input-gradient + weight-gradient launch); 0: LDS-staged forward that saves GELU / GELU' + op-by-op backward */
     int ln_linear;            /* 1 (round 5): LayerNorm + qkv projection of a C = 128 block in one launch where rvt_ln_linear_supported, and fc1 + GELU at K = 256, N = 1024 on the weight-stationary kernel (both ln_linear.hpp) */
     int conv_wgrad_tn;        /* 1 (round 5): conv weight gradients with Cout % 256 == 0 and k*k*Cin % 256 == 0 take ppgemm_tn.hpp (im2col gather by LDS-DMA) */
-    int reserved[5];          /* zero */
+    int attn_staged;          /* 1 (round 5): the partition-attention core of stages 2-4 stages its rows through LDS (whole-line requests) where built */
+    int reserved[4];          /* zero */
 } RvtTuning;
-#define RVT_TUNING_DEFAULTS {(int)sizeof(RvtTuning), 0, 1, 0, 512, 8192, 1, 4096, 0, 0, 0, 0, 1, 4, 0, 1, 1, 0, 0, 1, -1, 1, 1, -1, 1, 1, 0, 1, 1, 0, 1, 1, 1, 1, {0}}
+#define RVT_TUNING_DEFAULTS {(int)sizeof(RvtTuning), 0, 1, 0, 512, 8192, 1, 4096, 0, 0, 0, 0, 1, 4, 0, 1, 1, 0, 0, 1, -1, 1, 1, -1, 1, 1, 0, 1, 1, 0, 1, 1, 1, 1, 1, {0}}
 void rvt_tuning_defaults(RvtTuning* t);        /* fills *t with the production defaults */
 int rvt_get_tuning(RvtTuning* t);              /* t->struct_bytes must be set by the caller */
 int rvt_set_tuning(const RvtTuning* t);

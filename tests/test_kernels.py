@@ -328,6 +328,12 @@ def test_attention(backend, dt, window, case):
     want.backward(f64(dout))
     dq = ops.attn_bwd(qkv, dout, Fr, H, W, C, dh, ph, pw, window)
     close(dq, qr.grad, dt, 'attn_bwd', mult=2.0)
+    if dt == torch.bfloat16:
+        # rows staged through LDS (whole-line requests) against the direct kernels: the same arithmetic on the same values
+        with tuning.override(attn_staged=0):
+            out0 = ops.attn_fwd(qkv, Fr, H, W, C, dh, ph, pw, window)
+            dq0 = ops.attn_bwd(qkv, dout, Fr, H, W, C, dh, ph, pw, window)
+        assert torch.equal(out.cpu(), out0.cpu()) and torch.equal(dq.cpu(), dq0.cpu())
 
 
 AB_CASES = [  # F, H, W, ph, pw   (C = 64, dim_head 32: two heads)
