@@ -107,34 +107,42 @@ attn_core_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, AttnGeom g)
     }
 }
 
-// The same forward with the rows STAGED through LDS (bf16, partitions of 33..64 tokens, dim_head 32).  In the kernel above a lane owns a
+// The same forward with the rows STAGED through LDS (bf16, partitions of 33..96 tokens, dim_head 32).  In the kernel above a lane owns a
 // token and fetches its q / k / v as 16-byte chunks: 32 bytes of 32 different lines per load instruction, and the output rows leave
 // the same way - four times the memory requests of whole lines.  With every load and store instruction of the kernel above replaced by a
 // contiguous 1-KiB access (wrong results, same bytes) the stage-2 launch takes 0.37 instead of 0.48 ms.  Here the 192 contiguous bytes
-// [q | k | v] of a (token, head) arrive by LDS-DMA into a wave-private tile [64 tokens][192 B] (lane-linear destination = the tile
+// [q | k | v] of a (token, head) arrive by LDS-DMA into a wave-private tile [32 NB tokens][192 B] (lane-linear destination = the tile
 // itself; piece p = 64 i + lane is token p / 12, 16-byte piece p % 12 - the token's row offset comes from the lane that computed it by
 // a wave shuffle; tokens beyond L get an out-of-range offset = zeros), the operand fragments are plain 16-byte LDS reads, and the
 // output rows bounce through the same tile and leave as 64-byte pieces of 16 tokens per store instruction.
-template <int HG>
+template <int NB, int HG>
 __global__ void __launch_bounds__(64 * HG)
 attn_core_fwd_staged_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, AttnGeom g, unsigned qkv_bytes, unsigned out_bytes) {
     typedef bf16 T;
-    constexpr int NB = 2, TILE = 64 * 192;
+    static_assert(NB == 2 || NB == 3, "partitions of 33 .. 96 tokens");
+    constexpr int TILE = 32 * NB * 192, NDMA = 32 * NB * 12 / 64;
     __shared__ __attribute__((aligned(16))) char smem[HG * TILE];
     const int lane = threadIdx.x & 63, li = lane & 31, half = lane >> 5;
     const int wv = wave_uniform((int)threadIdx.x >> 6);
     char* const tile = smem + wv * TILE;
     const AcPart a = ac_partition(g, HG, wv);
-    const bool lv = lane < g.L;
-    const int tk = attn_token(g, a.f, a.p, lv ? lane : 0);
-    const int rowq = lv ? tk * (3 * g.C * 2) + a.qoff * 2 : 0x7ffff000;      // byte offsets of this lane's token (slot l = lane) in qkv / out
-    const int rowo = lv ? tk * (g.C * 2) + a.head * 64 : 0x7ffff000;
+    // byte offsets in qkv / out of the partition's token slots: slot l = lane in (rowq, rowo), slot 64 + lane (lanes 0 .. 31, NB = 3) in (rowq2, rowo2)
+    const bool lv = lane < g.L, lv2 = NB == 3 && 64 + lane < g.L;
+    const int tk = attn_token(g, a.f, a.p, lv ? lane : 0), tk2 = NB == 3 ? attn_token(g, a.f, a.p, lv2 ? 64 + lane : 0) : 0;
+    const int rowq = lv ? tk * (3 * g.C * 2) + a.qoff * 2 : 0x7ffff000, rowq2 = lv2 ? tk2 * (3 * g.C * 2) + a.qoff * 2 : 0x7ffff000;
+    const int rowo = lv ? tk * (g.C * 2) + a.head * 64 : 0x7ffff000, rowo2 = lv2 ? tk2 * (g.C * 2) + a.head * 64 : 0x7ffff000;
+    auto slot = [&](int v, int v2, int t) __attribute__((always_inline)) {     // the offset of token slot t, from the lane that holds it
+        const int lo = __shfl(v, t & 63);
+        if (NB == 2) return lo;
+        const int hi = __shfl(v2, t & 31);
+        return t < 64 ? lo : hi;
+    };
     {
         const pp_rsrc rq = pp_make_rsrc(qkv, qkv_bytes);
 #pragma unroll
-        for (int i = 0; i < 12; i++) {
-            const int p = 64 * i + lane, t = (p * 5462) >> 16, w = p - 12 * t;       // p / 12 for p < 768
-            pp_glds16(rq, smem, wv * TILE + i * 1024, __shfl(rowq, t) + w * 16, 0);
+        for (int i = 0; i < NDMA; i++) {
+            const int p = 64 * i + lane, t = (p * 5462) >> 16, w = p - 12 * t;       // p / 12 for p < 1152
+            pp_glds16(rq, smem, wv * TILE + i * 1024, slot(rowq, rowq2, t) + w * 16, 0);
         }
     }
     const int klim = g.L - 32 * (NB - 1) - 4 * half;
@@ -188,7 +196,7 @@ attn_core_fwd_staged_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out
         for (int it = 0; it < 2; it++) {
             const int t = 16 * it + (lane >> 2), q = lane & 3;
             const u32x4 v = *reinterpret_cast<const u32x4*>(tile + t * 64 + ((q ^ (t & 3)) << 4));
-            pp_store16(ro, __shfl(rowo, 32 * bi + t) + q * 16, v);
+            pp_store16(ro, slot(rowo, rowo2, 32 * bi + t) + q * 16, v);
         }
     }
 }
@@ -307,14 +315,14 @@ attn_core_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ dout, T* _
 // The backward with its rows staged the same way: [q | k | v] (192 B per token and head) and dO (64 B) arrive by LDS-DMA into a
 // wave-private 16-KiB region whose head is reused for the P / dS tiles once the fragments are in registers; dQ, dK, dV leave through a
 // 2-KiB bounce as 64-byte pieces of 16 tokens per store instruction.  The arithmetic is that of attn_core_bwd_kernel, value for value.
-template <int HG>
-__global__ void __launch_bounds__(64 * HG, 2)
+template <int NB, int HG>
+__global__ void __launch_bounds__(64 * HG, NB == 3 ? 1 : 2)
 attn_core_bwd_staged_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout, bf16* __restrict__ dqkv, AttnGeom g,
                             unsigned qkv_bytes, unsigned out_bytes) {
     typedef bf16 T;
-    constexpr int NB = 2;
+    static_assert(NB == 2 || NB == 3, "partitions of 33 .. 96 tokens");
     typedef AbBwdScratch<T, NB> SC;
-    constexpr int QKV_T = 64 * 192, DO_T = 64 * 64, REGION = QKV_T + DO_T;       // 16 KiB per wave
+    constexpr int QKV_T = 32 * NB * 192, DO_T = 32 * NB * 64, REGION = QKV_T + DO_T;       // 16 (24) KiB per wave
     static_assert(SC::BYTES + 32 * 64 <= REGION, "P / dS tiles + the store bounce reuse the staging region");
     __shared__ __attribute__((aligned(16))) char smem[HG * REGION];
     const int lane = threadIdx.x & 63, li = lane & 31, half = lane >> 5;
@@ -325,21 +333,28 @@ attn_core_bwd_staged_kernel(const bf16* __restrict__ qkv, const bf16* __restrict
     char* const bnc = reg + SC::BYTES;                    // [32 tokens][64 B]
     const AcPart a = ac_partition(g, HG, wv);
     const int C3 = 3 * g.C;
-    const bool lv = lane < g.L;
-    const int tk = attn_token(g, a.f, a.p, lv ? lane : 0);
-    const int rowq = lv ? tk * (C3 * 2) + a.qoff * 2 : 0x7ffff000;            // byte offsets of this lane's token (slot l = lane)
-    const int rowo = lv ? tk * (g.C * 2) + a.head * 64 : 0x7ffff000;
+    // byte offsets of the partition's token slots (see the forward)
+    const bool lv = lane < g.L, lv2 = NB == 3 && 64 + lane < g.L;
+    const int tk = attn_token(g, a.f, a.p, lv ? lane : 0), tk2 = NB == 3 ? attn_token(g, a.f, a.p, lv2 ? 64 + lane : 0) : 0;
+    const int rowq = lv ? tk * (C3 * 2) + a.qoff * 2 : 0x7ffff000, rowq2 = lv2 ? tk2 * (C3 * 2) + a.qoff * 2 : 0x7ffff000;
+    const int rowo = lv ? tk * (g.C * 2) + a.head * 64 : 0x7ffff000, rowo2 = lv2 ? tk2 * (g.C * 2) + a.head * 64 : 0x7ffff000;
+    auto slot = [&](int v, int v2, int t) __attribute__((always_inline)) {
+        const int lo = __shfl(v, t & 63);
+        if (NB == 2) return lo;
+        const int hi = __shfl(v2, t & 31);
+        return t < 64 ? lo : hi;
+    };
     {
         const pp_rsrc rq = pp_make_rsrc(qkv, qkv_bytes), rd = pp_make_rsrc(dout, out_bytes);
 #pragma unroll
-        for (int i = 0; i < 12; i++) {
-            const int p = 64 * i + lane, t = (p * 5462) >> 16, w = p - 12 * t;       // p / 12 for p < 768
-            pp_glds16(rq, smem, wv * REGION + i * 1024, __shfl(rowq, t) + w * 16, 0);
+        for (int i = 0; i < QKV_T / 1024; i++) {
+            const int p = 64 * i + lane, t = (p * 5462) >> 16, w = p - 12 * t;       // p / 12 for p < 1152
+            pp_glds16(rq, smem, wv * REGION + i * 1024, slot(rowq, rowq2, t) + w * 16, 0);
         }
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < DO_T / 1024; i++) {
             const int p = 64 * i + lane;
-            pp_glds16(rd, smem, wv * REGION + QKV_T + i * 1024, __shfl(rowo, p >> 2) + (p & 3) * 16, 0);
+            pp_glds16(rd, smem, wv * REGION + QKV_T + i * 1024, slot(rowo, rowo2, p >> 2) + (p & 3) * 16, 0);
         }
     }
     const int klim = g.L - 32 * (NB - 1) - 4 * half;
@@ -376,7 +391,7 @@ attn_core_bwd_staged_kernel(const bf16* __restrict__ qkv, const bf16* __restrict
         for (int it = 0; it < 2; it++) {
             const int t = 16 * it + (lane >> 2), q = lane & 3;
             const u32x4 v = *reinterpret_cast<const u32x4*>(bnc + t * 64 + ((q ^ (t & 3)) << 4));
-            pp_store16(ro, __shfl(rowq, 32 * b + t) + off + q * 16, v);
+            pp_store16(ro, slot(rowq, rowq2, 32 * b + t) + off + q * 16, v);
         }
     };
     f32x16 dk[NB], dv[NB];

@@ -34,21 +34,21 @@ static void launch_attn(bool bwd, const void* qkv, const void* dout, void* out, 
     dim3 grid((unsigned)(g.F * g.P * (g.heads / HG)));
     if constexpr (HG == 1 || HG * AbBwdScratch<T, NB>::BYTES <= ATTN_LDS_BUDGET) {
         if (bwd) {
-            if constexpr (sizeof(T) == 2 && NB == 2) {
+            if constexpr (sizeof(T) == 2 && (NB == 2 || NB == 3)) {
                 const size_t qb = (size_t)g.F * g.H * g.W * 3 * g.C * 2, ob = qb / 3;
                 if (g.dh == 32 && qb < 0x7fff0000ull && tuning().attn_staged != 0) {
-                    hipLaunchKernelGGL((attn_core_bwd_staged_kernel<HG>), grid, dim3(64 * HG), 0, st, (const bf16*)qkv, (const bf16*)dout, (bf16*)out, g,
+                    hipLaunchKernelGGL((attn_core_bwd_staged_kernel<NB, HG>), grid, dim3(64 * HG), 0, st, (const bf16*)qkv, (const bf16*)dout, (bf16*)out, g,
                                        (unsigned)qb, (unsigned)ob);
                     return;
                 }
             }
             hipLaunchKernelGGL((attn_core_bwd_kernel<T, NB, HG>), grid, dim3(64 * HG), 0, st, (const T*)qkv, (const T*)dout, (T*)out, g);
         } else {
-            if constexpr (sizeof(T) == 2 && NB == 2) {
+            if constexpr (sizeof(T) == 2 && (NB == 2 || NB == 3)) {
                 // rows staged through LDS (attn_core_fwd_staged_kernel): dim_head 32, tensors below 2 GiB; tuning.attn_staged = 0: the direct kernel
                 const size_t qb = (size_t)g.F * g.H * g.W * 3 * g.C * 2, ob = qb / 3;
                 if (g.dh == 32 && qb < 0x7fff0000ull && tuning().attn_staged != 0) {
-                    hipLaunchKernelGGL((attn_core_fwd_staged_kernel<HG>), grid, dim3(64 * HG), 0, st, (const bf16*)qkv, (bf16*)out, g, (unsigned)qb, (unsigned)ob);
+                    hipLaunchKernelGGL((attn_core_fwd_staged_kernel<NB, HG>), grid, dim3(64 * HG), 0, st, (const bf16*)qkv, (bf16*)out, g, (unsigned)qb, (unsigned)ob);
                     return;
                 }
             }
