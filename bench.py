@@ -6,6 +6,10 @@ all-reduce when N>1) over one synthetic event-tensor sequence batch.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
+Both forms work for N > 1: without a launcher (`WORLD_SIZE` unset) the first form starts its N ranks itself under
+torch.distributed.run (`self_launch`).  The default N=1 line also carries `also`: BASELINE configs[1] (RVT-Tiny / Gen1
+training step) and configs[4] (streaming-inference latency) measured right after the headline run.
+
 Workload (default): BASELINE.json configs[2] — RVT-Base, 1 Mpx shape (20x360x640 uint8, padded to 384x640
 by the model), T=21, batch=24 per GPU, bf16, random-init weights, inputs resident in HBM.
 A "step" = forward_sequence over (T,B) + backward with random upstream gradients on the stage 2/3/4
@@ -313,9 +317,9 @@ def cpu_baseline(workload: str):
                     sample=f'cpu baseline did not finish within its 150 s bound ({type(e).__name__})')
 
 
-def stream_latency(wl, dtype, device, args):
+def stream_latency(wl, dtype, device, args, with_detector=True):
     """BASELINE configs[4]: one forward step (T=1) on a batch of 64 streams with the ConvLSTM state carried across
-    steps (the validation / deployment path, modules/detection.py:231-255), latency per step."""
+    steps (the validation / deployment path, modules/detection.py:231-255), latency per step.  Returns the record."""
     model = build_model(wl, dtype, device)
     Bs = args.batch or 64
     g = torch.Generator(device=device).manual_seed(3)
@@ -347,6 +351,16 @@ def stream_latency(wl, dtype, device, args):
     gpu = sorted(x[1] for x in lat)
     host = sorted(x[2] for x in lat)
     pct = lambda a, q: a[min(len(a) - 1, int(q * len(a)))]
+    rec = {'metric': 'streaming-inference step latency (T=1, persistent ConvLSTM state)', 'unit': 'ms',
+           'batch': Bs, 'dtype': args.dtype, 'config': {'workload': wl['label'].split(',')[0] + f', B={Bs}, T=1'},
+           'wall_p50': round(pct(wall, 0.5), 3), 'wall_p99': round(pct(wall, 0.99), 3),
+           'gpu_p50': round(pct(gpu, 0.5), 3), 'gpu_p99': round(pct(gpu, 0.99), 3),
+           'host_enqueue_p50': round(pct(host, 0.5), 3),
+           'mfma_frac_p50': round(Bs * wl['f_fwd'] / (pct(wall, 0.5) * 1e-3) / (PEAK_TFLOPS[args.dtype] * 1e12), 4),
+           'event_tensors_per_s_p50': round(Bs / pct(wall, 0.5) * 1e3, 1),
+           'steps_timed': len(lat), 'higher_is_better': False, 'data': 'synthetic'}
+    if not with_detector:
+        return rec
     # the whole detector step (rows f2 / f3): backbone step + YOLOX PAFPN + head + decode, inference mode, random-init weights
     from rvt_amd import fpn as _fpn, head as _head
     dims, strides = model.get_stage_dims((2, 3, 4)), model.get_strides((2, 3, 4))
@@ -365,16 +379,87 @@ def stream_latency(wl, dtype, device, args):
             torch.cuda.synchronize()
             det.append(1e3 * (time.perf_counter() - t0))
     det.sort()
-    print(json.dumps({'metric': 'streaming-inference step latency (T=1, persistent ConvLSTM state)', 'unit': 'ms',
-                      'batch': Bs, 'dtype': args.dtype, 'config': {'workload': wl['label'].split(',')[0] + f', B={Bs}, T=1'},
-                      'wall_p50': round(pct(wall, 0.5), 3), 'wall_p99': round(pct(wall, 0.99), 3),
-                      'gpu_p50': round(pct(gpu, 0.5), 3), 'gpu_p99': round(pct(gpu, 0.99), 3),
-                      'host_enqueue_p50': round(pct(host, 0.5), 3),
-                      'mfma_frac_p50': round(Bs * wl['f_fwd'] / (pct(wall, 0.5) * 1e-3) / (PEAK_TFLOPS[args.dtype] * 1e12), 4),
-                      'event_tensors_per_s_p50': round(Bs / pct(wall, 0.5) * 1e3, 1),
-                      'detector_wall_p50': round(pct(det, 0.5), 3), 'detector_wall_p99': round(pct(det, 0.99), 3),
-                      'detector_note': 'backbone step + YOLOX PAFPN + head + decode (rvt_amd.fpn / rvt_amd.head, inference mode), same batch',
-                      'higher_is_better': False, 'data': 'synthetic'}), flush=True)
+    rec.update({'detector_wall_p50': round(pct(det, 0.5), 3), 'detector_wall_p99': round(pct(det, 0.99), 3),
+                'detector_note': 'backbone step + YOLOX PAFPN + head + decode (rvt_amd.fpn / rvt_amd.head, inference mode), same batch'})
+    return rec
+
+
+def also_configs(dtype_name, device, args):
+    """BASELINE configs[1] (RVT-Tiny, Gen1, T=21, B=8, fwd+bwd+AdamW) and configs[4] (RVT-Base 1Mpx streaming step, B=64, T=1)
+    measured in the same process right after the headline run, so that the ONE line the driver records carries them too
+    (`also`).  Same step definition, same synchronisation as the headline; a few seconds in total."""
+    import gc
+    dtype = torch.bfloat16 if dtype_name == 'bf16' else torch.float32
+    out = {}
+    try:
+        wl = WORKLOADS['tiny_gen1']
+        model = build_model(wl, dtype, device)
+        params = list(model.parameters())
+        opt = torch.optim.AdamW(params, lr=2e-4, fused=True)
+        xs = make_batch(wl, device, seed=1)
+        T, B = wl['T'], wl['B']
+        geoms = model.stage_geoms(*model.in_res_hw)
+        gen = torch.Generator(device=device).manual_seed(7)
+        cots = {s + 1: torch.randn((T, B, geoms[s].H, geoms[s].W, geoms[s].C), generator=gen, device=device,
+                                   dtype=dtype).permute(0, 1, 4, 2, 3) for s in (1, 2, 3)}
+
+        def step():
+            feats, _ = model.forward_sequence(xs, None)
+            torch.autograd.backward([feats[s] for s in (2, 3, 4)], [cots[s] for s in (2, 3, 4)])
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        step()
+        host_one = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        gc.collect()
+        K = 20
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            step()
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / K
+        ev = B * T / (ms * 1e-3)
+        out['tiny_gen1'] = {'config': 'BASELINE configs[1]: ' + wl['label'] + f', {dtype_name}, fwd+bwd+AdamW(fused)', 'steps': K,
+                            'ms_per_step': round(ms, 3), 'value': round(ev, 1), 'unit': 'event-tensors/s',
+                            'mfma_frac': round(ev * wl['f_fwdbwd'] / (PEAK_TFLOPS[dtype_name] * 1e12), 4),
+                            'host_enqueue_ms_per_step': round(1e3 * host_one, 2)}
+        del model, params, opt, xs, cots
+    except Exception as e:                         # never lose the headline to a secondary measurement
+        out['tiny_gen1'] = {'error': f'{type(e).__name__}: {e}'[:300]}
+    try:
+        ns = argparse.Namespace(batch=None, warmup=3, steps=100, dtype=dtype_name)
+        r = stream_latency(dict(WORKLOADS['base_1mpx']), dtype, device, ns, with_detector=False)
+        out['stream_latency'] = {'config': 'BASELINE configs[4]: ' + r['config']['workload'] + f', {dtype_name}, persistent ConvLSTM state',
+                                 'p50': r['wall_p50'], 'p99': r['wall_p99'], 'gpu_p50': r['gpu_p50'], 'gpu_p99': r['gpu_p99'],
+                                 'host_enqueue_p50': r['host_enqueue_p50'], 'unit': 'ms', 'steps': r['steps_timed'],
+                                 'mfma_frac_p50': r['mfma_frac_p50'], 'event_tensors_per_s_p50': r['event_tensors_per_s_p50']}
+    except Exception as e:
+        out['stream_latency'] = {'error': f'{type(e).__name__}: {e}'[:300]}
+    return out
+
+
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks of this very command under torch.distributed.run (one
+    process per GPU, RCCL rendezvous on 127.0.0.1, a free port) - what the reference gets from one trainer flag
+    (train.py:60-67,133).  Rank 0's JSON line goes to our stdout unchanged."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f'[bench] --gpus {n} without WORLD_SIZE: launching {n} ranks under torch.distributed.run (127.0.0.1:{port})',
+          file=sys.stderr, flush=True)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault('OMP_NUM_THREADS', '4')
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -398,6 +483,8 @@ def main():
     ap.add_argument('--stream-latency', action='store_true',
                     help='BASELINE configs[4] instead of the training step: T=1 streaming inference with persistent '
                          'ConvLSTM state, batch 64; prints per-step latency percentiles (not the headline metric)')
+    ap.add_argument('--no-also', action='store_true',
+                    help='skip the `also` object (BASELINE configs[1] and [4] measured after the headline run)')
     ap.add_argument('--tuning', action='append', default=[], metavar='FIELD=INT',
                     help='experiment only: override a field of the RvtTuning record (the line then carries config.tuning_overrides)')
     args = ap.parse_args()
@@ -414,10 +501,18 @@ def main():
         wl['B'] = args.batch
     if args.seq:
         wl['T'] = args.seq
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args.gpus))          # one process per GPU; this process only waits for them
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
+    if world != args.gpus:
+        sys.exit(f'bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}; pass the same N to both '
+                 f'(or drop the launcher: `python bench.py --gpus N` starts the ranks itself)')
+    visible = torch.cuda.device_count()
+    if local_rank >= visible:
+        sys.exit(f'bench.py: rank {rank} of {world} needs cuda:{local_rank} but only {visible} device(s) are visible on this box '
+                 f'(one process per GPU; no CPU fallback)')
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
     import torch.distributed as dist
@@ -426,7 +521,8 @@ def main():
 
     dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
     if args.stream_latency:
-        return stream_latency(wl, dtype, device, args)
+        print(json.dumps(stream_latency(wl, dtype, device, args)), flush=True)
+        return
     model = build_model(wl, dtype, device)
     params = [p for p in model.parameters()]
     use_graph = args.graph == 'on' or (args.graph == 'auto' and world == 1 and not args.force_reducer)
@@ -637,6 +733,8 @@ def main():
             'roofline_table': top_table,
             'roofline_entry_points': entry_table,
             'instrumented_step_ms': round(step_ms_instrumented, 3),
+            'instrumented_step_note': 'sum over launches of min(duration in pass 1, duration in pass 2) of two instrumented steps: a lower '
+                                      'envelope, not comparable with eager_ms_per_step (a mean over K un-instrumented steps)',
             'hbm_traffic_per_step': {'measured_bytes': step_traffic(wkey), 'source': 'profiles/latest_traffic.json (rocprofv3 FETCH_SIZE x2 + '
                                      'WRITE_SIZE passes of this command), null when no pass of THIS workload is committed',
                                      # what the launches of one step move if every operand / result crosses HBM exactly once (opmodel.py, sum
@@ -654,6 +752,12 @@ def main():
         }
         if dist_info is not None:
             out['distributed'] = dist_info
+        if world == 1 and args.workload == 'base_1mpx' and not args.no_also and not (args.batch or args.seq):
+            del xs, cots
+            model = opt = params = None
+            gc.collect()
+            torch.cuda.empty_cache()
+            out['also'] = also_configs(args.dtype, device, args)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.workload)
         print(json.dumps(out), flush=True)

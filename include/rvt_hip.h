@@ -81,7 +81,7 @@ typedef struct RvtTuning {
     int mlp_stream;           /* 1 (round 5): C = 128 MLP halves take the streamed-weight chain kernels (mlp_stream.hpp): nothing-saved forward,
                                  recompute backward (input-gradient + weight-gradient launch); 0: LDS-staged forward that saves GELU / GELU' + op-by-op backward */
     int ln_linear;            /* 1 (round 5): LayerNorm + qkv projection of a C = 128 block in one launch where rvt_ln_linear_supported, and fc1 + GELU at K = 256, N = 1024 on the weight-stationary kernel (both ln_linear.hpp) */
-    int conv_wgrad_tn;        /* 1 (round 5): conv weight gradients with Cout % 256 == 0 and k*k*Cin % 256 == 0 take ppgemm_tn.hpp (im2col gather by LDS-DMA) */
+    int conv_wgrad_tn;        /* 1 (round 5): conv weight gradients with Cout % 256 == 0, Cin % 64 == 0 and k*k*Cin >= 256 take ppgemm_tn.hpp (im2col gather by LDS-DMA; the last 256-wide k tile may lie partly beyond K) */
     int attn_staged;          /* 1 (round 5): the partition-attention core of stages 2-4 stages its rows through LDS (whole-line requests) where built */
     int reserved[4];          /* zero */
 } RvtTuning;
@@ -154,7 +154,9 @@ int rvt_layernorm_bwd(const void* x, const float* w, const void* dy, const void*
 int rvt_linear_fwd(const void* x, const void* w, const float* bias, void* y, int dtype, int M, int N, int K,
                    int gelu_in, void* stream);
 /* MLP fc1 with its activation (maxvit.py:100-112): g = GELU(x W^T + bias) and, if gp != NULL, gp = GELU'(x W^T + bias)
- * (saved for backward so that no kernel re-evaluates erf). */
+ * (saved for backward so that no kernel re-evaluates erf).  Route note: bf16 at K = 256, N = 1024 (any M) takes the
+ * weight-stationary kernel of ln_linear.hpp, whose GELU / GELU' come from the nearest-entry pair table of gelu_lut.hpp
+ * (tests/test_kernels.py::test_linear_gelu_weight_stationary); every other shape evaluates erf. */
 int rvt_linear_gelu_fwd(const void* x, const void* w, const float* bias, void* g, void* gp, int dtype, int M, int N, int K,
                         void* stream);
 /* y = res + gamma * (f(x) W^T + bias)   — LayerScale + residual (maxvit.py:51-53,268-269). */

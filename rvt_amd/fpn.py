@@ -68,11 +68,12 @@ class _BaseConvFn(torch.autograd.Function):
         bn = mod.bn
         g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
         y = torch.empty_like(y0)
-        if bn.momentum is None or not bn.track_running_stats:
-            raise NotImplementedError('rvt_amd.fpn.BaseConv: BatchNorm2d with momentum=None (cumulative average) or '
-                                      'track_running_stats=False is not built (no shipped config uses either)')
-        mom = float(bn.momentum)
-        rm, rv = (L.ptr(bn.running_mean), L.ptr(bn.running_var)) if bn.track_running_stats else (None, None)
+        if not bn.track_running_stats or (training and bn.momentum is None):
+            # (an eval / no-grad forward never updates the running statistics: momentum is irrelevant there)
+            raise NotImplementedError('rvt_amd.fpn.BaseConv: BatchNorm2d with track_running_stats=False, or a training forward with '
+                                      'momentum=None (cumulative average), is not built (no shipped config uses either)')
+        mom = 0.0 if bn.momentum is None else float(bn.momentum)
+        rm, rv = L.ptr(bn.running_mean), L.ptr(bn.running_var)
         if training:                                                                      # finalize + activation in one launch
             L.call('rvt_bn_train_act_fwd', L.ptr(y0), L.ptr(stats[0]), L.ptr(stats[1]), count, L.ptr(g32), L.ptr(b32), float(bn.eps), mom,
                    rm, rv, L.ptr(fin[0]), L.ptr(fin[1]), L.ptr(fin[2]), L.ptr(fin[3]), L.ptr(y), L.dtype_code(dt), rows, Cout,

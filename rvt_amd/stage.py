@@ -125,6 +125,10 @@ class SideStream:
             self.stream.wait_event(ev)
             for fn in self._queue:
                 fn()
+        # the closures hold the last references to what their launches read (the stage's saved activations: backbone.py has
+        # already dropped ctx.svs[si]); they stay alive until join() has ordered the main stream behind the side stream -
+        # dropping them here would hand the blocks back to the caching allocator while the side-stream kernels are pending
+        self._keep.extend(self._queue)
         self._queue = []
         self._flushed = True
         return True

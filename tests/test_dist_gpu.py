@@ -56,3 +56,29 @@ def test_bench_under_torchrun_world1():
                         '--force-reducer'], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert '"value"' in r.stdout
+
+
+def test_bench_gpus2_self_launch_reports_missing_device():
+    """`python bench.py --gpus 2` (no launcher) starts two ranks itself; on a one-GPU box rank 1 says which device is missing."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip('>= 2 GPUs here: the launch would run the real 2-GPU bench')
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0',
+                        '--workload', 'tiny_gen1', '--no-cpu-baseline'], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode != 0
+    assert 'launching 2 ranks under torch.distributed.run' in r.stderr
+    assert 'needs cuda:1 but only 1 device(s) are visible' in r.stderr, r.stderr[-3000:]
+
+
+def test_bench_default_line_carries_also_configs():
+    """The N=1 headline line carries BASELINE configs[1] and configs[4] under `also` (driver-visible)."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '2', '--warmup', '1', '--no-cpu-baseline'],
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    also = line['also']
+    assert also['tiny_gen1']['value'] > 0 and also['tiny_gen1']['ms_per_step'] > 0, also
+    assert also['stream_latency']['p50'] > 0 and also['stream_latency']['p99'] >= also['stream_latency']['p50'], also
+    assert line['roofline']['frac'] < 1 and line['n_gpus'] == 1

@@ -460,3 +460,31 @@ def test_dropin_through_reference_registry_and_detector(tmp_path):
     script.write_text(DROPIN_WORKER)
     r = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and 'DROPIN OK' in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_bench_gpus_n_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the form the scaling run uses) must START two ranks under
+    torch.distributed.run instead of asserting, and each rank must then fail loudly - with the device count in the message -
+    when the box has fewer GPUs than ranks (this container: none).  No CPU fallback."""
+    import subprocess
+    import sys
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip('box has >= 2 GPUs: the launch would succeed (covered by the gpu-marked test)')
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0',
+                        '--workload', 'tiny_gen1', '--no-cpu-baseline'], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0
+    assert 'launching 2 ranks under torch.distributed.run' in r.stderr, r.stderr[-2000:]
+    assert 'AssertionError' not in r.stderr, r.stderr[-2000:]
+    n_vis = torch.cuda.device_count()
+    # every rank whose device is missing says so itself (rank 1 always; rank 0 too when there is no GPU at all)
+    assert f'needs cuda:1 but only {n_vis} device(s) are visible' in r.stderr, r.stderr[-2000:]
+
+
+def test_bench_rejects_mismatched_world_size():
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0',
+                        '--no-cpu-baseline'], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and 'WORLD_SIZE=1' in r.stderr and 'AssertionError' not in r.stderr, r.stderr[-1500:]

@@ -300,3 +300,34 @@ def test_deferred_weight_gradient_stream_gives_identical_gradients():
     for k, a in res[0][0].items():
         b = res[2][0][k]
         assert float((a - b).abs().max()) <= 1e-5 * max(float(a.abs().max()), 1e-30), k
+
+
+def test_deferred_side_stream_keeps_operands_alive_until_join():
+    """SideStream.flush() launches the queued closures on the side stream; whatever they read must stay referenced until
+    join() has ordered the main stream behind them (the closures are the last owners of a stage's saved activations).  Checked on the
+    object level: a tensor owned only by a queued closure survives flush() and is released by join()."""
+    import gc
+    import weakref
+    from rvt_amd import tuning as tn
+    from rvt_amd.stage import SideStream
+    with tn.override(route_wgrad_stream=2):
+        like = torch.zeros(8, device=DEV)
+        side = SideStream(like)
+        assert side.enabled and side.defer_mode
+        side.deferring = True
+        owned = torch.ones(1 << 20, device=DEV)
+        out = torch.zeros(1, device=DEV)
+        ref = weakref.ref(owned)
+
+        def fn(owned=owned):
+            out.add_(owned.sum())
+        side.run(fn)                       # no operand list on purpose: the closure is the only owner (qkv_wgrad_fn reads s['u'] like this)
+        del owned, fn
+        assert side.flush()
+        gc.collect()
+        assert ref() is not None, 'flush() dropped the last reference to a tensor the side stream is still reading'
+        side.join()
+        gc.collect()
+        assert ref() is None
+        torch.cuda.synchronize()
+        assert float(out) == float(1 << 20)
