@@ -83,9 +83,11 @@ typedef struct RvtTuning {
     int ln_linear;            /* 1 (round 5): LayerNorm + qkv projection of a C = 128 block in one launch where rvt_ln_linear_supported, and fc1 + GELU at K = 256, N = 1024 on the weight-stationary kernel (both ln_linear.hpp) */
     int conv_wgrad_tn;        /* 1 (round 5): conv weight gradients with Cout % 256 == 0, Cin % 64 == 0 and k*k*Cin >= 256 take ppgemm_tn.hpp (im2col gather by LDS-DMA; the last 256-wide k tile may lie partly beyond K) */
     int attn_staged;          /* 1 (round 5): the partition-attention core of stages 2-4 stages its rows through LDS (whole-line requests) where built */
-    int reserved[4];          /* zero */
+    int lstm_scan3;           /* 1 (round 6): the ConvLSTM of the wide stages (bf16, C = 256, dws_conv False) runs with the time loop in the kernel, weights streamed from L2 in operand order, gates saved for the reverse scan (lstm_scan3.hpp) */
+    int lstm_scan3_rb256;     /* 32-token blocks per workgroup tile of that forward at C = 256: 1 or 2 */
+    int reserved[2];          /* zero */
 } RvtTuning;
-#define RVT_TUNING_DEFAULTS {(int)sizeof(RvtTuning), 0, 1, 0, 512, 8192, 1, 4096, 0, 0, 0, 0, 1, 4, 0, 1, 1, 0, 0, 1, -1, 1, 1, -1, 1, 1, 0, 1, 1, 0, 1, 1, 1, 1, 1, {0}}
+#define RVT_TUNING_DEFAULTS {(int)sizeof(RvtTuning), 0, 1, 0, 512, 8192, 1, 4096, 0, 0, 0, 0, 1, 4, 0, 1, 1, 0, 0, 1, -1, 1, 1, -1, 1, 1, 0, 1, 1, 0, 1, 1, 1, 1, 1, 1, 1, {0}}
 void rvt_tuning_defaults(RvtTuning* t);        /* fills *t with the production defaults */
 int rvt_get_tuning(RvtTuning* t);              /* t->struct_bytes must be set by the caller */
 int rvt_set_tuning(const RvtTuning* t);
@@ -297,6 +299,26 @@ int rvt_lstm_scan_bwd(const void* x_all, const void* Hall, const void* Csave, co
                       const float* dc_last, const void* w, const void* wt, const float* bias, void* dx_all, void* dz_all,
                       void* dh0, float* dc0, float* dw, float* db, float* ws, const void* gates, int dtype, int M, int C,
                       int T_steps, void* stream);
+
+/* ---- ConvLSTM of the WIDE stages with the time loop in the kernel (csrc/lstm_scan3.hpp; reference models/layers/rnn.py:43-67 over
+ * the loop of modules/detection.py:131-148, and its BPTT).  bf16, dws_conv False, C = 256 (rvt_lstm_scan3_supported).  The weights do
+ * not fit on chip: they are streamed from L2 every step in MFMA-operand order, which rvt_lstm_scan3_pack produces once per
+ * optimizer step from the natural [4C][2C] matrix (gate order f,i,o,g, input order [x | h]: rnn.py:52-61):
+ *   wp_fwd  [C/64][2C/16][8][64][8]   (wave, k-step, (channel block, gate), lane, element)    = 4C * 2C elements
+ *   wtp_bwd [C/64][4C/16][4][64][8]   (wave, k-step, (channel block, x | h part), lane, element) = rows of W^T, same size
+ * Forward: x_all [T][M][C], Hall [T+1][M][C] (slot 0 = incoming h, filled by the caller; slots 1.. written), c0 fp32 [M][C] or
+ * NULL (zeros, rnn.py:43-47), c_last fp32 [M][C].  For BPTT it saves the ACTIVATED gates (gsave) and a bf16 copy of the cell
+ * states (Csave) in a private register-dump order; both buffers hold T * rvt_lstm_scan3_rows(C, M) * 4C / * C elements and are
+ * NULL together for a no-grad forward.  Backward: reads them back (same M, same tuning), dH [T][M][C] = cotangent of Hall[1..]
+ * (NULL = zeros), dc_last fp32 [M][C] (NULL = zeros); writes dx_all [T][M][C], dz_all [T][M][4C] (natural gate order: the operand
+ * of rvt_lstm_wgrad), dh0 [M][C], dc0 fp32 [M][C]. */
+int rvt_lstm_scan3_supported(int dtype, int C);
+int rvt_lstm_scan3_rows(int C, int M);
+int rvt_lstm_scan3_pack(const void* w, void* wp_fwd, void* wtp_bwd, int C, void* stream);
+int rvt_lstm_scan3_fwd(const void* x_all, void* Hall, const float* c0, float* c_last, void* Csave, const void* wp, const float* bias,
+                       void* gsave, int dtype, int M, int C, int T_steps, void* stream);
+int rvt_lstm_scan3_bwd(const void* gsave, const void* Csave, const float* c0, const void* dH, const float* dc_last, const void* wtp,
+                       void* dx_all, void* dz_all, void* dh0, float* dc0, int dtype, int M, int C, int T_steps, void* stream);
 
 /* ---- stage-major driver (rvt_stage_seq_fwd) -------------------------------------------------------------
  * One backbone stage (reference maxvit_rnn.py:169-182: down-sampling conv + LayerNorm, the window and grid attention blocks,

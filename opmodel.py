@@ -141,6 +141,17 @@ def model(name: str, a) -> Optional[Tuple[float, float]]:
         fl = 16.0 + (16.0 if wgrad else 0.0)                                 # dgrad (+ in-kernel weight gradient); executed: + gate recompute (16) unless the gates were saved
         rows = (2 + 4 if saved_gates else 4) + 1 + (4 if dz else 0)          # (c, dH, gates | x, h, c, dH) in, dx out (+ dz out)
         return fl * M * C * C * T, 1.0 * rows * M * C * T * e + 16.0 * M * C + 16 * C * C * e
+    if name == 'rvt_lstm_scan3_fwd':                     # wide stages: x in, h out (+ bf16 c copy + 4 activated gates when saving); weights once
+        e, M, C, T = _elt(a[8]), a[9], a[10], a[11]
+        rows = 2 + (5 if P(7) else 0)
+        return 16.0 * M * C * C * T, 1.0 * rows * M * C * T * e + 8.0 * M * C + 8 * C * C * e
+    if name == 'rvt_lstm_scan3_bwd':                     # gates (4) + c + dH in, dz (4) + dx out; W^T once
+        e, M, C, T = _elt(a[10]), a[11], a[12], a[13]
+        rows = 4 + 1 + (1 if P(3) else 0) + 4 + 1
+        return 16.0 * M * C * C * T, 1.0 * rows * M * C * T * e + 16.0 * M * C + 8 * C * C * e
+    if name == 'rvt_lstm_scan3_pack':
+        C = a[3]
+        return 0.0, 8.0 * C * C * 2 * (1 + (1 if P(1) else 0) + (1 if P(2) else 0))
     if name == 'rvt_dwconv_fwd':
         e, N, H, W, C, k = _elt(a[6]), *a[7:12]
         return 0.0, 2.0 * N * H * W * C * e

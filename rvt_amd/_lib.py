@@ -62,6 +62,9 @@ _SIGS = {
     'rvt_mlp_bwd_recompute_both': [_vp] * 16 + [_i, _i, _i, _f, _vp],
     'rvt_lstm_scan_fwd': [_vp] * 8 + [_i, _i, _i, _i, _vp],
     'rvt_lstm_scan_bwd': [_vp] * 17 + [_i, _i, _i, _i, _vp],
+    'rvt_lstm_scan3_pack': [_vp, _vp, _vp, _i, _vp],
+    'rvt_lstm_scan3_fwd': [_vp] * 8 + [_i, _i, _i, _i, _vp],
+    'rvt_lstm_scan3_bwd': [_vp] * 10 + [_i, _i, _i, _i, _vp],
     'rvt_layerscale_grad_table': [_vp, _i, _i, _vp],
     'rvt_bn_stats': [_vp, _vp, _vp, _i, _i, _i, _vp],
     'rvt_bn_finalize': [_vp, _vp, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
@@ -79,7 +82,7 @@ EXPORTS = sorted(list(_SIGS) + ['rvt_last_error', 'rvt_is_emulator', 'rvt_wgrad_
                                'rvt_mlp_bwd_fused_ws_floats', 'rvt_attn_block_supported', 'rvt_lstm_scan_bwd_ws_floats',
                                'rvt_lstm_scan_saves_gates', 'rvt_stem_supported', 'rvt_stem_wgrad_ws_floats', 'rvt_conv_dgrad4_supported',
                                'rvt_linear_dgrad_ln_supported', 'rvt_ln_linear_supported', 'rvt_tuning_defaults', 'rvt_get_tuning', 'rvt_set_tuning', 'rvt_probe_mfma',
-                               'rvt_stage_seq_fwd', 'rvt_stage_seq_fwd_ws_bytes', 'rvt_simota_ws_bytes', 'rvt_mlp_bwd_both_supported'])
+                               'rvt_stage_seq_fwd', 'rvt_stage_seq_fwd_ws_bytes', 'rvt_lstm_scan3_supported', 'rvt_lstm_scan3_rows', 'rvt_simota_ws_bytes', 'rvt_mlp_bwd_both_supported'])
 
 
 def _bind(lib: ctypes.CDLL) -> ctypes.CDLL:
@@ -107,6 +110,10 @@ def _bind(lib: ctypes.CDLL) -> ctypes.CDLL:
     lib.rvt_attn_block_supported.argtypes = [_i, _i, _i, _i]
     lib.rvt_lstm_scan_supported.restype = ctypes.c_int
     lib.rvt_lstm_scan_supported.argtypes = [_i, _i]
+    lib.rvt_lstm_scan3_supported.restype = ctypes.c_int
+    lib.rvt_lstm_scan3_supported.argtypes = [_i, _i]
+    lib.rvt_lstm_scan3_rows.restype = ctypes.c_int
+    lib.rvt_lstm_scan3_rows.argtypes = [_i, _i]
     lib.rvt_linear_dgrad_ln_supported.restype = ctypes.c_int
     lib.rvt_linear_dgrad_ln_supported.argtypes = [_i, _i, _i]
     lib.rvt_ln_linear_supported.restype = ctypes.c_int

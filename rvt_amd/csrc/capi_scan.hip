@@ -3,6 +3,7 @@
 #include "gemm.hpp"
 #include "lstm_scan.hpp"
 #include "lstm_scan2.hpp"
+#include "lstm_scan3.hpp"
 
 using namespace rvt;
 
@@ -142,6 +143,48 @@ int rvt_lstm_scan_bwd(const void* x_all, const void* Hall, const void* Csave, co
     }
 #undef RVT_SCAN_BWD
     return check_launch("lstm_scan_bwd");
+}
+
+
+// ---------------------------------------------------------------- wide stages: streamed weights, saved gates (lstm_scan3.hpp)
+// RB of the forward tile (32 RB tokens per workgroup); the reverse scan always walks 32-token blocks
+static int scan3_rb(int C) { return C == 256 ? tuning().lstm_scan3_rb256 : 1; }
+int rvt_lstm_scan3_supported(int dtype, int C) { return dtype == RVT_BF16 && tuning().lstm_scan3 != 0 && C == 256; }
+int rvt_lstm_scan3_rows(int C, int M) {
+    const int tm = 32 * scan3_rb(C);
+    return (M + tm - 1) / tm * tm;
+}
+int rvt_lstm_scan3_pack(const void* w, void* wp_fwd, void* wtp_bwd, int C, void* stream) {
+    RVT_CHECK(C % 64 == 0 && w != nullptr, "lstm_scan3_pack: C=%d must be a multiple of 64", C);
+    hipStream_t st = (hipStream_t)stream;
+    const int pieces = (C / 64) * (2 * C / 16) * 8 * 64;        // (same count in both directions)
+    const int grid = imax(1, imin(1024, (pieces + 255) / 256));
+    if (wp_fwd != nullptr) hipLaunchKernelGGL(lstm_scan3_pack_kernel<false>, dim3(grid), dim3(256), 0, st, (const bf16*)w, (bf16*)wp_fwd, C);
+    if (wtp_bwd != nullptr) hipLaunchKernelGGL(lstm_scan3_pack_kernel<true>, dim3(grid), dim3(256), 0, st, (const bf16*)w, (bf16*)wtp_bwd, C);
+    return check_launch("lstm_scan3_pack");
+}
+int rvt_lstm_scan3_fwd(const void* x_all, void* Hall, const float* c0, float* c_last, void* Csave, const void* wp, const float* bias,
+                       void* gsave, int dtype, int M, int C, int T_steps, void* stream) {
+    RVT_CHECK(rvt_lstm_scan3_supported(dtype, C), "lstm_scan3_fwd: not built for dtype=%d C=%d", dtype, C);
+    RVT_CHECK(M >= 1 && T_steps >= 1 && (Csave == nullptr) == (gsave == nullptr), "lstm_scan3_fwd: empty problem, or only one of Csave / gsave");
+    hipStream_t st = (hipStream_t)stream;
+#define RVT_SCAN3_FWD(CC, RBB) do { auto k = lstm_scan3_fwd_kernel<CC, RBB>;                                                     \
+        hipLaunchKernelGGL(k, dim3(scan_grid(k, CC, M, 32 * RBB)), dim3(CC), 0, st, (const bf16*)x_all, (bf16*)Hall, c0, c_last, \
+                           (bf16*)Csave, (const bf16*)wp, bias, (bf16*)gsave, M, T_steps); } while (0)
+    if (scan3_rb(C) == 2) RVT_SCAN3_FWD(256, 2); else RVT_SCAN3_FWD(256, 1);
+#undef RVT_SCAN3_FWD
+    return check_launch("lstm_scan3_fwd");
+}
+int rvt_lstm_scan3_bwd(const void* gsave, const void* Csave, const float* c0, const void* dH, const float* dc_last, const void* wtp,
+                       void* dx_all, void* dz_all, void* dh0, float* dc0, int dtype, int M, int C, int T_steps, void* stream) {
+    RVT_CHECK(rvt_lstm_scan3_supported(dtype, C), "lstm_scan3_bwd: not built for dtype=%d C=%d", dtype, C);
+    RVT_CHECK(M >= 1 && T_steps >= 1 && gsave != nullptr && Csave != nullptr && dx_all != nullptr && dz_all != nullptr,
+              "lstm_scan3_bwd: empty problem / missing buffers");
+    hipStream_t st = (hipStream_t)stream;
+    auto k = lstm_scan3_bwd_kernel<256>;
+    hipLaunchKernelGGL(k, dim3(scan_grid(k, 256, M, 32)), dim3(256), 0, st, (const bf16*)gsave, (const bf16*)Csave, c0, (const bf16*)dH,
+                       dc_last, (const bf16*)wtp, (bf16*)dx_all, (bf16*)dz_all, (bf16*)dh0, dc0, M, T_steps, scan3_rb(C));
+    return check_launch("lstm_scan3_bwd");
 }
 
 }  // extern "C"

@@ -2,7 +2,7 @@
 streams only; every op below is one HIP kernel launch (conv_dgrad: one per stride-parity class)."""
 from __future__ import annotations
 
-from typing import Optional
+from typing import Optional, Tuple
 
 import torch
 
@@ -474,6 +474,48 @@ def lstm_scan_bwd(x_all: Tensor, Hall: Tensor, Csave: Tensor, c0: Optional[Tenso
     L.call('rvt_lstm_scan_bwd', L.ptr(x_all), L.ptr(Hall), L.ptr(Csave), L.ptr(c0), L.ptr(dH), L.ptr(dc_last), L.ptr(w),
            L.ptr(wt), L.ptr(bias), L.ptr(dx_all), L.ptr(dz_all), L.ptr(dh0), L.ptr(dc0), L.ptr(dw), L.ptr(db), L.ptr(ws),
            L.ptr(gates), L.dtype_code(x_all.dtype), M, C, T_, st)
+
+
+def lstm_scan3_supported(dtype: torch.dtype, C: int) -> bool:
+    """ConvLSTM of the wide stages with the time loop in the kernel and streamed weights (csrc/lstm_scan3.hpp): bf16, C = 256."""
+    return dtype in L._DT and bool(L.get_lib().rvt_lstm_scan3_supported(L.dtype_code(dtype), C))
+
+
+def lstm_scan3_rows(C: int, M: int) -> int:
+    """Rows per time step of the register-dump buffers (gates, cell states) the forward saves for the reverse scan."""
+    return int(L.get_lib().rvt_lstm_scan3_rows(C, M))
+
+
+def lstm_scan3_pack(w: Tensor, fwd: bool = True, bwd: bool = True) -> Tuple[Optional[Tensor], Optional[Tensor]]:
+    """Natural [4C][2C] ConvLSTM weights -> the operand-order streams of lstm_scan3_fwd / lstm_scan3_bwd."""
+    C = w.shape[1] // 2
+    assert tuple(w.shape) == (4 * C, 2 * C) and w.is_contiguous()
+    wp = torch.empty(4 * C * 2 * C, dtype=w.dtype, device=w.device) if fwd else None
+    wtp = torch.empty(4 * C * 2 * C, dtype=w.dtype, device=w.device) if bwd else None
+    L.call('rvt_lstm_scan3_pack', L.ptr(w), L.ptr(wp), L.ptr(wtp), C, L.stream_of(w))
+    return wp, wtp
+
+
+def lstm_scan3_fwd(x_all: Tensor, Hall: Tensor, c0: Optional[Tensor], c_last: Tensor, Csave: Optional[Tensor], wp: Tensor,
+                   bias: Tensor, gsave: Optional[Tensor]) -> None:
+    """All T steps in one launch; Csave / gsave: dump buffers of T * lstm_scan3_rows(C, M) * C / * 4C elements, or both None."""
+    T_, C = x_all.shape[0], x_all.shape[-1]
+    M = x_all[0].numel() // C
+    assert c_last.dtype == torch.float32 and (c0 is None or c0.dtype == torch.float32) and bias.dtype == torch.float32
+    if gsave is not None:
+        rows = lstm_scan3_rows(C, M)
+        assert gsave.numel() >= T_ * rows * 4 * C and Csave.numel() >= T_ * rows * C
+    L.call('rvt_lstm_scan3_fwd', L.ptr(x_all), L.ptr(Hall), L.ptr(c0), L.ptr(c_last), L.ptr(Csave), L.ptr(wp), L.ptr(bias),
+           L.ptr(gsave), L.dtype_code(x_all.dtype), M, C, T_, L.stream_of(x_all))
+
+
+def lstm_scan3_bwd(gsave: Tensor, Csave: Tensor, c0: Optional[Tensor], dH: Optional[Tensor], dc_last: Optional[Tensor], wtp: Tensor,
+                   dx_all: Tensor, dz_all: Tensor, dh0: Tensor, dc0: Tensor) -> None:
+    T_, C = dx_all.shape[0], dx_all.shape[-1]
+    M = dx_all[0].numel() // C
+    assert dc0.dtype == torch.float32 and (dc_last is None or dc_last.dtype == torch.float32)
+    L.call('rvt_lstm_scan3_bwd', L.ptr(gsave), L.ptr(Csave), L.ptr(c0), L.ptr(dH), L.ptr(dc_last), L.ptr(wtp), L.ptr(dx_all),
+           L.ptr(dz_all), L.ptr(dh0), L.ptr(dc0), L.dtype_code(dx_all.dtype), M, C, T_, L.stream_of(dx_all))
 
 
 def dwconv(x: Tensor, w: Tensor, b: Optional[Tensor], k: int, transpose: bool = False, out: Optional[Tensor] = None) -> Tensor:

@@ -68,6 +68,15 @@ def use_lstm_scan(dtype, C: int, dws, T: int = 0, save: bool = True) -> bool:
     return True if mode == 1 else (C <= 64 or ops.lstm_scan_saves_gates(dtype, C))
 
 
+def use_lstm_scan3(dtype, C: int, dws, T: int = 0, save: bool = True) -> bool:
+    """ConvLSTM of the wide stages (bf16, C = 256; weights too large for the chip) with the time loop in the kernel, the weights
+    streamed from L2 in operand order and the gates saved for the reverse scan (csrc/lstm_scan3.hpp) instead of 3 launches per step.
+    One no-grad step (streaming inference, T = 1) keeps the per-step GEMM: packing + streaming the weights buys nothing there."""
+    if dws is not None or not ops.lstm_scan3_supported(dtype, C):
+        return False
+    return save or T > 1
+
+
 class SideStream:
     """Weight-gradient GEMMs are off the critical path of backward (nothing downstream reads dW until the optimizer) and
     are read-only streams, while the input-gradient chain they hang off is write-heavy; running them on a second HIP
@@ -173,10 +182,11 @@ class StageGeom:
 
 class StageSaved:
     """Activations kept for backward (everything else is recomputed from these)."""
-    __slots__ = ('inp', 'y0', 'blocks', 'x_last', 'Hall', 'Call', 'gates', 'mask', 'xin_lstm', 'hconv', 'Csave', 'c0', '__weakref__')
+    __slots__ = ('inp', 'y0', 'blocks', 'x_last', 'Hall', 'Call', 'gates', 'mask', 'xin_lstm', 'hconv', 'Csave', 'c0', 'scan3', '__weakref__')
 
     def __init__(self):
         self.blocks: List[Dict[str, Tensor]] = []
+        self.scan3 = False
 
 
 def stage_seq_forward(sw: StageWeights, g: StageGeom, inp: Tensor, h0: Optional[Tensor], c0: Optional[Tensor],
@@ -257,6 +267,18 @@ def stage_seq_forward(sw: StageWeights, g: StageGeom, inp: Tensor, h0: Optional[
         Hall[0].zero_()                                                           # rnn.py:43-47
     elif not direct0:
         Hall[0].copy_(h0)
+    if use_lstm_scan3(dt, C, dws, T, save):
+        # wide stage: all T steps in ONE launch, weights streamed in operand order, gates + cell states saved in dump order
+        c_last = torch.empty((B, H, W, C), dtype=torch.float32, device=dev)
+        rows = ops.lstm_scan3_rows(C, B * H * W)
+        Csave = torch.empty((T, rows, C), dtype=dt, device=dev) if save else None
+        gsave = torch.empty((T, rows, 4 * C), dtype=dt, device=dev) if save else None
+        ops.lstm_scan3_fwd(x.view(T, B, H, W, C), Hall, c0, c_last, Csave, sw.scan3_packed(bwd=False), sw.lstm_bn, gsave)
+        if save:
+            sv.x_last, sv.Hall, sv.Call, sv.gates = x, Hall, None, gsave
+            sv.xin_lstm, sv.hconv, sv.Csave, sv.c0 = x, None, Csave, (None if c0 is None else c0.clone())
+            sv.scan3 = True
+        return Hall, c_last, sv
     if use_lstm_scan(dt, C, dws, T, save):
         # all T steps in ONE launch: h / c stay on chip, BPTT keeps only a T-typed copy of the cell states
         c_last = torch.empty((B, H, W, C), dtype=torch.float32, device=dev)
@@ -325,7 +347,14 @@ def stage_seq_backward(sw: StageWeights, g: StageGeom, sv: StageSaved, dH: Optio
     dws = sw.dws
     lstm_wgrad_done = False
     dz = None
-    if sv.Csave is not None:
+    if sv.scan3:
+        # reverse scan of a wide stage in ONE launch on the saved gates; dz goes to the weight-gradient GEMM below
+        dh_rec = torch.empty((B, H, W, C), dtype=dt, device=dev)
+        dc_rec = torch.empty((B, H, W, C), dtype=f32, device=dev)
+        dz = torch.empty((T, B, H, W, 4 * C), dtype=dt, device=dev)
+        ops.lstm_scan3_bwd(sv.gates, sv.Csave, sv.c0, dH, None if dc_last is None else dc_last.to(f32).contiguous(),
+                           sw.scan3_packed(bwd=True), dx, dz, dh_rec, dc_rec)
+    elif sv.Csave is not None:
         # reverse scan in ONE launch: gates recomputed from (x_t, h_{t-1}), dc / dh_rec in registers across t; where built
         # (bf16, C <= 64) the weight gradients are accumulated in the same kernel and dz never exists in HBM
         dh_rec = torch.empty((B, H, W, C), dtype=dt, device=dev)

@@ -92,7 +92,24 @@ class _Arena:
 
 class StageWeights:
     """Everything one stage's kernels read (views into ModelWeights' flat buffers, or the fp32 parameters themselves)."""
-    pass
+    pack_epoch = 0            # bumped by ModelWeights.pack(): derived copies made lazily below are stale afterwards
+    _scan3 = None
+
+    def scan3_packed(self, bwd: bool) -> Tensor:
+        """The ConvLSTM weights in the operand order the wide-stage scan kernels stream (csrc/lstm_scan3.hpp), re-derived from
+        `lstm_wn` once per pack() and direction; the buffers persist (stable addresses for hipGraph replay)."""
+        from . import ops
+        st = self._scan3
+        if st is None:
+            st = self._scan3 = dict(fwd=None, bwd=None, fwd_epoch=-1, bwd_epoch=-1)
+        key = 'bwd' if bwd else 'fwd'
+        if st[key] is None:
+            st[key] = torch.empty(self.lstm_wn.numel(), dtype=self.lstm_wn.dtype, device=self.lstm_wn.device)
+        if st[key + '_epoch'] != self.pack_epoch:
+            L.call('rvt_lstm_scan3_pack', L.ptr(self.lstm_wn), None if bwd else L.ptr(st['fwd']), L.ptr(st['bwd']) if bwd else None,
+                   self.lstm_wn.shape[1] // 2, L.stream_of(self.lstm_wn))
+            st[key + '_epoch'] = self.pack_epoch
+        return st[key]
 
 
 class StageGrads:
@@ -291,6 +308,8 @@ class ModelWeights:
             shadow.copy_(param.detach())
         L.call('rvt_pack_table', L.ptr(self.table.dev), len(self.table), self.table.blocks, L.dtype_code(self.dtype),
                L.stream_of(self.bufT))
+        for sw in self.stages:
+            sw.pack_epoch += 1
 
     def finalize_stage_grads(self, si: int) -> None:
         """LayerScale fold + conv weight-gradient unpack of stage si: two launches on the current stream."""

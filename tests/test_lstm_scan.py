@@ -138,3 +138,82 @@ def test_lstm_scan_fwd_bwd(backend, dt, C, M, T, zero_state):
     # no upstream cotangents at all -> every gradient is zero / finite
     ops.lstm_scan_bwd(x, Hall, Csave, c0, None, None, w, w.t().contiguous(), b, dx, dz, dh0, dc0)
     assert float(dx.float().abs().max()) == 0.0 and float(dz.float().abs().max()) == 0.0
+
+
+# ---- wide stages (bf16, C = 256): weights streamed in operand order, gates saved for the reverse scan (csrc/lstm_scan3.hpp) ----
+def _scan3_run(dev, C, M, T, zero_state, rb):
+    from rvt_amd import tuning as tn
+    dt = torch.bfloat16
+    x = rnd((T, M, C), dev, dt, 1)
+    h0 = torch.zeros(M, C, dtype=dt, device=dev) if zero_state else rnd((M, C), dev, dt, 2, 0.5)
+    c0 = None if zero_state else rnd((M, C), dev, torch.float32, 3, 0.7)
+    w = rnd((4 * C, 2 * C), dev, dt, 4, 1.0 / (2 * C) ** 0.5 * 2)
+    b = rnd((4 * C,), dev, torch.float32, 5, 0.2)
+    dH = None if zero_state else rnd((T, M, C), dev, dt, 6)
+    dc_last = None if zero_state else rnd((M, C), dev, torch.float32, 7)
+    with tn.override(lstm_scan3_rb256=rb):
+        assert ops.lstm_scan3_supported(dt, C)
+        rows = ops.lstm_scan3_rows(C, M)
+        assert rows >= M and rows % (32 * rb) == 0
+        wp, wtp = ops.lstm_scan3_pack(w)
+        Hall = torch.empty(T + 1, M, C, dtype=dt, device=dev)
+        Hall[0].copy_(h0)
+        c_last = torch.empty(M, C, dtype=torch.float32, device=dev)
+        Csave = torch.empty(T, rows, C, dtype=dt, device=dev)
+        gsave = torch.empty(T, rows, 4 * C, dtype=dt, device=dev)
+        ops.lstm_scan3_fwd(x, Hall, c0, c_last, Csave, wp, b, gsave)
+        # no-grad flavour: same numbers, nothing saved
+        Hall2 = torch.empty_like(Hall)
+        Hall2[0].copy_(h0)
+        c_last2 = torch.empty_like(c_last)
+        ops.lstm_scan3_fwd(x, Hall2, c0, c_last2, None, wp, b, None)
+        assert torch.equal(Hall2.cpu(), Hall.cpu()) and torch.equal(c_last2.cpu(), c_last.cpu())
+        dx = torch.empty(T, M, C, dtype=dt, device=dev)
+        dz = torch.empty(T, M, 4 * C, dtype=dt, device=dev)
+        dh0 = torch.empty(M, C, dtype=dt, device=dev)
+        dc0 = torch.empty(M, C, dtype=torch.float32, device=dev)
+        ops.lstm_scan3_bwd(gsave, Csave, c0, dH, dc_last, wtp, dx, dz, dh0, dc0)
+    return dict(x=x, h0=h0, c0=c0, w=w, b=b, dH=dH, dc_last=dc_last, Hall=Hall, c_last=c_last, dx=dx, dz=dz, dh0=dh0, dc0=dc0)
+
+
+@pytest.mark.parametrize('M,T,rb', [(200, 3, 2), (97, 4, 1), (64, 2, 2), (31, 2, 1), (333, 3, 2)])
+@pytest.mark.parametrize('zero_state', [False, True])
+def test_lstm_scan3_fwd_bwd(backend, M, T, rb, zero_state):
+    C, dt = 256, torch.bfloat16
+    r = _scan3_run(backend, C, M, T, zero_state, rb)
+    x, h0, c0, w, b = r['x'], r['h0'], r['c0'], r['w'], r['b']
+    xr, wr, br = x.double().cpu().requires_grad_(True), w.double().cpu().requires_grad_(True), b.double().cpu().requires_grad_(True)
+    h0r = h0.double().cpu().requires_grad_(True)
+    c0r = (torch.zeros(M, C, dtype=torch.float64) if c0 is None else c0.double().cpu()).requires_grad_(True)
+    hs, cs = ref_lstm(xr, h0r, c0r, wr, br)
+    tol = TOL[dt]
+    assert rel(r['Hall'][1:], hs) <= tol, ('h', rel(r['Hall'][1:], hs))
+    assert rel(r['c_last'], cs[-1]) <= tol, ('c_last', rel(r['c_last'], cs[-1]))
+    if zero_state:         # no upstream cotangents at all -> every gradient is exactly zero
+        for k in ('dx', 'dz', 'dh0', 'dc0'):
+            assert float(r[k].float().abs().max()) == 0.0, k
+        return
+    (hs * r['dH'].double().cpu()).sum().backward(retain_graph=True)
+    torch.autograd.backward([cs[-1]], [r['dc_last'].double().cpu()])
+    assert rel(r['dx'], xr.grad) <= tol, ('dx', rel(r['dx'], xr.grad))
+    assert rel(r['dh0'], h0r.grad) <= tol, ('dh0', rel(r['dh0'], h0r.grad))
+    assert rel(r['dc0'], c0r.grad) <= tol, ('dc0', rel(r['dc0'], c0r.grad))
+    xh = torch.cat([x.double().cpu(), r['Hall'][:T].double().cpu()], -1).reshape(T * M, 2 * C)
+    dzc = r['dz'].double().cpu().reshape(T * M, 4 * C)
+    assert rel(dzc.t() @ xh, wr.grad) <= tol, ('dW', rel(dzc.t() @ xh, wr.grad))
+    assert rel(dzc.sum(0), br.grad) <= tol, ('db', rel(dzc.sum(0), br.grad))
+
+
+def test_lstm_scan3_matches_per_step_kernels(backend):
+    """Same arithmetic as the per-step kernels it replaces (gate-interleaved GEMM + gate kernels): bf16 round-off apart."""
+    C, M, T, dt, dev = 256, 130, 3, torch.bfloat16, backend
+    r = _scan3_run(dev, C, M, T, False, 2)
+    perm = weights.lstm_gate_perm(C, dev)
+    Hs = torch.empty_like(r['Hall'])
+    Hs[0].copy_(r['h0'])
+    Cs = torch.zeros(T + 1, M, C, dtype=torch.float32, device=dev)
+    Cs[0].copy_(r['c0'])
+    for t in range(T):
+        ops.lstm_fwd(r['x'][t], Hs[t], Cs[t], r['w'][perm].contiguous(), r['b'][perm].contiguous(), Hs[t + 1], Cs[t + 1], None)
+    assert rel(r['Hall'][1:], Hs[1:]) <= 1e-2
+    assert rel(r['c_last'], Cs[T]) <= 1e-2
