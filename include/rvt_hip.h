@@ -83,11 +83,12 @@ typedef struct RvtTuning {
     int ln_linear;            /* 1 (round 5): LayerNorm + qkv projection of a C = 128 block in one launch where rvt_ln_linear_supported, and fc1 + GELU at K = 256, N = 1024 on the weight-stationary kernel (both ln_linear.hpp) */
     int conv_wgrad_tn;        /* 1 (round 5): conv weight gradients with Cout % 256 == 0, Cin % 64 == 0 and k*k*Cin >= 256 take ppgemm_tn.hpp (im2col gather by LDS-DMA; the last 256-wide k tile may lie partly beyond K) */
     int attn_staged;          /* 1 (round 5): the partition-attention core of stages 2-4 stages its rows through LDS (whole-line requests) where built */
-    int lstm_scan3;           /* 1 (round 6): the ConvLSTM of the wide stages (bf16, C = 256, dws_conv False) runs with the time loop in the kernel, weights streamed from L2 in operand order, gates saved for the reverse scan (lstm_scan3.hpp) */
+    int lstm_scan3;           /* round 6: ConvLSTM (bf16, dws_conv False) with the time loop in the kernel, weights streamed from L2 in operand order, gates saved for the reverse scan (lstm_scan3.hpp): bit 0 = at C 256, bit 1 = at C 128 (instead of lstm_scan.hpp's register-resident weights) */
     int lstm_scan3_rb256;     /* 32-token blocks per workgroup tile of that forward at C = 256: 1 or 2 */
-    int reserved[2];          /* zero */
+    int lstm_scan3_rb128;     /* ... at C = 128 */
+    int reserved[1];          /* zero */
 } RvtTuning;
-#define RVT_TUNING_DEFAULTS {(int)sizeof(RvtTuning), 0, 1, 0, 512, 8192, 1, 4096, 0, 0, 0, 0, 1, 4, 0, 1, 1, 0, 0, 1, -1, 1, 1, -1, 1, 1, 0, 1, 1, 0, 1, 1, 1, 1, 1, 1, 1, {0}}
+#define RVT_TUNING_DEFAULTS {(int)sizeof(RvtTuning), 0, 1, 0, 512, 8192, 1, 4096, 0, 0, 0, 0, 1, 4, 0, 1, 1, 0, 0, 1, -1, 1, 1, -1, 1, 1, 0, 1, 1, 0, 1, 1, 1, 1, 1, 3, 1, 1, {0}}
 void rvt_tuning_defaults(RvtTuning* t);        /* fills *t with the production defaults */
 int rvt_get_tuning(RvtTuning* t);              /* t->struct_bytes must be set by the caller */
 int rvt_set_tuning(const RvtTuning* t);
@@ -301,7 +302,7 @@ int rvt_lstm_scan_bwd(const void* x_all, const void* Hall, const void* Csave, co
                       int T_steps, void* stream);
 
 /* ---- ConvLSTM of the WIDE stages with the time loop in the kernel (csrc/lstm_scan3.hpp; reference models/layers/rnn.py:43-67 over
- * the loop of modules/detection.py:131-148, and its BPTT).  bf16, dws_conv False, C = 256 (rvt_lstm_scan3_supported).  The weights do
+ * the loop of modules/detection.py:131-148, and its BPTT).  bf16, dws_conv False, C = 128 / 256 (rvt_lstm_scan3_supported).  The weights do
  * not fit on chip: they are streamed from L2 every step in MFMA-operand order, which rvt_lstm_scan3_pack produces once per
  * optimizer step from the natural [4C][2C] matrix (gate order f,i,o,g, input order [x | h]: rnn.py:52-61):
  *   wp_fwd  [C/64][2C/16][8][64][8]   (wave, k-step, (channel block, gate), lane, element)    = 4C * 2C elements

@@ -13,7 +13,7 @@ def timeit(fn, n=10):
     return e0.elapsed_time(e1) / n
 rnd = lambda *s: torch.randn(*s, device=dev).to(dt)
 T = 21
-for M, C in ((23040, 256), (640, 256)):
+for M, C in ((23040, 256), (640, 256), (92160, 128), (2560, 128)):
     x = rnd(T, M, C)
     w = rnd(4 * C, 2 * C) * 0.05
     b = torch.zeros(4 * C, device=dev)
@@ -23,7 +23,7 @@ for M, C in ((23040, 256), (640, 256)):
     dh0, dc0 = torch.empty(M, C, device=dev, dtype=dt), torch.empty(M, C, device=dev)
     c_last = torch.empty(M, C, device=dev)
     for rb in (1, 2):
-        with tuning.override(lstm_scan3_rb256=rb):
+        with tuning.override(lstm_scan3_rb256=rb, lstm_scan3_rb128=rb):
             rows = ops.lstm_scan3_rows(C, M)
             Hall = torch.zeros(T + 1, M, C, device=dev, dtype=dt)
             Cs, gs = torch.empty(T, rows, C, device=dev, dtype=dt), torch.empty(T, rows, 4 * C, device=dev, dtype=dt)
@@ -43,3 +43,9 @@ for M, C in ((23040, 256), (640, 256)):
     t2 = timeit(lambda: ops.lstm_dgrad(dzs, wt, dxs, dhs))
     t3 = timeit(lambda: ops.lstm_gates_bwd(dhin, dhs, dcr, go, co, cs_, dzs))
     print(f'M={M} C={C}: pack {tp * 1e3:.1f} us;  per-step route x{T}: fwd {T * t1:.3f} ms, bwd {T * (t2 + t3):.3f} ms', flush=True)
+    if C == 128:        # the register-resident-weight scan of lstm_scan.hpp (what stage 2 of RVT-Base ran before)
+        Hall = torch.zeros(T + 1, M, C, device=dev, dtype=dt)
+        Cs, gs = torch.empty(T, M, C, device=dev, dtype=dt), torch.empty(T, M, 4 * C, device=dev, dtype=dt)
+        tf = timeit(lambda: ops.lstm_scan_fwd(x, Hall, None, c_last, Cs, w, b, gates_out=gs))
+        tb = timeit(lambda: ops.lstm_scan_bwd(x, Hall, Cs, None, dH, dc_last, w, w.t().contiguous(), b, dx, dz, dh0, dc0, gates=gs))
+        print(f'M={M} C={C}: lstm_scan.hpp (weights in registers, saved gates): fwd {tf:.3f} ms  bwd {tb:.3f} ms', flush=True)

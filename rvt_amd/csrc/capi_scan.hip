@@ -148,8 +148,11 @@ int rvt_lstm_scan_bwd(const void* x_all, const void* Hall, const void* Csave, co
 
 // ---------------------------------------------------------------- wide stages: streamed weights, saved gates (lstm_scan3.hpp)
 // RB of the forward tile (32 RB tokens per workgroup); the reverse scan always walks 32-token blocks
-static int scan3_rb(int C) { return C == 256 ? tuning().lstm_scan3_rb256 : 1; }
-int rvt_lstm_scan3_supported(int dtype, int C) { return dtype == RVT_BF16 && tuning().lstm_scan3 != 0 && C == 256; }
+static int scan3_rb(int C) { return (C == 256 ? tuning().lstm_scan3_rb256 : tuning().lstm_scan3_rb128) == 2 ? 2 : 1; }
+// tuning().lstm_scan3: bit 0 = C 256, bit 1 = C 128
+int rvt_lstm_scan3_supported(int dtype, int C) {
+    return dtype == RVT_BF16 && ((C == 256 && (tuning().lstm_scan3 & 1)) || (C == 128 && (tuning().lstm_scan3 & 2)));
+}
 int rvt_lstm_scan3_rows(int C, int M) {
     const int tm = 32 * scan3_rb(C);
     return (M + tm - 1) / tm * tm;
@@ -171,7 +174,8 @@ int rvt_lstm_scan3_fwd(const void* x_all, void* Hall, const float* c0, float* c_
 #define RVT_SCAN3_FWD(CC, RBB) do { auto k = lstm_scan3_fwd_kernel<CC, RBB>;                                                     \
         hipLaunchKernelGGL(k, dim3(scan_grid(k, CC, M, 32 * RBB)), dim3(CC), 0, st, (const bf16*)x_all, (bf16*)Hall, c0, c_last, \
                            (bf16*)Csave, (const bf16*)wp, bias, (bf16*)gsave, M, T_steps); } while (0)
-    if (scan3_rb(C) == 2) RVT_SCAN3_FWD(256, 2); else RVT_SCAN3_FWD(256, 1);
+    if (C == 256) { if (scan3_rb(C) == 2) RVT_SCAN3_FWD(256, 2); else RVT_SCAN3_FWD(256, 1); }
+    else { if (scan3_rb(C) == 2) RVT_SCAN3_FWD(128, 2); else RVT_SCAN3_FWD(128, 1); }
 #undef RVT_SCAN3_FWD
     return check_launch("lstm_scan3_fwd");
 }
@@ -181,9 +185,11 @@ int rvt_lstm_scan3_bwd(const void* gsave, const void* Csave, const float* c0, co
     RVT_CHECK(M >= 1 && T_steps >= 1 && gsave != nullptr && Csave != nullptr && dx_all != nullptr && dz_all != nullptr,
               "lstm_scan3_bwd: empty problem / missing buffers");
     hipStream_t st = (hipStream_t)stream;
-    auto k = lstm_scan3_bwd_kernel<256>;
-    hipLaunchKernelGGL(k, dim3(scan_grid(k, 256, M, 32)), dim3(256), 0, st, (const bf16*)gsave, (const bf16*)Csave, c0, (const bf16*)dH,
-                       dc_last, (const bf16*)wtp, (bf16*)dx_all, (bf16*)dz_all, (bf16*)dh0, dc0, M, T_steps, scan3_rb(C));
+#define RVT_SCAN3_BWD(CC) do { auto k = lstm_scan3_bwd_kernel<CC>;                                                                       \
+        hipLaunchKernelGGL(k, dim3(scan_grid(k, CC, M, 32)), dim3(CC), 0, st, (const bf16*)gsave, (const bf16*)Csave, c0, (const bf16*)dH, \
+                           dc_last, (const bf16*)wtp, (bf16*)dx_all, (bf16*)dz_all, (bf16*)dh0, dc0, M, T_steps, scan3_rb(C)); } while (0)
+    if (C == 256) RVT_SCAN3_BWD(256); else RVT_SCAN3_BWD(128);
+#undef RVT_SCAN3_BWD
     return check_launch("lstm_scan3_bwd");
 }
 

@@ -38,6 +38,11 @@ static bool route_lstm_scan(const RvtStageDesc& d, int T) {
     if (mode == -1 && T == 1) return false;      // one step (streaming inference): the per-step GEMM beats staging the scan's weights (3.69 vs 3.81 ms per step at B = 64)
     return mode == 1 || d.C <= 64 || rvt_lstm_scan_saves_gates(d.dtype, d.C);
 }
+// (rvt_amd/stage.py: use_lstm_scan3) wide stages / long stage-2 scans with streamed weights; one step keeps the per-step GEMM
+static bool route_lstm_scan3(const RvtStageDesc& d, int T, int Ms) {
+    if (T <= 1 || !rvt_lstm_scan3_supported(d.dtype, d.C)) return false;
+    return !(d.C == 128 && Ms < 16384 && tuning().route_lstm_scan != 0);
+}
 static size_t stage_ws_bytes(const RvtStageDesc& d, int T, int B) {
     const int H = conv_out(d.H_in, d.k, d.stride, d.pad), W = conv_out(d.W_in, d.k, d.stride, d.pad);
     const size_t tok = (size_t)T * B * H * W, e = elt_bytes(d.dtype), pad = 256;
@@ -47,6 +52,7 @@ static size_t stage_ws_bytes(const RvtStageDesc& d, int T, int B) {
     if (!d.inp_u8 || !rvt_stem_supported(d.dtype, 1, d.Cin, d.C, d.k, d.stride, d.pad, d.w_raw))
         n += d.inp_u8 ? (size_t)T * B * d.H_in * d.W_in * d.cin_pad * e + pad : 0;      // prepacked input
     n += 2 * ((size_t)B * H * W * d.C * 4 + pad);                           // cell-state ping-pong of the per-step route
+    n += (size_t)8 * d.C * d.C * e + pad;                                   // ConvLSTM weights in operand order (lstm_scan3 route)
     return n + 4096;
 }
 }  // namespace
@@ -137,7 +143,14 @@ int rvt_stage_seq_fwd(const RvtStageDesc* dp, const void* inp, const void* h0, c
     const size_t sN = (size_t)B * H * W * C;             // elements of one state
     const int Ms = B * H * W;
     char* const HallB = (char*)Hall;
-    if (route_lstm_scan(d, T)) {
+    if (route_lstm_scan3(d, T, Ms)) {
+        void* wp = cv.take((size_t)8 * C * C * e);
+        RVT_CHECK(cv.ok, "stage_seq_fwd: workspace carving overflow");
+        if (h0 != nullptr) { if (hipMemcpyAsync(HallB, h0, sN * e, hipMemcpyDeviceToDevice, st) != hipSuccess) { set_last_error("stage_seq_fwd: state copy failed"); return 1; } }
+        else if (hipMemsetAsync(HallB, 0, sN * e, st) != hipSuccess) { set_last_error("stage_seq_fwd: memset failed"); return 1; }
+        RVT_TRY(rvt_lstm_scan3_pack(d.lstm_wn, wp, nullptr, C, stream));
+        RVT_TRY(rvt_lstm_scan3_fwd(x, Hall, c0, c_last, nullptr, wp, d.lstm_bn, nullptr, dt, Ms, C, T, stream));
+    } else if (route_lstm_scan(d, T)) {
         if (h0 != nullptr) { if (hipMemcpyAsync(HallB, h0, sN * e, hipMemcpyDeviceToDevice, st) != hipSuccess) { set_last_error("stage_seq_fwd: state copy failed"); return 1; } }
         else if (hipMemsetAsync(HallB, 0, sN * e, st) != hipSuccess) { set_last_error("stage_seq_fwd: memset failed"); return 1; }
         RVT_TRY(rvt_lstm_scan_fwd(x, Hall, c0, c_last, nullptr, d.lstm_wn, d.lstm_bn, nullptr, dt, Ms, C, T, stream));

@@ -31,7 +31,7 @@ template <int C, int RB> struct Scan3Geom {
     static constexpr int NKF = 2 * C / 16;             // k-steps of z = [x | h] W^T
     static constexpr int NKB = 4 * C / 16;             // k-steps of [dx | dh] = dz W
     static constexpr int PD = RB == 1 ? 4 : 8;         // k-steps (of 4 operand pieces = 4 KiB per wave) the weight ring runs ahead
-    static constexpr int WGS = RB == 1 ? 2 : 1;        // workgroups per CU the forward is built for (RB = 1: two, so that one's gate math overlaps the other's MFMAs)
+    static constexpr int WGS = RB == 1 ? 512 / C : 1;  // workgroups per CU the forward is built for (RB = 1: two waves per SIMD, so that one workgroup's gate math overlaps another's MFMAs)
     static_assert(C % 64 == 0 && NKF % PD == 0 && NKB % PD == 0, "geometry");
 };
 

@@ -68,11 +68,16 @@ def use_lstm_scan(dtype, C: int, dws, T: int = 0, save: bool = True) -> bool:
     return True if mode == 1 else (C <= 64 or ops.lstm_scan_saves_gates(dtype, C))
 
 
-def use_lstm_scan3(dtype, C: int, dws, T: int = 0, save: bool = True) -> bool:
-    """ConvLSTM of the wide stages (bf16, C = 256; weights too large for the chip) with the time loop in the kernel, the weights
-    streamed from L2 in operand order and the gates saved for the reverse scan (csrc/lstm_scan3.hpp) instead of 3 launches per step.
+def use_lstm_scan3(dtype, C: int, dws, T: int = 0, save: bool = True, M: int = 1 << 30) -> bool:
+    """ConvLSTM (bf16, C = 128 / 256) with the time loop in the kernel, the weights streamed from L2 in operand order and the gates
+    saved for the reverse scan (csrc/lstm_scan3.hpp): instead of 3 launches per step at C = 256 (weights too large for the chip),
+    instead of the register-resident-weight scan of lstm_scan.hpp at C = 128.
     One no-grad step (streaming inference, T = 1) keeps the per-step GEMM: packing + streaming the weights buys nothing there."""
     if dws is not None or not ops.lstm_scan3_supported(dtype, C):
+        return False
+    if C == 128 and M < 16384 and tuning.get('route_lstm_scan') != 0:
+        # few tokens per step (stage 3 of RVT-Tiny: 2560): the register-resident weights of lstm_scan.hpp win - 0.118 + 0.172 ms
+        # against 0.124 + 0.198; at 92160 tokens (stage 2 of RVT-Base) the streamed form does: 1.28 + 1.66 against 1.50 + 2.15
         return False
     return save or T > 1
 
@@ -261,13 +266,14 @@ def stage_seq_forward(sw: StageWeights, g: StageGeom, inp: Tensor, h0: Optional[
     dws = sw.dws
     # a no-grad forward on the per-step route reads the incoming states where they are (streaming inference, T = 1: the two
     # state copies per stage were 5 % of the step); BPTT and the scan kernel want them in slot 0
-    direct0 = (not save) and h0 is not None and not use_lstm_scan(dt, C, dws, T, save) and h0.dtype == dt and h0.is_contiguous() \
+    scan3 = use_lstm_scan3(dt, C, dws, T, save, B * H * W)
+    direct0 = (not save) and h0 is not None and not scan3 and not use_lstm_scan(dt, C, dws, T, save) and h0.dtype == dt and h0.is_contiguous() \
         and c0 is not None and c0.dtype == torch.float32 and c0.is_contiguous()
     if h0 is None:
         Hall[0].zero_()                                                           # rnn.py:43-47
     elif not direct0:
         Hall[0].copy_(h0)
-    if use_lstm_scan3(dt, C, dws, T, save):
+    if scan3:
         # wide stage: all T steps in ONE launch, weights streamed in operand order, gates + cell states saved in dump order
         c_last = torch.empty((B, H, W, C), dtype=torch.float32, device=dev)
         rows = ops.lstm_scan3_rows(C, B * H * W)

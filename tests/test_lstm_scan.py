@@ -151,7 +151,7 @@ def _scan3_run(dev, C, M, T, zero_state, rb):
     b = rnd((4 * C,), dev, torch.float32, 5, 0.2)
     dH = None if zero_state else rnd((T, M, C), dev, dt, 6)
     dc_last = None if zero_state else rnd((M, C), dev, torch.float32, 7)
-    with tn.override(lstm_scan3_rb256=rb):
+    with tn.override(lstm_scan3_rb256=rb, lstm_scan3_rb128=rb):
         assert ops.lstm_scan3_supported(dt, C)
         rows = ops.lstm_scan3_rows(C, M)
         assert rows >= M and rows % (32 * rb) == 0
@@ -176,10 +176,11 @@ def _scan3_run(dev, C, M, T, zero_state, rb):
     return dict(x=x, h0=h0, c0=c0, w=w, b=b, dH=dH, dc_last=dc_last, Hall=Hall, c_last=c_last, dx=dx, dz=dz, dh0=dh0, dc0=dc0)
 
 
+@pytest.mark.parametrize('C', [256, 128])
 @pytest.mark.parametrize('M,T,rb', [(200, 3, 2), (97, 4, 1), (64, 2, 2), (31, 2, 1), (333, 3, 2)])
 @pytest.mark.parametrize('zero_state', [False, True])
-def test_lstm_scan3_fwd_bwd(backend, M, T, rb, zero_state):
-    C, dt = 256, torch.bfloat16
+def test_lstm_scan3_fwd_bwd(backend, C, M, T, rb, zero_state):
+    dt = torch.bfloat16
     r = _scan3_run(backend, C, M, T, zero_state, rb)
     x, h0, c0, w, b = r['x'], r['h0'], r['c0'], r['w'], r['b']
     xr, wr, br = x.double().cpu().requires_grad_(True), w.double().cpu().requires_grad_(True), b.double().cpu().requires_grad_(True)
