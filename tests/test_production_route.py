@@ -331,3 +331,48 @@ def test_deferred_side_stream_keeps_operands_alive_until_join():
         assert ref() is None
         torch.cuda.synchronize()
         assert float(out) == float(1 << 20)
+
+
+OP_BY_OP = dict(route_fused_mlp=0, route_mlp_bwd_fused=0, route_attn_block=0, route_lstm_scan=0, route_lstm_scan_wgrad=0, lstm_scan3=0,
+                mlp_stream=0, ln_linear=0, mlp_chain=0, dgrad_ln=0, route_conv_dgrad4=0, conv_wgrad_tn=0, attn_staged=0, stem=0, ppgemm=0)
+# relative L2 error of the production route against the op-by-op route, per stage: (features, parameter gradients); 1.5 x the worst
+# value measured on MI355X (profiles/r6/route_vs_opbyop.txt)
+ROUTE_BOUNDS = {'tiny': {'feat': 1.0e-2, 'grad': 1.1e-2}, 'base': {'feat': 1.0e-2, 'grad': 1.1e-2}}
+
+
+@pytest.mark.parametrize('size,dataset,T,B', [('tiny', 'gen1', 5, 2), ('base', 'gen1', 4, 2)])
+def test_production_route_vs_op_by_op_route(production_route, size, dataset, T, B):
+    """the bf16 production route (fused attention / MLP halves, scans, streamed-weight kernels, stem, 256-wide GEMMs)
+    against the bf16 OP-BY-OP route (every fusion and special kernel routed off: one GEMM / row kernel per reference op, each gated
+    by its own fp64 kernel test): same dtype on both sides, so the two differ by bf16 rounding points only and every stage's features
+    and parameter gradients must agree to about a percent in relative L2 - a wrong kernel in ONE stage shows up as tens of percent
+    in that stage's group, which the whole-step cosine >= 0.70 of tests/test_detector_step.py would let through."""
+    res = {}
+    for route in ('production', 'op_by_op'):
+        with tuning.override(**(OP_BY_OP if route == 'op_by_op' else {})):
+            m = _bench_model(torch.bfloat16, size, dataset)
+            with torch.no_grad():
+                for k, p in m.named_parameters():
+                    if k.endswith('gamma'):
+                        p.fill_(0.5)             # LayerScale O(1): at 1e-5 the attention / MLP branches are invisible
+            g = torch.Generator(device=DEV).manual_seed(11)
+            hw = (240, 304)
+            xs = torch.randint(0, 11, (T, B, 20, *hw), generator=g, dtype=torch.uint8, device=DEV)
+            feats, states = m.forward_sequence(xs, None)
+            cots = [torch.randn(feats[s].shape, generator=g, device=DEV, dtype=torch.float32).to(feats[s].dtype) for s in (1, 2, 3, 4)]
+            torch.autograd.backward([feats[s] for s in (1, 2, 3, 4)], cots)
+            torch.cuda.synchronize()
+            res[route] = ({s: feats[s].detach().double() for s in (1, 2, 3, 4)}, {k: p.grad.double().flatten() for k, p in m.named_parameters()})
+    rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-30))
+    lines, bad = [], []
+    for st in range(4):
+        ef = rel(res['production'][0][st + 1], res['op_by_op'][0][st + 1])
+        ks = [k for k in res['op_by_op'][1] if k.startswith(f'stages.{st}.')]
+        eg = rel(torch.cat([res['production'][1][k] for k in ks]), torch.cat([res['op_by_op'][1][k] for k in ks]))
+        worst_k = max(ks, key=lambda k: rel(res['production'][1][k], res['op_by_op'][1][k]) if res['op_by_op'][1][k].norm() > 0 else 0.0)
+        lines.append(f'{size} stage {st + 1}: features {ef:.3e}  parameter gradients {eg:.3e}  (worst tensor {worst_k}: '
+                     f'{rel(res["production"][1][worst_k], res["op_by_op"][1][worst_k]):.3e})')
+        if ef > ROUTE_BOUNDS[size]['feat'] or eg > ROUTE_BOUNDS[size]['grad']:
+            bad.append(lines[-1])
+    print('\n'.join(lines))
+    assert not bad, '\n'.join(bad)
