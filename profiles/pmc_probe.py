@@ -190,6 +190,24 @@ elif op in ('mlps_fwd', 'mlps_dgrad', 'mlps_wgrad'):       # round 5: streamed-w
         fn = lambda: ops.mlp_bwd_recompute_dgrad(dys, xs, lw, lb, w1, b1, w2gt, w1t, dlw, dlb, 1e-5)
     else:
         fn = lambda: ops.mlp_bwd_recompute_wgrad(dys, xs, lw, lb, w1, b1, w2gt, dw1, db1, s2, cs2, 1e-5)
+if op.startswith('scan3_'):       # round 6: wide / long ConvLSTM scans with streamed weights (csrc/lstm_scan3.hpp): scan3_{fwd,bwd}_{256,128}
+    Cc = int(op.split('_')[2]); Mp, T_ = (23040, 21) if Cc == 256 else (92160, 21)
+    xa = rnd(T_, Mp, Cc)
+    w = rnd(4 * Cc, 2 * Cc) * 0.05
+    b = torch.zeros(4 * Cc, device=dev)
+    wp, wtp = ops.lstm_scan3_pack(w)
+    rows = ops.lstm_scan3_rows(Cc, Mp)
+    Hall = torch.zeros(T_ + 1, Mp, Cc, device=dev, dtype=dt)
+    Cs, gs = torch.empty(T_, rows, Cc, device=dev, dtype=dt), torch.empty(T_, rows, 4 * Cc, device=dev, dtype=dt)
+    cl = torch.empty(Mp, Cc, device=dev)
+    ops.lstm_scan3_fwd(xa, Hall, None, cl, Cs, wp, b, gs)
+    if op.startswith('scan3_fwd'):
+        fn = lambda: ops.lstm_scan3_fwd(xa, Hall, None, cl, Cs, wp, b, gs)
+    else:
+        dH, dcl = rnd(T_, Mp, Cc), torch.randn(Mp, Cc, device=dev)
+        dxa, dz = torch.empty(T_, Mp, Cc, device=dev, dtype=dt), torch.empty(T_, Mp, 4 * Cc, device=dev, dtype=dt)
+        dh0, dc0 = torch.empty(Mp, Cc, device=dev, dtype=dt), torch.empty(Mp, Cc, device=dev)
+        fn = lambda: ops.lstm_scan3_bwd(gs, Cs, None, dH, dcl, wtp, dxa, dz, dh0, dc0)
 for _ in range(3):
     fn()
 torch.cuda.synchronize()

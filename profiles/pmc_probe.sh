@@ -6,6 +6,7 @@ for OP in "$@"; do
   OUT=$ROOT/gpurun_out/pmc_$OP; rm -rf $OUT; mkdir -p $OUT
   timeout 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE \
       --kernel-trace --output-format csv -d $OUT -o pmc -- python $ROOT/profiles/pmc_probe.py $OP > $OUT/log.txt 2>&1
+  timeout 200 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCP_TCC_READ_REQ_sum --kernel-trace --output-format csv -d $OUT/L2 -o pmc -- python $ROOT/profiles/pmc_probe.py $OP > $OUT/log_L2.txt 2>&1
   for CTR in FETCH_SIZE WRITE_SIZE; do
     timeout 200 rocprofv3 --pmc $CTR --kernel-trace --output-format csv -d $OUT/$CTR -o pmc -- python $ROOT/profiles/pmc_probe.py $OP > $OUT/log_$CTR.txt 2>&1
   done
