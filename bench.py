@@ -517,6 +517,12 @@ def main():
     torch.cuda.set_device(device)
     import torch.distributed as dist
     if world > 1 or args.force_reducer:
+        if world == 1 and 'RANK' not in os.environ:            # --force-reducer without a launcher: a one-rank RCCL world of our own
+            import socket
+            with socket.socket() as sk:
+                sk.bind(('127.0.0.1', 0))
+                port = sk.getsockname()[1]
+            os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
         dist.init_process_group('nccl', device_id=device)      # "nccl" = RCCL on ROCm
 
     dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
