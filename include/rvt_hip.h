@@ -86,9 +86,9 @@ typedef struct RvtTuning {
     int lstm_scan3;           /* round 6: ConvLSTM (bf16, dws_conv False) with the time loop in the kernel, weights streamed from L2 in operand order, gates saved for the reverse scan (lstm_scan3.hpp): bit 0 = at C 256, bit 1 = at C 128 (instead of lstm_scan.hpp's register-resident weights) */
     int lstm_scan3_rb256;     /* 32-token blocks per workgroup tile of that forward at C = 256: 1 or 2 */
     int lstm_scan3_rb128;     /* ... at C = 128 */
-    int reserved[1];          /* zero */
+    int route_stage_driver_train; /* 1 (round 6): the training forward / backward of a stage take rvt_stage_seq_train_fwd / rvt_stage_seq_bwd (one call per stage and direction) where covered; 0: the Python host loop */
 } RvtTuning;
-#define RVT_TUNING_DEFAULTS {(int)sizeof(RvtTuning), 0, 1, 0, 512, 8192, 1, 4096, 0, 0, 0, 0, 1, 4, 0, 1, 1, 0, 0, 1, -1, 1, 1, -1, 1, 1, 0, 1, 1, 0, 1, 1, 1, 1, 1, 3, 1, 1, {0}}
+#define RVT_TUNING_DEFAULTS {(int)sizeof(RvtTuning), 0, 1, 0, 512, 8192, 1, 4096, 0, 0, 0, 0, 1, 4, 0, 1, 1, 0, 0, 1, -1, 1, 1, -1, 1, 1, 0, 1, 1, 0, 1, 1, 1, 1, 1, 3, 1, 1, 1}
 void rvt_tuning_defaults(RvtTuning* t);        /* fills *t with the production defaults */
 int rvt_get_tuning(RvtTuning* t);              /* t->struct_bytes must be set by the caller */
 int rvt_set_tuning(const RvtTuning* t);
@@ -358,6 +358,65 @@ typedef struct RvtStageDesc {
 size_t rvt_stage_seq_fwd_ws_bytes(const RvtStageDesc* desc, int T, int B);
 int rvt_stage_seq_fwd(const RvtStageDesc* desc, const void* inp, const void* h0, const float* c0, void* Hall, float* c_last,
                       void* ws, size_t ws_bytes, int T, int B, void* stream);
+
+/* ---- training-side stage driver (rvt_stage_seq_bwd; round 6) ----------------------------------------------
+ * The TRAINING forward and the BPTT backward of one stage (reference maxvit_rnn.py:169-182 under autograd, driven by
+ * modules/detection.py:131-148) as ONE library call each: the per-operator launches that rvt_amd/stage.py issued from Python
+ * (40 - 150 per stage and direction) are sequenced here.  Division of labour: the HOST decides the kernel routes (one place:
+ * rvt_amd/stage.py) and owns every tensor that outlives the call - the activations kept for backward (RvtBlockSaved and the
+ * stage-level pointers below) and the gradient buckets; the driver owns the order of launches and the backward's temporaries
+ * (carved from `ws`).  Nothing is launched that the operator entry points above do not launch.  Not covered (the host keeps its
+ * operator-by-operator loop): token masks, the DWS-ConvLSTM, the LDS-staged fused-MLP flavours that save GELU / GELU'. */
+typedef struct RvtBlockSaved {            /* activations of one block kept for backward; NULL = not kept on the chosen route */
+    const void* xin;                      /* block input [M][C] (= previous block's xout, or the LayerNorm output of the down-sampling) */
+    void* u;                              /* norm1(xin) (op-by-op attention with a norm1) */
+    void* qkv;                            /* [M][3C] (op-by-op attention) */
+    void* a;                              /* attention output rows [M][C] (operand of the proj weight gradient) */
+    void* xmid;                           /* [M][C] */
+    void* v2;                             /* norm2(xmid) (op-by-op MLP) */
+    void* hg; void* hgp;                  /* GELU(h), GELU'(h) [M][4C] (op-by-op MLP) */
+    void* xout;                           /* [M][C] */
+} RvtBlockSaved;
+typedef struct RvtBlockTrain {            /* backward-side operands and fp32 gradient accumulators (+=) of one block */
+    const void *qkv_wt, *proj_wt, *fc1_wt, *fc2_wt;      /* W^T copies; proj / fc2 with LayerScale folded in (rvt_amd/weights.py) */
+    float *d_n1_w, *d_n1_b;               /* NULL without norm1 */
+    float *d_qkv_w, *d_qkv_b, *d_S1, *d_cs1;             /* S1 = dxmid^T a, cs1 = colsum(dxmid): raw proj products (LayerScale fold later) */
+    float *d_n2_w, *d_n2_b, *d_fc1_w, *d_fc1_b, *d_S2, *d_cs2;
+} RvtBlockTrain;
+typedef struct RvtStageTrain {
+    int struct_bytes;                     /* sizeof(RvtStageTrain) */
+    /* routes, decided by the host */
+    int attn_block;                       /* 1: fused attention half (rvt_attn_block_fwd / _bwd) */
+    int ln_linear;                        /* 1: norm1 + qkv in one launch (rvt_ln_linear_fwd) */
+    int mlp_route;                        /* 0: LayerNorm, fc1 + GELU / GELU', fc2 as separate launches; 1: recompute route (rvt_mlp_fwd keeps nothing) */
+    int mlp_bwd_both;                     /* route 1: rvt_mlp_bwd_recompute_both instead of _dgrad + _wgrad */
+    int dgrad_ln_qkv, dgrad_ln_fc1;       /* 1: that input gradient + the LayerNorm backward behind it in one launch (rvt_linear_dgrad_ln) */
+    int lstm_route;                       /* 0: one launch per step; 1: the rvt_lstm_scan_ kernels, gates recomputed; 2: the same with saved gates; 3: the rvt_lstm_scan3_ kernels */
+    int lstm_scan_wgrad;                  /* routes 1: ConvLSTM weight gradients inside the reverse scan */
+    int conv_dgrad4;                      /* 1: rvt_conv_dgrad4 for the input gradient of the down-sampling conv */
+    const RvtBlockSaved* saved;           /* HOST arrays, 2 * num_blocks entries each */
+    const RvtBlockTrain* tb;
+    void *y0, *x0;                        /* conv output, LayerNorm output (= saved[0].xin) */
+    void* Hall;                           /* [T+1][B][H][W][C]; slot 0 = incoming h, filled by the host */
+    float* c_last;                        /* [B][H][W][C] */
+    void* Csave;                          /* scan routes: cell-state copies (layout of the scan kernel in use) */
+    void* gates;                          /* routes 0, 2, 3: activated gates */
+    float* Call;                          /* route 0: [T+1][B][H][W][C] fp32; slot 0 = incoming c, filled by the host */
+    const float* c0_saved;                /* scan routes, backward: the incoming cell state as the forward saw it (NULL = zeros) */
+    const void *lstm_wp3, *lstm_wtp3;     /* route 3: rvt_lstm_scan3_pack outputs */
+    const void *lstm_wt, *conv_wd4, *conv_wd;
+    float *d_lstm_w, *d_lstm_b, *d_ln_w, *d_ln_b, *d_raw_conv;
+} RvtStageTrain;
+/* inp / h0 / c0 as rvt_stage_seq_fwd.  No workspace: every buffer the forward writes is named in `tr`. */
+int rvt_stage_seq_train_fwd(const RvtStageDesc* desc, const RvtStageTrain* tr, const void* inp, const float* c0, int T, int B,
+                            void* stream);
+/* dH [T][B][H][W][C] cotangent of Hall[1..] (route 0: must not be NULL), dc_last fp32 (NULL = zeros), prev_cot: cotangent already
+ * attached to the stage's input frames (added to the conv input gradient; NULL = none), d_in [T*B][H_in][W_in][Cin] (NULL: no
+ * input gradient), dh0 [B][H][W][C], dc0 fp32.  `inp` = the tensor the forward read (planes or channels-last frames).
+ * ws: rvt_stage_seq_bwd_ws_bytes bytes.  Parameter gradients are ACCUMULATED (+=) into the pointers of `tr`. */
+size_t rvt_stage_seq_bwd_ws_bytes(const RvtStageDesc* desc, const RvtStageTrain* tr, int T, int B);
+int rvt_stage_seq_bwd(const RvtStageDesc* desc, const RvtStageTrain* tr, const void* inp, const void* dH, const float* dc_last,
+                      const void* prev_cot, void* d_in, void* dh0, float* dc0, void* ws, size_t ws_bytes, int T, int B, void* stream);
 
 /* Depth-wise k x k conv (k = 3; groups = channels, padding k/2, stride 1) of the DWS-ConvLSTM (rnn.py:25-29,50-54)
  * on channels-last maps: y[n][y][x][c] = b[c] + sum_taps w[c][ky][kx] x[...][c].  x / y rows have pitch ldx / ldy

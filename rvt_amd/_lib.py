@@ -82,7 +82,7 @@ EXPORTS = sorted(list(_SIGS) + ['rvt_last_error', 'rvt_is_emulator', 'rvt_wgrad_
                                'rvt_mlp_bwd_fused_ws_floats', 'rvt_attn_block_supported', 'rvt_lstm_scan_bwd_ws_floats',
                                'rvt_lstm_scan_saves_gates', 'rvt_stem_supported', 'rvt_stem_wgrad_ws_floats', 'rvt_conv_dgrad4_supported',
                                'rvt_linear_dgrad_ln_supported', 'rvt_ln_linear_supported', 'rvt_tuning_defaults', 'rvt_get_tuning', 'rvt_set_tuning', 'rvt_probe_mfma',
-                               'rvt_stage_seq_fwd', 'rvt_stage_seq_fwd_ws_bytes', 'rvt_lstm_scan3_supported', 'rvt_lstm_scan3_rows', 'rvt_simota_ws_bytes', 'rvt_mlp_bwd_both_supported'])
+                               'rvt_stage_seq_fwd', 'rvt_stage_seq_fwd_ws_bytes', 'rvt_lstm_scan3_supported', 'rvt_lstm_scan3_rows', 'rvt_stage_seq_train_fwd', 'rvt_stage_seq_bwd', 'rvt_stage_seq_bwd_ws_bytes', 'rvt_simota_ws_bytes', 'rvt_mlp_bwd_both_supported'])
 
 
 def _bind(lib: ctypes.CDLL) -> ctypes.CDLL:

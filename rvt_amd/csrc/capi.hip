@@ -10,3 +10,4 @@
 #include "capi_scan.hip"
 #include "capi_stage.hip"
 #include "capi_head.hip"
+#include "capi_train.hip"

@@ -187,11 +187,12 @@ class StageGeom:
 
 class StageSaved:
     """Activations kept for backward (everything else is recomputed from these)."""
-    __slots__ = ('inp', 'y0', 'blocks', 'x_last', 'Hall', 'Call', 'gates', 'mask', 'xin_lstm', 'hconv', 'Csave', 'c0', 'scan3', '__weakref__')
+    __slots__ = ('inp', 'y0', 'blocks', 'x_last', 'Hall', 'Call', 'gates', 'mask', 'xin_lstm', 'hconv', 'Csave', 'c0', 'scan3', 'train', '__weakref__')
 
     def __init__(self):
         self.blocks: List[Dict[str, Tensor]] = []
         self.scan3 = False
+        self.train = None           # set by the C-side training driver (rvt_amd/stage_driver.py: train_forward)
 
 
 def stage_seq_forward(sw: StageWeights, g: StageGeom, inp: Tensor, h0: Optional[Tensor], c0: Optional[Tensor],
@@ -201,6 +202,12 @@ def stage_seq_forward(sw: StageWeights, g: StageGeom, inp: Tensor, h0: Optional[
     F_ = T * B
     H, W, C = g.H, g.W, g.C
     dt, dev = sw.conv_w.dtype, inp.device
+    if save and tuning.get('route_stage_driver_train') != 0:
+        # the whole training forward of the stage as ONE library call (include/rvt_hip.h: rvt_stage_seq_train_fwd) where covered
+        from . import stage_driver
+        routes = stage_driver.train_routes(sw, g, dt, T, B, token_mask)
+        if routes is not None:
+            return stage_driver.train_forward(sw, g, inp, h0, c0, T, B, routes)
     sv = StageSaved() if save else None
 
     if inp.dtype == torch.uint8:
@@ -347,6 +354,13 @@ def stage_seq_backward(sw: StageWeights, g: StageGeom, sv: StageSaved, dH: Optio
     dt, dev = sv.y0.dtype, sv.y0.device
     f32 = torch.float32
     G = sg.g
+    if sv.train is not None:
+        # BPTT + block / conv backward of the stage as ONE library call (rvt_stage_seq_bwd); the LayerScale fold / conv unpack follow
+        from . import stage_driver
+        out = stage_driver.train_backward(sw, g, sv, dH, dc_last, T, B, need_input_grad, prev_cot, sg, pre)
+        if finalize is not None:
+            finalize()
+        return out
 
     # ---- ConvLSTM BPTT ------------------------------------------------------------------------------
     dx = torch.empty((T, B, H, W, C), dtype=dt, device=dev)

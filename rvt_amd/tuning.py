@@ -21,7 +21,7 @@ from typing import Dict, Iterator
 _GEOMETRY = ('gemm_resident', 'gemm_xcd_panels', 'wgrad_bn', 'wgrad_blocks', 'wgrad_slice_tokens', 'ppgemm', 'ppgemm_min_m',
              'ppgemm_all', 'ppgemm_grid', 'ppgemm_tn_items', 'one_per_cu_grid', 'stem', 'stem_depth', 'mlp_tm', 'mlp_chain',
              'mlp_chain_wgrad', 'chain_resident', 'attn_block_resident', 'dgrad_ln')
-_LATE = ('lstm_scan_v2', 'route_stage_driver', 'route_mlp_store_pre', 'route_mlp_bwd_both', 'mlp_stream', 'ln_linear', 'conv_wgrad_tn', 'attn_staged', 'lstm_scan3', 'lstm_scan3_rb256', 'lstm_scan3_rb128')          # fields appended after the routes (struct order = _GEOMETRY + _ROUTES + _LATE)
+_LATE = ('lstm_scan_v2', 'route_stage_driver', 'route_mlp_store_pre', 'route_mlp_bwd_both', 'mlp_stream', 'ln_linear', 'conv_wgrad_tn', 'attn_staged', 'lstm_scan3', 'lstm_scan3_rb256', 'lstm_scan3_rb128', 'route_stage_driver_train')          # fields appended after the routes (struct order = _GEOMETRY + _ROUTES + _LATE)
 _ROUTES = ('route_fused_mlp', 'route_mlp_bwd_fused', 'route_attn_block', 'route_lstm_scan', 'route_lstm_scan_wgrad',
            'route_conv_dgrad4', 'route_wgrad_stream')
 FIELDS = _GEOMETRY + _ROUTES + _LATE
@@ -29,7 +29,7 @@ FIELDS = _GEOMETRY + _ROUTES + _LATE
 
 class RvtTuning(ctypes.Structure):
     """Mirror of `struct RvtTuning` (include/rvt_hip.h) — field order is part of the C ABI."""
-    _fields_ = [('struct_bytes', ctypes.c_int)] + [(f, ctypes.c_int) for f in FIELDS] + [('reserved', ctypes.c_int * 1)]
+    _fields_ = [('struct_bytes', ctypes.c_int)] + [(f, ctypes.c_int) for f in FIELDS]
 
 
 # what the tests install: small grids so that test-size problems walk several tiles / K slices per workgroup, and every
