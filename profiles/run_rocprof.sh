@@ -14,7 +14,7 @@ timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OU
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o write -- $BENCH > $OUT/write.log 2>&1
 find $OUT -type f | head -50
 # keep only what fits the 64 MiB pull limit: stats + compacted per-kernel aggregates
-python $ROOT/profiles/summarize_rocprof.py $OUT base_1mpx:bf16:B24:T21 8 > $OUT/summary_$TAG.txt 2>&1      # (8 = warmup 1 + instrumented 2 + 2 + 1 + timed 2 steps)
+python $ROOT/profiles/summarize_rocprof.py $OUT base_1mpx:bf16:B24:T21 11 > $OUT/summary_$TAG.txt 2>&1      # (11 steps = warmup 1 + instrumented 2 + untimed 2 + host-enqueue probe 1 + timed 2 + roofline pass 1 + 2)
 cat $OUT/summary_$TAG.txt | head -80
 find $OUT -name '*.db' -delete
 find $OUT -name '*.csv' -size +4M -delete
