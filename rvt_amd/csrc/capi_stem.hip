@@ -29,9 +29,9 @@ int rvt_stem_fwd(const void* src, const void* w, const float* ln_w, const float*
     g.NR = Cin * STEM_K; g.KS = (g.NR + 1) / 2; g.KSP = (g.KS + D - 1) / D * D;
     RVT_CHECK(g.KSP <= STEM_KSP_MAX, "stem_fwd: %d k-steps do not fit the LDS", g.KSP);
     g.XS = (g.Wo + 31) / 32; g.OG = (g.Ho + STEM_FWD_PB - 1) / STEM_FWD_PB;
-    const int og8 = (g.OG + 7) / 8;
+    const int og8 = (g.OG * g.XS + 7) / 8;              // sets of eight (row group, segment) units per frame
     g.n_items = F * og8;
-    g.dOG = FastDiv(og8); g.d7 = FastDiv(STEM_K);
+    g.dOG = FastDiv(og8); g.d7 = FastDiv(STEM_K); g.dXS = FastDiv(g.XS);
     const int grid = one_per_cu_grid(g.n_items);
     if (D == 5)
         hipLaunchKernelGGL((stem_fwd_kernel<STEM_FWD_PB, 5>), dim3(grid), dim3(512), 0, (hipStream_t)stream, (const uint8_t*)src,

@@ -34,8 +34,8 @@ struct StemGeom {
     int F, Cin, cp, h, w, Ho, Wo;          // planes [F][Cin][h][w]; output [F][Ho][Wo][64]; cp = padded Cin of the weights
     int NR, KS, KSP;                       // contraction rows (c, ky), k-steps of two rows, k-steps padded to the pipeline depth
     int XS, OG;                            // 32-pixel segments per output row, groups of PB output rows
-    int n_items;                           // workgroup items: (frame, eight consecutive row groups)
-    FastDiv dOG, d7;                       // dOG: by the number of eight-row-group sets per frame
+    int n_items;                           // workgroup items: (frame, eight consecutive (row group, segment) units)
+    FastDiv dOG, d7, dXS;                  // dOG: by the number of eight-unit sets per frame; dXS: by the segments per row
 };
 
 constexpr int STEM_K = 7, STEM_STRIDE = 4, STEM_PAD = 3, STEM_CO = 64;
@@ -166,17 +166,23 @@ stem_fwd_kernel(const uint8_t* __restrict__ src, const bf16* __restrict__ wp, co
     __syncthreads();
 
     const size_t hw = (size_t)g.h * g.w;
-    // Work split: a workgroup item = eight consecutive row groups of one frame, one per wave; the wave walks its row group
-    // segment by segment.  The window of a segment reaches one dword into the cache line of the segment to its left, and
-    // three plane rows into the row group above: both are lines this wave / the neighbouring wave has just pulled in.
-    // (Items of (row group, segment) dealt round-robin fetched 4.4 GB for 2.3 GB of planes.)
+    // Work split (round 6): a workgroup item = eight consecutive (row group, segment) UNITS of one frame in row-major order, one per
+    // wave, all in flight at the same time.  A segment's window [128 xs - 4, 128 xs + 128) reaches one dword into the cache line of the
+    // segment to its left and three plane rows into the row group above: with the left / upper neighbour running on a neighbouring
+    // wave of the SAME workgroup those lines are in flight together.  Measured (profiles/r6/pmc_stem_fwd.txt): 4.36 GB fetched for
+    // 2.32 GB of planes and 1.30 ms, against 4.72 GB / 1.34 ms for the round-2 split (a wave walking its row group segment by segment:
+    // it came back to the neighbour line 50 KB per wave later) and 4.4 GB for units dealt round-robin over workgroups.  The fabric
+    // request counter agrees with FETCH_SIZE (TCC_EA0_RDREQ x 64 B = the raw counter); most of the remaining 1.9 x is NOT the halo
+    // (19 / 16 rows, 132 / 128 bytes) and is not explained yet.
     const int wv = wave_uniform(wave);
-    for (int item = blockIdx.x; item < g.n_items; item += gridDim.x)
-    for (int xs = 0; xs < g.XS; xs++) {
-        uint32_t f, og8;
-        g.dOG.divmod((uint32_t)item, f, og8);
-        const int og = 8 * (int)og8 + wv;
-        if (og >= g.OG) continue;
+    for (int item = blockIdx.x; item < g.n_items; item += gridDim.x) {
+        uint32_t f, u8;
+        g.dOG.divmod((uint32_t)item, f, u8);
+        const int unit = 8 * (int)u8 + wv;
+        if (unit >= g.OG * g.XS) continue;
+        uint32_t ogu, xsu;
+        g.dXS.divmod((uint32_t)unit, ogu, xsu);
+        const int og = (int)ogu, xs = (int)xsu;
         const int oy0 = PB * og, ox = 32 * xs + li;
         const bool colok = ox < g.Wo;
         // per-lane source columns: d0 = bytes x 4ox-4 .. 4ox-1 (the zero padding at ox = 0), d1 = bytes x 4ox .. 4ox+3 (zeros past
