@@ -2,8 +2,8 @@
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 OUT=$ROOT/gpurun_out/pmc_stem_ea; rm -rf $OUT; mkdir -p $OUT
-timeout 200 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT -o pmc -- python $ROOT/profiles/pmc_probe.py stem_fwd > $OUT/log.txt 2>&1
-timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/f -o pmc -- python $ROOT/profiles/pmc_probe.py stem_fwd > $OUT/logf.txt 2>&1
+timeout 200 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT -o pmc -- python $ROOT/profiles/pmc_probe.py stem_fwd $PROBE_LIB > $OUT/log.txt 2>&1
+timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/f -o pmc -- python $ROOT/profiles/pmc_probe.py stem_fwd $PROBE_LIB > $OUT/logf.txt 2>&1
 python - "$OUT" <<'PY'
 import csv, glob, os, sys
 from collections import defaultdict
