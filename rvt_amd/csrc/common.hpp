@@ -94,6 +94,32 @@ inline void mma32(f32x16& c, const f32x8& a, const f32x8& b) { mma32_emu(c, a, b
 inline void mma32_zero(f32x16& c, const bf16x8& a, const bf16x8& b) { for (int i = 0; i < 16; i++) c[i] = 0.f; mma32_emu(c, a, b); }
 #endif
 
+// ---- MFMA: one 16x16 output block, K = 32 (v_mfma_f32_16x16x32_bf16) ----------------------------------------------
+// lane l supplies row l & 15 of A (and of B), k-slots 8 (l >> 4) + 0..7; C/D: col = l & 15 (B's row), row = 4 (l >> 4) + r, r in [0, 4).
+// Same FLOP rate as the 32x32 form; used where a product has to be cut into MORE blocks than a 32x32 tiling gives (one per wave).
+#ifndef RVT_EMU
+__device__ __forceinline__ void mma16(f32x4& c, const bf16x8& a, const bf16x8& b) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+#else
+inline void mma16(f32x4& c, const bf16x8& a, const bf16x8& b) {
+    float ab[16];
+    for (int j = 0; j < 8; j++) { ab[j] = (float)a[j]; ab[8 + j] = (float)b[j]; }
+    auto buf = emu::exchange(ab, sizeof(ab));
+    const int lane = emu::g.cur->lane, col = lane & 15;
+    for (int r = 0; r < 4; r++) {
+        const int row = 4 * (lane >> 4) + r;
+        float s = c[r];
+        for (int g = 0; g < 4; g++) {
+            const float* pa = reinterpret_cast<const float*>(buf[row + 16 * g]);
+            const float* pb = reinterpret_cast<const float*>(buf[col + 16 * g]) + 8;
+            for (int e = 0; e < 8; e++) s += pa[e] * pb[e];
+        }
+        c[r] = s;
+    }
+}
+#endif
+
 __device__ __forceinline__ void acc_zero(f32x16& c) {
 #pragma unroll
     for (int i = 0; i < 16; i++) c[i] = 0.0f;

@@ -330,9 +330,10 @@ constexpr int MCW_ROWB = 144;              // LDS row pitch of the [32 tokens][6
 // DGRAD = true (round 4): the same launch ALSO produces the input gradient dxmid = dxout + LN2'(dh W1) and dln_w / dln_b — what
 // mlpc_bwd_dgrad_kernel computes from a second recompute of h and a second read of xmid / dxout.  dh is already here, split over the
 // waves by hidden column; it takes three more stations, each one phase (= one workgroup barrier) behind the previous:
-//   compute(i)   every wave also writes its dh columns to the tile DH[t][j]                       (16 two-byte LDS stores per lane)
-//   duty(i-1)    TWO waves (rotating, on different SIMDs) multiply  dv2[t][c] = sum_j DH[t][j] W1[j][c]  for 32 channels each
-//                (16 MFMAs, A = DH rows, B = rows of W1^T staged in LDS once; plain 16-byte reads) and leave it in PB[t][c] (bf16)
+//   compute(i)   every wave also writes its dh columns to the tile DH^T[j][t]                     (4 eight-byte LDS stores per lane)
+//   duty(i-1)    all eight waves multiply  dv2[t][c] = sum_j DH[t][j] W1[j][c]  as 16 x 16 blocks (16 tokens x 16 channels per wave,
+//                eight v_mfma_f32_16x16x32_bf16; operands = rows of W1^T staged in LDS once and rows of DH, plain 16-byte reads) and
+//                leave it in PB[t][c] (bf16).  (Round 4: two waves, 32 x 32 blocks, sixteen chained MFMAs each - six waves waiting.)
 //   lnbwd(i-2)   all 512 threads in the staging role (16 per token, 4 channels each): LayerNorm backward + residual, 8-byte
 //                stores of dxmid; the rows of xmid / dxout come back from L2 (fetched one phase ahead), mean / rstd from the
 //                tile's own stash through a 1-KB LDS ring.
@@ -348,14 +349,15 @@ mlpc_bwd_wgrad_kernel(const bf16* __restrict__ dxout, const bf16* __restrict__ x
                       const bf16* __restrict__ W1T, bf16* __restrict__ dxmid, float* __restrict__ dln_w, float* __restrict__ dln_b) {
     typedef bf16 T;
     constexpr int C = 64, KS = C / 16, NCB = C / 32, HID = 4 * C, TILE = 32 * MCW_ROWB;
-    constexpr int EXTRA = DGRAD ? (C * MCW_HP + 2 * 32 * MCW_HP + 2 * 32 * MCW_PP + 4 * 32 * 8) : 0;
+    constexpr int DHT_BYTES = HID * 64;                                          // one DH^T tile: [256 hidden][32 tokens] bf16
+    constexpr int EXTRA = DGRAD ? (C * MCW_HP + 2 * DHT_BYTES + 2 * 32 * MCW_PP + 4 * 32 * 8) : 0;
     __shared__ __attribute__((aligned(16))) char smem[4 * TILE + GELU_NLUT2_BYTES + 16 + EXTRA];
     char* const V2 = smem;
     char* const DX = smem + 2 * TILE;
     float* const lut = reinterpret_cast<float*>(smem + 4 * TILE);
     char* const WT = smem + ((4 * TILE + GELU_NLUT2_BYTES + 15) & ~15);          // W1^T: [64 channels][256 hidden]
-    char* const DH = WT + C * MCW_HP;                                            // 2 x [32 tokens][256 hidden]
-    char* const PB = DH + 2 * 32 * MCW_HP;                                       // 2 x [32 tokens][64 channels]
+    char* const DH = WT + C * MCW_HP;                                            // 2 x DH^T [256 hidden][32 tokens], 8-byte chunk ^= (row >> 2) & 7
+    char* const PB = DH + 2 * DHT_BYTES;                                         // 2 x [32 tokens][64 channels]
     float* const MR = reinterpret_cast<float*>(PB + 2 * 32 * MCW_PP);            // ring of 4 tiles x [32 tokens] x {mean, rstd} (stash -> lnbwd)
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, half = lane >> 5, wave = tid >> 6;
     gelu_nlut2_fill(lut, tid, 512);
@@ -443,12 +445,17 @@ mlpc_bwd_wgrad_kernel(const bf16* __restrict__ dxout, const bf16* __restrict__ x
                 dhf[q][e] = (T)d;
             }
         }
-        if (DGRAD) {                  // dh[t][j]: this lane's hidden column, the tile's 16 tokens of this half
-            char* const dhb = DH + buf * (32 * MCW_HP) + (32 * wave + li) * 2;
+        if (DGRAD) {                  // dh^T[j][t]: this lane's hidden column is a ROW of the tile; accumulator registers 4 g .. 4 g + 3 are the
+                                      // four consecutive tokens 8 g + 4 half ..: four 8-byte stores (the [t][j] form took sixteen 2-byte stores)
+            char* const dhb = DH + buf * DHT_BYTES + (32 * wave + li) * 64;
+            const int sw = (li >> 2) & 7;
 #pragma unroll
-            for (int q = 0; q < 2; q++)
+            for (int g = 0; g < 4; g++) {
+                bf16x4 v;
 #pragma unroll
-                for (int e = 0; e < 8; e++) *reinterpret_cast<T*>(dhb + acc_row(8 * q + e, lane) * MCW_HP) = dhf[q][e];
+                for (int w = 0; w < 4; w++) v[w] = dhf[g >> 1][4 * (g & 1) + w];
+                *reinterpret_cast<bf16x4*>(dhb + (((2 * g + half) ^ sw) << 3)) = v;
+            }
         }
 #pragma unroll
         for (int cb = 0; cb < NCB; cb++)
@@ -464,25 +471,30 @@ mlpc_bwd_wgrad_kernel(const bf16* __restrict__ dxout, const bf16* __restrict__ x
     // ---- DGRAD stations (see the head comment).  `k` = how many tiles this workgroup has started before the one in question.
     auto duty = [&](int buf, int tile, int k) {
         if (!DGRAD || tile < 0 || tile >= n_tiles) return;
-        const int w0 = k & 3, w1 = 4 + ((k + 2) & 3);                // two waves on different SIMDs, rotating with the tile count
-        if (wave != w0 && wave != w1) return;
-        const int cb = wave == w0 ? 0 : 1;
-        const char* const a = DH + buf * (32 * MCW_HP) + li * MCW_HP + half * 16;
-        const char* const b = WT + (32 * cb + li) * MCW_HP + half * 16;
-        // sixteen k-steps on two accumulator chains (one chain: every MFMA waits for its predecessor's result)
-        f32x16 acc, acc2;
-        acc_zero(acc);
-        acc_zero(acc2);
+        (void)k;
+        // dv2^T[c][t] = sum_j W1^T[c][j] DH[t][j] cut into EIGHT 16 x 16 blocks, one per wave (v_mfma_f32_16x16x32_bf16): wave w owns
+        // tokens 16 (w & 1) .., channels 16 (w >> 1) ..  (Round 4 gave the product to two waves as 32 x 32 blocks, sixteen chained
+        // MFMAs each, while the other six waited at the barrier.)  A = rows of W1^T, B = rows of DH: a lane ends up with FOUR
+        // CONSECUTIVE CHANNELS of one token = one 8-byte store into PB.
+        const int l15 = lane & 15, kg = lane >> 4, tb = wave & 1, cq = wave >> 1;
+        const char* const a = WT + (16 * cq + l15) * MCW_HP + kg * 16;
+        // B = rows of DH ("row token, slots = hidden 32 ks + 8 kg + e") out of the DH^T tile through the transposing read: lane L of a
+        // 16-lane group addresses the four tokens 16 tb + 4 (L & 3) .. of hidden row 32 ks + 8 kg + (L >> 2) (+ 4 for slots 4..7)
+        const int jr = 8 * kg + (l15 >> 2), ct = 4 * tb + (l15 & 3);
+        const char* const b_lo = DH + buf * DHT_BYTES + jr * 64 + ((ct ^ ((2 * kg) & 7)) << 3);
+        const char* const b_hi = DH + buf * DHT_BYTES + (jr + 4) * 64 + ((ct ^ ((2 * kg + 1) & 7)) << 3);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};          // two chains: a dependent MFMA waits for its predecessor
 #pragma unroll
-        for (int ks = 0; ks < HID / 16; ks += 2) {
-            mma32(acc, *reinterpret_cast<const frag_t<T>*>(a + ks * 32), *reinterpret_cast<const frag_t<T>*>(b + ks * 32));
-            mma32(acc2, *reinterpret_cast<const frag_t<T>*>(a + (ks + 1) * 32), *reinterpret_cast<const frag_t<T>*>(b + (ks + 1) * 32));
+        for (int ks = 0; ks < HID / 32; ks += 2) {
+            mma16(acc, *reinterpret_cast<const frag_t<T>*>(a + ks * 64),
+                  frag_from_tr<T>(reinterpret_cast<const bf16*>(b_lo + ks * 2048), reinterpret_cast<const bf16*>(b_hi + ks * 2048)));
+            mma16(acc2, *reinterpret_cast<const frag_t<T>*>(a + (ks + 1) * 64),
+                  frag_from_tr<T>(reinterpret_cast<const bf16*>(b_lo + (ks + 1) * 2048), reinterpret_cast<const bf16*>(b_hi + (ks + 1) * 2048)));
         }
+        bf16x4 o;
 #pragma unroll
-        for (int r = 0; r < 16; r++) acc[r] += acc2[r];
-        char* const pb = PB + buf * (32 * MCW_PP) + (32 * cb + li) * 2;
-#pragma unroll
-        for (int r = 0; r < 16; r++) *reinterpret_cast<T*>(pb + acc_row(r, lane) * MCW_PP) = (T)acc[r];
+        for (int r = 0; r < 4; r++) o[r] = (T)(acc[r] + acc2[r]);
+        *reinterpret_cast<bf16x4*>(PB + buf * (32 * MCW_PP) + (16 * tb + l15) * MCW_PP + (16 * cq + 4 * kg) * 2) = o;
     };
     auto lnbwd = [&](const Stage& st, int buf, int tile, int slot) {
         if (!DGRAD || tile < 0 || tile >= n_tiles) return;
