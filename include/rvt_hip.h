@@ -87,8 +87,9 @@ typedef struct RvtTuning {
     int lstm_scan3_rb256;     /* 32-token blocks per workgroup tile of that forward at C = 256: 1 or 2 */
     int lstm_scan3_rb128;     /* ... at C = 128 */
     int route_stage_driver_train; /* 1 (round 6): the training forward / backward of a stage take rvt_stage_seq_train_fwd / rvt_stage_seq_bwd (one call per stage and direction) where covered; 0: the Python host loop */
+    int route_attn_preln;     /* 1 (round 6): the backward of a stage's first block on the fused attention half also carries the gradient through the down-sampling LayerNorm (rvt_attn_block_bwd_preln) where no token mask sits between them; 0: rvt_attn_block_bwd + rvt_layernorm_bwd */
 } RvtTuning;
-#define RVT_TUNING_DEFAULTS {(int)sizeof(RvtTuning), 0, 1, 0, 512, 8192, 1, 4096, 0, 0, 0, 0, 1, 4, 0, 1, 1, 0, 0, 1, -1, 1, 1, -1, 1, 1, 0, 1, 1, 0, 1, 1, 1, 1, 1, 3, 1, 1, 1}
+#define RVT_TUNING_DEFAULTS {(int)sizeof(RvtTuning), 0, 1, 0, 512, 8192, 1, 4096, 0, 0, 0, 0, 1, 4, 0, 1, 1, 0, 0, 1, -1, 1, 1, -1, 1, 1, 0, 1, 1, 0, 1, 1, 1, 1, 1, 3, 1, 1, 1, 1}
 void rvt_tuning_defaults(RvtTuning* t);        /* fills *t with the production defaults */
 int rvt_get_tuning(RvtTuning* t);              /* t->struct_bytes must be set by the caller */
 int rvt_set_tuning(const RvtTuning* t);
@@ -261,6 +262,14 @@ int rvt_attn_block_bwd(const void* x, const void* dxmid, void* dx, void* dqkv, v
                        const float* ln_b, const void* wqkv, const float* bqkv, const void* wpg_t, float* dln_w, float* dln_b,
                        int dtype, int F, int H, int W, int C, int dim_head, int ph, int pw, int window, float eps,
                        void* stream);
+/* The backward of a stage's FIRST block (no norm1: its input x = LN_pre(y0) is the output of the down-sampling norm,
+ * maxvit.py:177, maxvit_rnn.py:153) carried through that norm in the same launch (round 6): dy0 = LN_pre'(dxmid + dqkv wqkv ; y0)
+ * is written instead of dx, ln_w is LN_pre's weight, dln_w / dln_b += its parameter gradients (autograd of maxvit.py:177).
+ * Replaces rvt_attn_block_bwd(ln_w = NULL) followed by rvt_layernorm_bwd(y0, ..): same dqkv bits, one row per token less to
+ * write and two less to read.  Partitions of at most 64 tokens (two 32-token blocks), like rvt_attn_block_bwd. */
+int rvt_attn_block_bwd_preln(const void* x, const void* y0, const void* dxmid, void* dy0, void* dqkv, const float* ln_w,
+                             const void* wqkv, const float* bqkv, const void* wpg_t, float* dln_w, float* dln_b, int dtype, int F,
+                             int H, int W, int C, int dim_head, int ph, int pw, int window, float eps, void* stream);
 
 /* ConvLSTM cell with 1x1 conv (rnn.py:52-67): mix = [x|h_prev] Wp^T + bp with gate-interleaved rows
  * (row n' = (c/8)*32 + gate*8 + c%8, gates f,i,o,g); writes h_out [M][C], c_out [M][C] (float32) and,
@@ -394,6 +403,7 @@ typedef struct RvtStageTrain {
     int lstm_route;                       /* 0: one launch per step; 1: the rvt_lstm_scan_ kernels, gates recomputed; 2: the same with saved gates; 3: the rvt_lstm_scan3_ kernels */
     int lstm_scan_wgrad;                  /* routes 1: ConvLSTM weight gradients inside the reverse scan */
     int conv_dgrad4;                      /* 1: rvt_conv_dgrad4 for the input gradient of the down-sampling conv */
+    int attn_preln;                       /* attn_block = 1: the first block's backward also carries the gradient through the down-sampling norm (rvt_attn_block_bwd_preln) */
     const RvtBlockSaved* saved;           /* HOST arrays, 2 * num_blocks entries each */
     const RvtBlockTrain* tb;
     void *y0, *x0;                        /* conv output, LayerNorm output (= saved[0].xin) */

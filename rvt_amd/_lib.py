@@ -46,6 +46,7 @@ _SIGS = {
     'rvt_attn_bwd': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     'rvt_attn_block_fwd': [_vp] * 10 + [_i] * 9 + [_f, _vp],
     'rvt_attn_block_bwd': [_vp] * 12 + [_i] * 9 + [_f, _vp],
+    'rvt_attn_block_bwd_preln': [_vp] * 11 + [_i] * 9 + [_f, _vp],
     'rvt_lstm_fwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     'rvt_lstm_gates_bwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     'rvt_lstm_dgrad': [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],

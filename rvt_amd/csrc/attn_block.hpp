@@ -391,20 +391,27 @@ template <class T, int NB> struct AbBwdScratch {          // per wave: P and dS 
 // identity MFMAs, multiplied with u in the same form, 32x32 results added into an LDS-resident fp32 image of dW with
 // ds_add_f32: correct, but an LDS float atomic costs ~180 cycles per wave instruction on gfx950 — 16.7 ms against 2.7 ms for
 // this kernel plus the weight-gradient GEMM.)
-template <class T, int C, int NB, bool LN, int WPB>
+// PRE (with LN = false; round 6): the block input x is itself the output of a LayerNorm, x = LN_pre(y0) - the down-sampling
+// norm in front of a stage's first block (maxvit.py:177, which is why that block has no norm1: `skip_first_norm`) - and the launch
+// carries the gradient through it: `dx` receives dy0 = LN_pre'(dxmid + du ; y0) instead of dxmid + du, `ln_w` is THAT norm's weight,
+// dln_w / dln_b its parameter gradients.  The attention part is the LN = false kernel unchanged (same dqkv bits); only the last
+// step differs, where the y0 rows are read (one more row per token) - the stand-alone LayerNorm backward launch (three rows per
+// token: 0.63 ms at stage 1 of RVT-Base) disappears.
+template <class T, int C, int NB, bool LN, int WPB, bool PRE = false>
 __global__ void __launch_bounds__(64 * WPB, 1)
 attn_block_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dxmid, T* __restrict__ dx, T* __restrict__ dqkv,
                       T* __restrict__ u_out, const float* __restrict__ ln_w, const float* __restrict__ ln_b,
                       const T* __restrict__ Wqkv, const float* __restrict__ bqkv, const T* __restrict__ WpgT,
-                      float* __restrict__ dln_w, float* __restrict__ dln_b, AttnGeom g, float eps) {
+                      float* __restrict__ dln_w, float* __restrict__ dln_b, AttnGeom g, float eps, const T* __restrict__ y0) {
+    static_assert(!(PRE && LN), "PRE carries the gradient through the norm in FRONT of a block without norm1");
     typedef AbSmem<T, C> S;
     typedef AbBwdScratch<T, NB> SC;
     constexpr int KS = C / 16, HEADS = C / 32, NCB = C / 32, LP = 32 * NB;
     // per wave: P / dS scratch
     constexpr int DLN = 0;
-    constexpr bool STASH = LN && sizeof(T) == 2;                       // raw rows for the LayerNorm backward: lane-private LDS slots (see the forward)
+    constexpr bool STASH = (LN || PRE) && sizeof(T) == 2;              // raw rows for the LayerNorm backward: lane-private LDS slots (see the forward)
     constexpr int STASH_B = STASH ? NB * KS * 64 * 16 : 0;
-    constexpr int OFF_STASH = S::OFF_S + WPB * (SC::BYTES + DLN) + (LN ? WPB * 2 * C * 4 : 0);
+    constexpr int OFF_STASH = S::OFF_S + WPB * (SC::BYTES + DLN) + ((LN || PRE) ? WPB * 2 * C * 4 : 0);
     __shared__ __attribute__((aligned(16))) char smem[OFF_STASH + WPB * STASH_B];
     char* const Wq_l = smem;
     char* const Wp_l = smem + S::OFF_P;
@@ -428,7 +435,7 @@ attn_block_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dxmid, T* _
     ab_stage_weights<T, C, false>(Wq_l, Wqkv, 3 * C, tid, 64 * WPB);
     ab_stage_weights<T, C, false>(Wp_l, WpgT, C, tid, 64 * WPB);
     for (int i = tid; i < C; i += 64 * WPB) {
-        kst[S::K_LNW + i] = LN ? ln_w[i] : 1.f;
+        kst[S::K_LNW + i] = (LN || PRE) ? ln_w[i] : 1.f;
         kst[S::K_LNB + i] = LN ? ln_b[i] : 0.f;
     }
     for (int i = tid; i < 3 * C; i += 64 * WPB) kst[S::K_BQKV + i] = bqkv[i];
@@ -445,11 +452,39 @@ attn_block_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dxmid, T* _
         float mean[NB], rstd[NB];
         ab_load_rows<T, C, NB>(uf, x, pt.tok, pt.valid, half);
         ab_load_rows<T, C, NB>(df, dxmid, pt.tok, pt.valid, half);
-        if (STASH) {
+        if (STASH && !PRE) {
 #pragma unroll
             for (int b = 0; b < NB; b++)
 #pragma unroll
                 for (int ks = 0; ks < KS; ks++) *reinterpret_cast<frag_t<T>*>(stash + (b * KS + ks) * 1024) = uf[b][ks];
+        }
+        if (PRE) {
+            // the rows of the norm IN FRONT of the block: requested here, beside the x / dxmid rows (at the end of the partition the
+            // wave has nothing else in flight to hide an HBM round trip behind: +0.47 ms measured), statistics now (lane = row:
+            // in-lane sums + one exchange), the rows themselves parked in the lane-private LDS stash until the last step
+            frag_t<T> yf[NB][KS];
+            ab_load_rows<T, C, NB>(yf, y0, pt.tok, pt.valid, half);
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+                float sm = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++)
+#pragma unroll
+                    for (int e = 0; e < 8; e++) sm += (float)yf[b][ks][e];
+                sm += __shfl_xor(sm, 32);
+                mean[b] = sm / (float)C;
+                float q = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++)
+#pragma unroll
+                    for (int e = 0; e < 8; e++) { const float dd = (float)yf[b][ks][e] - mean[b]; q += dd * dd; }
+                q += __shfl_xor(q, 32);
+                rstd[b] = 1.0f / sqrtf(q / (float)C + eps);
+                if (STASH) {
+#pragma unroll
+                    for (int ks = 0; ks < KS; ks++) *reinterpret_cast<frag_t<T>*>(stash + (b * KS + ks) * 1024) = yf[b][ks];
+                }
+            }
         }
         if (LN) {       // the raw rows come back from the LDS stash (fp32: L2) for the LayerNorm backward at the end: 32 registers less across the heads
             ab_layernorm<T, C, NB>(uf, uf, kst + S::K_LNW, kst + S::K_LNB, pt.valid, half, eps, mean, rstd);
@@ -598,15 +633,21 @@ attn_block_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dxmid, T* _
 #pragma unroll
                     for (int e = 0; e < 8; e++) d8[2 * cb + m][e] = pt.valid[b] ? r8[m][e] : 0.f;
             }
-            if (LN) {
+            if (LN || PRE) {
                 float gsum = 0.f, gxsum = 0.f;
                 float xh[KS][8];
+                if (PRE) {             // the cotangent that enters the norm: g = dxmid + du
+#pragma unroll
+                    for (int ks = 0; ks < KS; ks++)
+#pragma unroll
+                        for (int e = 0; e < 8; e++) d8[ks][e] += (float)df[b][ks][e];
+                }
 #pragma unroll
                 for (int ks = 0; ks < KS; ks++) {
                     float w[8];
                     load_cols<8>(kst + S::K_LNW, 16 * ks + 8 * half, w);
                     const frag_t<T> xr = STASH ? *reinterpret_cast<const frag_t<T>*>(stash + (b * KS + ks) * 1024)
-                                               : frag_load<T>(x + (size_t)pt.tok[b] * C + (2 * ks + half) * 8);
+                                               : frag_load<T>((PRE ? y0 : x) + (size_t)pt.tok[b] * C + (2 * ks + half) * 8);
 #pragma unroll
                     for (int e = 0; e < 8; e++) {
                         xh[ks][e] = pt.valid[b] ? ((float)xr[e] - mean[b]) * rstd[b] : 0.f;
@@ -640,7 +681,7 @@ attn_block_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dxmid, T* _
                     load_cols<8>(kst + S::K_LNW, 16 * ks + 8 * half, w);
 #pragma unroll
                     for (int e = 0; e < 8; e++)
-                        o[e] = (float)df[b][ks][e] + rstd[b] * (d8[ks][e] * w[e] - m1 - xh[ks][e] * m2);
+                        o[e] = (PRE ? 0.f : (float)df[b][ks][e]) + rstd[b] * (d8[ks][e] * w[e] - m1 - xh[ks][e] * m2);
                     if (pt.valid[b]) frag_store<T>(dx + (size_t)pt.tok[b] * C + (2 * ks + half) * 8, frag_from_float<T>(o));
                 }
             } else {
@@ -654,7 +695,7 @@ attn_block_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dxmid, T* _
             }
         }
     }
-    if (LN) {
+    if (LN || PRE) {
         // fold the two halves and the waves: one atomic per channel per workgroup
         float* const red = reinterpret_cast<float*>(smem + S::OFF_S + WPB * (SC::BYTES + DLN));      // [WPB][dln_w C | dln_b C]
 #pragma unroll

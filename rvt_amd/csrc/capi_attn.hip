@@ -119,7 +119,16 @@ static void launch_ab_bwd(const void* x, const void* dxmid, void* dx, void* dqkv
     constexpr int WPB = AbWaves<T, NB>::V;
     auto k = attn_block_bwd_kernel<T, 64, NB, LN, WPB>;
     hipLaunchKernelGGL(k, dim3(ab_grid(k, 64 * WPB, g.F * g.P, WPB)), dim3(64 * WPB), 0, st, (const T*)x, (const T*)dxmid, (T*)dx,
-                       (T*)dqkv, (T*)u_out, ln_w, ln_b, (const T*)wqkv, bqkv, (const T*)wpg_t, dln_w, dln_b, g, eps);
+                       (T*)dqkv, (T*)u_out, ln_w, ln_b, (const T*)wqkv, bqkv, (const T*)wpg_t, dln_w, dln_b, g, eps, (const T*)nullptr);
+}
+template <class T>
+static void launch_ab_bwd_pre(const void* x, const void* y0, const void* dxmid, void* dy0, void* dqkv, const float* ln_w, const void* wqkv,
+                              const float* bqkv, const void* wpg_t, float* dln_w, float* dln_b, const AttnGeom& g, float eps, hipStream_t st) {
+    constexpr int WPB = AbWaves<T, 2>::V;
+    auto k = attn_block_bwd_kernel<T, 64, 2, false, WPB, true>;
+    hipLaunchKernelGGL(k, dim3(ab_grid(k, 64 * WPB, g.F * g.P, WPB)), dim3(64 * WPB), 0, st, (const T*)x, (const T*)dxmid, (T*)dy0,
+                       (T*)dqkv, (T*)nullptr, ln_w, (const float*)nullptr, (const T*)wqkv, bqkv, (const T*)wpg_t, dln_w, dln_b, g, eps,
+                       (const T*)y0);
 }
 extern "C" {
 int rvt_attn_block_fwd(const void* x, void* xmid, void* a_out, const float* ln_w, const float* ln_b, const void* wqkv,
@@ -161,6 +170,18 @@ int rvt_attn_block_bwd(const void* x, const void* dxmid, void* dx, void* dqkv, v
     DISPATCH_DTYPE(dtype, { if (ln_w) RVT_AB_BWD(2, true); else RVT_AB_BWD(2, false); });
 #undef RVT_AB_BWD
     return check_launch("attn_block_bwd");
+}
+
+int rvt_attn_block_bwd_preln(const void* x, const void* y0, const void* dxmid, void* dy0, void* dqkv, const float* ln_w,
+                             const void* wqkv, const float* bqkv, const void* wpg_t, float* dln_w, float* dln_b, int dtype, int F,
+                             int H, int W, int C, int dim_head, int ph, int pw, int window, float eps, void* stream) {
+    RVT_CHECK(rvt_attn_block_supported(dtype, C, dim_head, ph * pw) && ph * pw <= 64,
+              "attn_block_bwd_preln: not built for dtype=%d C=%d dim_head=%d L=%d", dtype, C, dim_head, ph * pw);
+    RVT_CHECK(y0 != nullptr && ln_w != nullptr && dln_w != nullptr && dln_b != nullptr, "attn_block_bwd_preln: y0, ln_w, dln_w, dln_b are required");
+    AttnGeom g;
+    if (make_attn_geom(g, F, H, W, C, dim_head, ph, pw, window)) return 1;
+    DISPATCH_DTYPE(dtype, (launch_ab_bwd_pre<T>(x, y0, dxmid, dy0, dqkv, ln_w, wqkv, bqkv, wpg_t, dln_w, dln_b, g, eps, (hipStream_t)stream)));
+    return check_launch("attn_block_bwd_preln");
 }
 
 }  // extern "C"

@@ -207,8 +207,8 @@ int rvt_stacked_histogram(const long long* x, const long long* y, const long lon
 int rvt_pack_table(const void* descs, int n_desc, int total_blocks, int dtype, void* stream) {
     RVT_CHECK(n_desc >= 1 && total_blocks >= 1 && descs != nullptr, "pack_table: empty table");
     hipStream_t st = (hipStream_t)stream;
-    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((pack_table_kernel<T>), dim3(total_blocks), dim3(256), 0, st,
-                                             (const PackDesc*)descs, n_desc));
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((pack_table_kernel<T>), dim3((total_blocks + PACK_LBPW - 1) / PACK_LBPW), dim3(256), 0, st,
+                                             (const PackDesc*)descs, n_desc, (unsigned)total_blocks));
     return check_launch("pack_table");
 }
 

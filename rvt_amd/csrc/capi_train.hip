@@ -207,6 +207,7 @@ int rvt_stage_seq_bwd(const RvtStageDesc* dp, const RvtStageTrain* tp, const voi
         RVT_TRY(rvt_lstm_wgrad(dz, x_last, HallB, t.d_lstm_w, t.d_lstm_b, ws_wgrad, dt, M, C, stream));
 
     // ---- attention blocks, reversed ----
+    bool preln_done = false;                                 // the first block's launch already wrote dy0 (rvt_attn_block_bwd_preln)
     int ri = 0;                                              // ring[ri] = the cotangent of the current block's output
     for (int bi = nb - 1; bi >= 0; bi--) {
         const RvtBlockWeights& bw = d.blocks[bi];
@@ -243,8 +244,15 @@ int rvt_stage_seq_bwd(const RvtStageDesc* dp, const RvtStageTrain* tp, const voi
         RVT_TRY(rvt_linear_wgrad(dxmid, sv.a, tb.d_S1, tb.d_cs1, ws_wgrad, dt, M, C, C, 0, stream));
         if (t.attn_block) {
             void* const u_out = bw.n1_w != nullptr ? t1 : nullptr;
-            RVT_TRY(rvt_attn_block_bwd(sv.xin, dxmid, dxi, dqkv, u_out, bw.n1_w, bw.n1_b, bw.qkv_w, bw.qkv_b, tb.proj_wt, tb.d_n1_w, tb.d_n1_b, dt, F, H, W,
-                                       C, d.dim_head, d.ph, d.pw, window, d.eps, stream));
+            if (t.attn_preln && bi == 0 && bw.n1_w == nullptr) {
+                // the stage's first block: the same launch carries the gradient through the down-sampling norm in front of it
+                RVT_TRY(rvt_attn_block_bwd_preln(sv.xin, t.y0, dxmid, dy0, dqkv, d.ln_w, bw.qkv_w, bw.qkv_b, tb.proj_wt, t.d_ln_w, t.d_ln_b, dt, F, H, W,
+                                                 C, d.dim_head, d.ph, d.pw, window, d.eps, stream));
+                preln_done = true;
+            } else {
+                RVT_TRY(rvt_attn_block_bwd(sv.xin, dxmid, dxi, dqkv, u_out, bw.n1_w, bw.n1_b, bw.qkv_w, bw.qkv_b, tb.proj_wt, tb.d_n1_w, tb.d_n1_b, dt, F, H, W,
+                                           C, d.dim_head, d.ph, d.pw, window, d.eps, stream));
+            }
             RVT_TRY(rvt_linear_wgrad(dqkv, u_out != nullptr ? u_out : sv.xin, tb.d_qkv_w, tb.d_qkv_b, ws_wgrad, dt, M, 3 * C, C, 0, stream));
         } else {
             RVT_TRY(rvt_linear_dgrad(dxmid, tb.proj_wt, nullptr, nullptr, nullptr, t1, dt, M, C, C, stream));          // da
@@ -262,7 +270,7 @@ int rvt_stage_seq_bwd(const RvtStageDesc* dp, const RvtStageTrain* tp, const voi
         ri = (ri + 2) % 3;
     }
     // ---- down-sampling LayerNorm + conv ----
-    RVT_TRY(rvt_layernorm_bwd(t.y0, d.ln_w, ring[ri], nullptr, dy0, t.d_ln_w, t.d_ln_b, dt, M, C, d.eps, stream));
+    if (!preln_done) RVT_TRY(rvt_layernorm_bwd(t.y0, d.ln_w, ring[ri], nullptr, dy0, t.d_ln_w, t.d_ln_b, dt, M, C, d.eps, stream));
     if (d.inp_u8) {
         RVT_TRY(rvt_stem_wgrad(inp, dy0, t.d_raw_conv, ws_stem, dt, F, d.Cin, d.cin_pad, d.h_raw, d.w_raw, d.H_in, d.W_in, stream));
     } else {

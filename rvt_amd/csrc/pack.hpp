@@ -34,23 +34,45 @@ struct PackDesc {             // 96 bytes; mirrored by rvt_amd/weights.py (numpy
 };
 static_assert(sizeof(PackDesc) == 96, "PackDesc layout is part of the C ABI");
 
+// one "logical block" = 1024 consecutive destination elements of one descriptor (block0 counts them): the unit the host tables are
+// built in.  A workgroup serves PACK_LBPW consecutive logical blocks: it finds the descriptor of its first one by COUNTING the
+// descriptors that start at or before it (every thread looks at its share: one round of loads) and walks on from there - a
+// launch over the 18.5 M parameters of RVT-Base is 30 k logical blocks, and one workgroup per logical block spent its time
+// on the descriptor look-up and the launch of the workgroup itself (0.21 ms per step; 0.07 ms for the plain copies alone).
+constexpr int PACK_LBPW = 8;
+
 template <class T>
-__global__ void __launch_bounds__(256)
-pack_table_kernel(const PackDesc* __restrict__ descs, int nd) {
-    // which descriptor does this block serve?  (block0 is ascending; nd is a few hundred at most)
-    int lo = 0, hi = nd - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (descs[mid].block0 <= blockIdx.x) lo = mid; else hi = mid - 1;
+__device__ __forceinline__ void pack_logical_block(const PackDesc& d, unsigned lbi, float (*tile)[33]) {
+    // (32-bit element indices: a packed weight has far fewer than 2^32 elements, and the index arithmetic below is all divisions)
+    const unsigned i0 = (lbi * 256u + threadIdx.x) * 4u, n32 = (unsigned)d.n;
+    if (d.kind == PACK_TRANSPOSE && ((d.d[0] | d.d[1]) & 31) == 0) {
+        // logical block = one 32 x 32 tile (r fastest), through LDS: 128-byte runs on the source side AND on the destination side
+        // (every weight of the backbone takes this path; the two forms below serve odd shapes).  d is uniform: every thread is here.
+        const unsigned R = (unsigned)d.d[0], K = (unsigned)d.d[1], ntr = R >> 5;
+        const unsigned tk = lbi / ntr, tr = lbi - tk * ntr, c = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+        __syncthreads();                                   // (the previous logical block's reads of the tile)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned row = 32 * tr + r0 + 8 * j;
+            float v = d.src[(size_t)row * K + 32 * tk + c];
+            if (d.scale) v *= d.scale[row];
+            tile[r0 + 8 * j][c] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned krow = r0 + 8 * j;
+            const size_t o = (size_t)(32 * tk + krow) * R + 32 * tr + c;
+            const float v = tile[c][krow];
+            if (d.out_f32) reinterpret_cast<float*>(d.dst)[o] = v;
+            else reinterpret_cast<T*>(d.dst)[o] = (T)v;
+        }
+        return;
     }
-    const PackDesc d = descs[lo];
-    // (32-bit element indices: a packed weight has far fewer than 2^32 elements, and the index arithmetic below is all divisions -
-    // as 64-bit divisions they were most of this kernel's time: 0.22 ms for the 18.5 M parameters of RVT-Base)
-    const unsigned i0 = ((blockIdx.x - d.block0) * 256u + threadIdx.x) * 4u, n32 = (unsigned)d.n;
     if (d.kind == PACK_TRANSPOSE && (d.d[1] & 3) == 0 && ((size_t)d.src & 15) == 0) {
         // a thread takes FOUR CONSECUTIVE k of one source row r (one 16-byte read) and writes them to four destination rows; the
-        // threads of a wave walk r, so every one of the four stores is a contiguous run (the element-order form read the source
-        // with stride K: one 4-byte word per fetched line - 0.21 ms for the stage-4 weights of RVT-Base)
+        // threads of a wave walk r, so every one of the four stores is a contiguous run (the element-order form reads the source
+        // with stride K: one 4-byte word per fetched line)
         const unsigned R = (unsigned)d.d[0], K = (unsigned)d.d[1], q = i0 >> 2;
         if (i0 >= n32) return;
         const unsigned kq = q / R, r = q - kq * R;
@@ -61,6 +83,34 @@ pack_table_kernel(const PackDesc* __restrict__ descs, int nd) {
             const size_t o = (size_t)(4 * kq + u) * R + r;
             if (d.out_f32) reinterpret_cast<float*>(d.dst)[o] = v4[u];
             else reinterpret_cast<T*>(d.dst)[o] = (T)v4[u];
+        }
+        return;
+    }
+    if (d.kind == PACK_COPY && ((size_t)d.src & 15) == 0 && ((size_t)d.dst & 15) == 0 && i0 + 4 <= n32) {
+        const f32x4 v4 = *reinterpret_cast<const f32x4*>(d.src + i0);
+        if (d.out_f32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(d.dst) + i0) = v4;
+        else {
+            typedef __attribute__((ext_vector_type(4))) T vec4;
+            vec4 o;
+#pragma unroll
+            for (int u = 0; u < 4; u++) o[u] = (T)v4[u];
+            *reinterpret_cast<vec4*>(reinterpret_cast<T*>(d.dst) + i0) = o;
+        }
+        return;
+    }
+    if (d.kind == PACK_LSTM_ROWS && (d.d[1] & 3) == 0 && ((size_t)d.src & 15) == 0 && ((size_t)d.dst & 15) == 0 && i0 < n32) {
+        // four consecutive k of one (interleaved) row: one 16-byte read, one store
+        const unsigned C = (unsigned)d.d[0], K = (unsigned)d.d[1];
+        const unsigned np = i0 / K, kc = i0 - np * K;
+        const unsigned c = (np >> 5) * 8 + (np & 7), gate = (np & 31) >> 3;
+        const f32x4 v4 = *reinterpret_cast<const f32x4*>(d.src + (size_t)(gate * C + c) * K + kc);
+        if (d.out_f32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(d.dst) + i0) = v4;
+        else {
+            typedef __attribute__((ext_vector_type(4))) T vec4;
+            vec4 o;
+#pragma unroll
+            for (int u = 0; u < 4; u++) o[u] = (T)v4[u];
+            *reinterpret_cast<vec4*>(reinterpret_cast<T*>(d.dst) + i0) = o;
         }
         return;
     }
@@ -128,6 +178,32 @@ pack_table_kernel(const PackDesc* __restrict__ descs, int nd) {
         }
         if (d.out_f32) reinterpret_cast<float*>(d.dst)[o] = v;
         else reinterpret_cast<T*>(d.dst)[o] = (T)v;
+    }
+}
+
+template <class T>
+__global__ void __launch_bounds__(256)
+pack_table_kernel(const PackDesc* __restrict__ descs, int nd, unsigned total_blocks) {
+    const unsigned lb0 = blockIdx.x * (unsigned)PACK_LBPW;
+    const unsigned lb1 = lb0 + PACK_LBPW < total_blocks ? lb0 + PACK_LBPW : total_blocks;
+    __shared__ int s_cnt;
+    __shared__ float tile[32][33];
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    int cnt = 0;
+    for (int j = threadIdx.x; j < nd; j += 256) cnt += descs[j].block0 <= lb0 ? 1 : 0;       // (block0 is ascending, descs[0].block0 = 0)
+    if (cnt) atomicAdd(&s_cnt, cnt);
+    __syncthreads();
+    int lo = wave_uniform(s_cnt - 1);
+    PackDesc d = descs[lo];
+    unsigned next0 = lo + 1 < nd ? descs[lo + 1].block0 : 0xffffffffu;
+    for (unsigned lb = lb0; lb < lb1; lb++) {
+        while (lb >= next0) {
+            lo++;
+            d = descs[lo];
+            next0 = lo + 1 < nd ? descs[lo + 1].block0 : 0xffffffffu;
+        }
+        pack_logical_block<T>(d, lb - d.block0, tile);
     }
 }
 

@@ -392,6 +392,19 @@ def attn_block_bwd(x: Tensor, dxmid: Tensor, ln_w: Optional[Tensor], ln_b: Optio
     return dx, dqkv, u
 
 
+def attn_block_bwd_preln(x: Tensor, y0: Tensor, dxmid: Tensor, ln_w: Tensor, wqkv: Tensor, bqkv: Tensor, wpg_t: Tensor, dln_w: Tensor,
+                         dln_b: Tensor, F_: int, H: int, W: int, C: int, dh: int, ph: int, pw: int, window: bool, eps: float):
+    """Backward of the fused attention half of a stage's FIRST block (no norm1) carried through the LayerNorm in front of it,
+    x = LN(y0) (the down-sampling norm, maxvit.py:177): returns (dy0, dqkv); dln_w / dln_b of THAT norm are accumulated.
+    Same dqkv as attn_block_bwd(ln_w=None); dy0 = layernorm_bwd(y0, ln_w, dx) of its dx, in one launch."""
+    dy0 = torch.empty_like(x)
+    dqkv = torch.empty((*x.shape[:-1], 3 * C), dtype=x.dtype, device=x.device)
+    L.call('rvt_attn_block_bwd_preln', L.ptr(x), L.ptr(y0), L.ptr(dxmid), L.ptr(dy0), L.ptr(dqkv), L.ptr(ln_w), L.ptr(wqkv), L.ptr(bqkv),
+           L.ptr(wpg_t), L.ptr(dln_w), L.ptr(dln_b), L.dtype_code(x.dtype), F_, H, W, C, dh, ph, pw, int(window), float(eps),
+           L.stream_of(x))
+    return dy0, dqkv
+
+
 def lstm_fwd(x: Tensor, h_prev: Tensor, c_prev: Tensor, w_perm: Tensor, b_perm: Tensor, h_out: Tensor, c_out: Tensor,
              gates: Optional[Tensor]) -> None:
     C = x.shape[-1]

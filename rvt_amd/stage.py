@@ -432,6 +432,7 @@ def stage_seq_backward(sw: StageWeights, g: StageGeom, sv: StageSaved, dH: Optio
     del dz
 
     # ---- attention blocks, reversed ---------------------------------------------------------------------
+    dy0_fused = None
     bi_flat = len(sv.blocks)
     for pi in range(len(sw.blocks) - 1, -1, -1):
         for which in (1, 0):
@@ -493,10 +494,20 @@ def stage_seq_backward(sw: StageWeights, g: StageGeom, sv: StageSaved, dH: Optio
             if s['qkv'] is None:
                 # fused: proj / attention / qkv input gradients and the norm1 backward in one launch (from the block input)
                 has_n1 = bw['n1_w'] is not None
-                dx, dqkv, u = ops.attn_block_bwd(s['xin'], dxmid, bw['n1_w'], bw['n1_b'], bw['qkv_w'], bw['qkv_b'], bw['proj_wt'],
-                                                 G(bp + 'norm1.weight') if has_n1 else None,
-                                                 G(bp + 'norm1.bias') if has_n1 else None, F_, H, W, C, g.dim_head, g.ph, g.pw,
-                                                 window, g.eps)
+                if bi_flat == 0 and not has_n1 and sv.mask is None and tuning.get('route_attn_preln') != 0:
+                    # the stage's first block: its input is the down-sampling norm's output, and nothing sits between them -
+                    # the same launch carries the gradient through that norm (dy0 instead of dx)
+                    dy0_fused, dqkv = ops.attn_block_bwd_preln(s['xin'], sv.y0, dxmid, sw.ln_w, bw['qkv_w'], bw['qkv_b'], bw['proj_wt'],
+                                                               G(pre + 'downsample_cf2cl.norm.weight'),
+                                                               G(pre + 'downsample_cf2cl.norm.bias'), F_, H, W, C, g.dim_head,
+                                                               g.ph, g.pw, window, g.eps)
+                    dx, u = None, None
+                else:
+                    dy0_fused = None
+                    dx, dqkv, u = ops.attn_block_bwd(s['xin'], dxmid, bw['n1_w'], bw['n1_b'], bw['qkv_w'], bw['qkv_b'], bw['proj_wt'],
+                                                     G(bp + 'norm1.weight') if has_n1 else None,
+                                                     G(bp + 'norm1.bias') if has_n1 else None, F_, H, W, C, g.dim_head, g.ph, g.pw,
+                                                     window, g.eps)
                 u = s['xin'] if u is None else u
                 def qkv_wgrad_fused_fn(dqkv=dqkv, u=u, bp=bp):
                     ops.linear_wgrad(dqkv, u, G(bp + 'self_attn.qkv.weight'), colsum_out=G(bp + 'self_attn.qkv.bias'))
@@ -523,8 +534,11 @@ def stage_seq_backward(sw: StageWeights, g: StageGeom, sv: StageSaved, dH: Optio
     # ---- token mask, down-sampling LayerNorm + conv ---------------------------------------------------------
     if sv.mask is not None:
         ops.token_mask_bwd(dx, sv.mask, G(pre + 'mask_token').view(C))            # also zeroes dx on masked tokens
-    dy0 = ops.layernorm_bwd(sv.y0, sw.ln_w, dx, None, G(pre + 'downsample_cf2cl.norm.weight'),
-                            G(pre + 'downsample_cf2cl.norm.bias'), g.eps)
+    if dy0_fused is not None:
+        dy0 = dy0_fused                                                           # (rvt_attn_block_bwd_preln of the first block)
+    else:
+        dy0 = ops.layernorm_bwd(sv.y0, sw.ln_w, dx, None, G(pre + 'downsample_cf2cl.norm.weight'),
+                                G(pre + 'downsample_cf2cl.norm.bias'), g.eps)
     def conv_wgrad_fn(dy0=dy0):
         if sv.inp.dtype == torch.uint8:
             ops.stem_wgrad(sv.inp, dy0, G('raw/conv'), g.H_in, g.W_in)

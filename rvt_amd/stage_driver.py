@@ -122,7 +122,7 @@ class RvtBlockTrain(ctypes.Structure):
 
 class RvtStageTrain(ctypes.Structure):
     _fields_ = [('struct_bytes', _i)] + [(n, _i) for n in ('attn_block', 'ln_linear', 'mlp_route', 'mlp_bwd_both', 'dgrad_ln_qkv',
-                                                          'dgrad_ln_fc1', 'lstm_route', 'lstm_scan_wgrad', 'conv_dgrad4')] + \
+                                                          'dgrad_ln_fc1', 'lstm_route', 'lstm_scan_wgrad', 'conv_dgrad4', 'attn_preln')] + \
                [('saved', ctypes.POINTER(RvtBlockSaved)), ('tb', ctypes.POINTER(RvtBlockTrain))] + \
                [(n, _vp) for n in ('y0', 'x0', 'Hall', 'c_last', 'Csave', 'gates', 'Call', 'c0_saved', 'lstm_wp3', 'lstm_wtp3', 'lstm_wt',
                                    'conv_wd4', 'conv_wd', 'd_lstm_w', 'd_lstm_b', 'd_ln_w', 'd_ln_b', 'd_raw_conv')]
@@ -178,6 +178,8 @@ def train_routes(sw, g, dt, T: int, B: int, token_mask) -> Optional[dict]:
     r['lstm_scan_wgrad'] = int(r['lstm_route'] == 1 and tuning.get('route_lstm_scan_wgrad') != 0 and ops.lstm_scan_wgrad_supported(dt, C, Ms))
     r['conv_dgrad4'] = int(sw.conv_wd4 is not None and tuning.get('route_conv_dgrad4') != 0 and
                            ops.conv_dgrad4_supported(dt, g.H_in, g.W_in, g.Cin, C, g.k, g.stride, g.pad, T * B))
+    # (the first block of a stage never has a norm1: maxvit_rnn.py:153 `skip_first_norm`; no token mask on this route)
+    r['attn_preln'] = int(r['attn_block'] and tuning.get('route_attn_preln') != 0 and sw.blocks[0][0]['n1_w'] is None)
     return r
 
 

@@ -402,6 +402,55 @@ def test_attn_block_fused(backend, dt, window, ln, case):
 
 
 @pytest.mark.parametrize('dt', DTYPES)
+@pytest.mark.parametrize('window', [True, False])
+@pytest.mark.parametrize('case', [c for c in AB_CASES if c[3] * c[4] <= 64])
+def test_attn_block_bwd_preln(backend, dt, window, case):
+    """rvt_attn_block_bwd_preln (a stage's first block: the backward carried through the down-sampling LayerNorm in front of it,
+    maxvit.py:177 + :268) against fp64 autograd of LN -> attention half, and against the two launches it replaces
+    (rvt_attn_block_bwd without norm1 + rvt_layernorm_bwd): same dqkv bits."""
+    Fr, H, W, ph, pw = case
+    C, dh, eps = 64, 32, 1e-5
+    y0 = rnd((Fr, H, W, C), backend, dt, 1) * 1.5 + 0.25
+    dxm = rnd((Fr, H, W, C), backend, dt, 2)
+    ln_w = 1.0 + 0.3 * rnd((C,), backend, torch.float32, 3)
+    ln_b = 0.2 * rnd((C,), backend, torch.float32, 4)
+    wqkv32 = rnd((3 * C, C), backend, torch.float32, 5, C ** -0.5)
+    bqkv = 0.3 * rnd((3 * C,), backend, torch.float32, 6)
+    wp32 = rnd((C, C), backend, torch.float32, 7, C ** -0.5)
+    bp = 0.3 * rnd((C,), backend, torch.float32, 8)
+    gamma = 0.5 + rnd((C,), backend, torch.float32, 9).abs()
+    wqkv, wp = wqkv32.to(dt), wp32.to(dt)
+    wpg_t = (wp32 * gamma[:, None]).t().contiguous().to(dt)
+    x = ops.layernorm_fwd(y0, ln_w, ln_b, eps)                        # the block input as the forward stored it
+
+    yr = f64(y0).requires_grad_(True)
+    lw, lb = f64(ln_w).requires_grad_(True), f64(ln_b).requires_grad_(True)
+    # the kernels see the ROUNDED block input x; the norm's own backward sees y0: x_r = x + (LN(y0) - LN(y0).detach()) keeps both
+    ln_r = F.layer_norm(yr, (C,), lw, lb, eps)
+    x_r = f64(x) + (ln_r - ln_r.detach())
+    qkv_r = x_r @ f64(wqkv).t() + f64(bqkv)
+    qkv_r.retain_grad()
+    a_r = ref_attention(qkv_r, Fr, H, W, C, dh, ph, pw, window)
+    xmid_r = x_r + f64(gamma) * (a_r @ (f64(wpg_t).t() / f64(gamma)[:, None]).t() + f64(bp))
+    xmid_r.backward(f64(dxm))
+
+    z = lambda: torch.zeros(C, dtype=torch.float32, device=backend)
+    dlw, dlb, dlw2, dlb2 = z(), z(), z(), z()
+    dy0, dqkv = ops.attn_block_bwd_preln(x, y0, dxm, ln_w, wqkv, bqkv, wpg_t, dlw, dlb, Fr, H, W, C, dh, ph, pw, window, eps)
+    close(dqkv, qkv_r.grad, dt, 'attn_block_preln dqkv', f32_mult=2.0)
+    close(dy0, yr.grad, dt, 'attn_block_preln dy0', f32_mult=2.0)
+    close(dlw, lw.grad, dt, 'attn_block_preln dln_w', f32_mult=4.0)
+    close(dlb, lb.grad, dt, 'attn_block_preln dln_b', f32_mult=4.0)
+    # the two launches it replaces (dx rounded to the storage type in between)
+    dx, dqkv2, u = ops.attn_block_bwd(x, dxm, None, None, wqkv, bqkv, wpg_t, None, None, Fr, H, W, C, dh, ph, pw, window, eps)
+    dy0_2 = ops.layernorm_bwd(y0, ln_w, dx, None, dlw2, dlb2, eps)
+    assert u is None and torch.equal(dqkv, dqkv2)
+    close(dy0, dy0_2.double(), dt, 'attn_block_preln dy0 vs two launches', f32_mult=2.0)
+    close(dlw, dlw2.double(), dt, 'attn_block_preln dln_w vs two launches', f32_mult=4.0)
+    close(dlb, dlb2.double(), dt, 'attn_block_preln dln_b vs two launches', f32_mult=4.0)
+
+
+@pytest.mark.parametrize('dt', DTYPES)
 @pytest.mark.parametrize('M,C', [(150, 16), (70, 72)])
 def test_lstm_cell(backend, dt, M, C):
     x, h = rnd((M, C), backend, dt, 1), rnd((M, C), backend, dt, 2)
