@@ -172,13 +172,15 @@ template <class T, int MODE> static int mlp_bwd_fused_grid(int M) {
 static void mlp_fold_partials(const float* ws, int grid, int C, float* dw1, float* db1, float* s2, float* cs2, hipStream_t st) {
     const size_t wc = (size_t)4 * C * C;
     const float* p = ws;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(reduce_grid(wc)), dim3(256), 0, st, p, dw1, grid, wc, 0);
+    FoldJobs fj;                               // (one launch for the four outputs: they were four)
+    fj.add(p, dw1, grid, wc, wc);
     p += (size_t)grid * wc;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(reduce_grid(wc)), dim3(256), 0, st, p, s2, grid, wc, 0);
+    fj.add(p, s2, grid, wc, wc);
     p += (size_t)grid * wc;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(reduce_grid((size_t)4 * C)), dim3(256), 0, st, p, db1, 2 * grid, (size_t)4 * C, 0);
+    fj.add(p, db1, 2 * grid, (size_t)4 * C, (size_t)4 * C);
     p += (size_t)2 * grid * 4 * C;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(reduce_grid((size_t)C)), dim3(256), 0, st, p, cs2, grid, (size_t)C, 0);
+    fj.add(p, cs2, grid, (size_t)C, (size_t)C);
+    launch_fold_jobs(fj, st);
 }
 // tile streams of mlps_bwd_wgrad_kernel: two workgroups (hidden halves) per stream, one workgroup per CU
 static int msw_streams(int M) {

@@ -53,11 +53,10 @@ static void launch_lstm_scan_bwd(const void* x_all, const void* Hall, const void
         // fold the per-workgroup partial records: the [4C][2C] weight block and the NWM bias rows are column sums over records
         constexpr int NWM = NW / (C / 32);
         const size_t rec = (size_t)4 * C * 2 * C + (size_t)NWM * 4 * C;
-        hipLaunchKernelGGL(strided_reduce_kernel, dim3(reduce_grid((size_t)4 * C * 2 * C)), dim3(256), 0, st, (const float*)ws, dw,
-                           grid, rec, (size_t)4 * C * 2 * C);
-        for (int m = 0; m < NWM; m++)
-            hipLaunchKernelGGL(strided_reduce_kernel, dim3(reduce_grid((size_t)4 * C)), dim3(256), 0, st,
-                               (const float*)(ws + (size_t)4 * C * 2 * C + (size_t)m * 4 * C), db, grid, rec, (size_t)4 * C);
+        FoldJobs fj;
+        fj.add((const float*)ws, dw, grid, rec, (size_t)4 * C * 2 * C);
+        fj.add((const float*)(ws + (size_t)4 * C * 2 * C), db, grid, rec, (size_t)4 * C, 0, NWM, (size_t)4 * C);     // NWM bias rows per record -> one output
+        launch_fold_jobs(fj, st);
     }
 }
 extern "C" {
@@ -129,10 +128,10 @@ int rvt_lstm_scan_bwd(const void* x_all, const void* Hall, const void* Csave, co
             hipLaunchKernelGGL(k, dim3(grid), dim3(512), 0, st, (const bf16*)x_all, (const bf16*)Hall, (const bf16*)Csave, c0,
                                (const bf16*)dH, dc_last, (const bf16*)w, bias, (bf16*)dx_all, (bf16*)dh0, dc0, ws, M, T_steps);
             const size_t wn = (size_t)4 * C * 2 * C;
-            hipLaunchKernelGGL(strided_reduce_kernel, dim3(reduce_grid(wn)), dim3(256), 0, st, (const float*)ws, dw, grid,
-                               Scan2BwdSmem::REC, wn);
-            hipLaunchKernelGGL(strided_reduce_kernel, dim3(reduce_grid((size_t)4 * C)), dim3(256), 0, st, (const float*)(ws + wn), db,
-                               grid, Scan2BwdSmem::REC, (size_t)4 * C);
+            FoldJobs fj;
+            fj.add((const float*)ws, dw, grid, Scan2BwdSmem::REC, wn);
+            fj.add((const float*)(ws + wn), db, grid, Scan2BwdSmem::REC, (size_t)4 * C);
+            launch_fold_jobs(fj, st);
         }
         else if (C == 64) { if (wgrad) RVT_SCAN_BWD(bf16, 64, 4, true, true); else RVT_SCAN_BWD(bf16, 64, 4, true, false); }
         else RVT_SCAN_BWD(bf16, 128, 4, false, false);

@@ -572,10 +572,10 @@ inline int reduce_grid(size_t count) {
 }
 template <class Addr>
 __device__ __forceinline__ void reduce_rows_32x8(const float* __restrict__ ws, int nrec, size_t count, const Addr& addr,
-                                                  float* __restrict__ out, int t_cols) {
+                                                  float* __restrict__ out, int t_cols, unsigned bid, unsigned nblk) {
     __shared__ float red[8][33];
     const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
-    for (size_t i0 = (size_t)blockIdx.x * 32; i0 < count; i0 += (size_t)gridDim.x * 32) {
+    for (size_t i0 = (size_t)bid * 32; i0 < count; i0 += (size_t)nblk * 32) {
         const size_t i = i0 + e;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
         if (i < count) {
@@ -602,12 +602,46 @@ __device__ __forceinline__ void reduce_rows_32x8(const float* __restrict__ ws, i
 // (static: gemm.hpp is included by several translation units of the gfx950 build)
 static __global__ void __launch_bounds__(256)
 splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int nsplit, size_t count, int t_cols) {
-    reduce_rows_32x8(ws, nsplit, count, [count](int s) { return (size_t)s * count; }, out, t_cols);
+    reduce_rows_32x8(ws, nsplit, count, [count](int s) { return (size_t)s * count; }, out, t_cols, blockIdx.x, gridDim.x);
 }
 // out[i] += sum_s ws[s * stride + i], i < count  (per-workgroup partial RECORDS of `stride` floats each)
 static __global__ void __launch_bounds__(256)
 strided_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int nrec, size_t stride, size_t count) {
-    reduce_rows_32x8(ws, nrec, count, [stride](int s) { return (size_t)s * stride; }, out, 0);
+    reduce_rows_32x8(ws, nrec, count, [stride](int s) { return (size_t)s * stride; }, out, 0, blockIdx.x, gridDim.x);
+}
+// Several folds of ONE producer launch in one launch (round 6): a weight gradient and its bias column sums, the four outputs of
+// an MLP weight-gradient kernel, a ConvLSTM weight block and its bias rows.  73 fold launches per RVT-Base step were 0.8 ms, most
+// of it the launches themselves (a bias fold is one or two workgroups).  Job j owns the workgroups [block0, block0 + blocks).
+struct FoldJob { const float* ws; float* out; size_t count, stride, sub_stride; int nrec, t_cols, sub; unsigned block0, blocks; };
+struct FoldJobs {
+    static constexpr int MAX = 4;
+    FoldJob j[MAX]; int n; unsigned total;
+    FoldJobs() : n(0), total(0) {}
+    // out[i] += sum_s ws[s * stride + i], i < count; t_cols as splitk_reduce_kernel.  sub > 1: every record holds `sub` rows, sub_stride
+    // apart, that all fold into the SAME output (two jobs must never share an output: their workgroups run side by side).
+    void add(const float* ws, float* out, int nrec, size_t stride, size_t count, int t_cols = 0, int sub = 1, size_t sub_stride = 0) {
+        FoldJob& f = j[n++];
+        f.ws = ws; f.out = out; f.count = count; f.stride = stride; f.nrec = nrec * sub; f.t_cols = t_cols; f.sub = sub; f.sub_stride = sub_stride;
+        f.block0 = total; f.blocks = (unsigned)reduce_grid(count);
+        total += f.blocks;
+    }
+};
+static __global__ void __launch_bounds__(256)
+fold_jobs_kernel(FoldJobs jobs) {
+    int k = 0;
+#pragma unroll
+    for (int i = 1; i < FoldJobs::MAX; i++) k += (i < jobs.n && blockIdx.x >= jobs.j[i].block0) ? 1 : 0;
+    const FoldJob f = jobs.j[k];
+    const size_t stride = f.stride, sub_stride = f.sub_stride;
+    const int sub = f.sub;
+    if (sub == 1)
+        reduce_rows_32x8(f.ws, f.nrec, f.count, [stride](int s) { return (size_t)s * stride; }, f.out, f.t_cols, blockIdx.x - f.block0, f.blocks);
+    else
+        reduce_rows_32x8(f.ws, f.nrec, f.count, [stride, sub_stride, sub](int s) { return (size_t)(s / sub) * stride + (size_t)(s % sub) * sub_stride; },
+                         f.out, f.t_cols, blockIdx.x - f.block0, f.blocks);
+}
+inline void launch_fold_jobs(const FoldJobs& jobs, hipStream_t st) {
+    if (jobs.n > 0) hipLaunchKernelGGL(fold_jobs_kernel, dim3(jobs.total), dim3(256), 0, st, jobs);
 }
 
 // conv input-gradient of one parity class: row m = (frame, yy, xx) -> pixel (s*yy+py, s*xx+px); out = v + add

@@ -56,11 +56,10 @@ static void launch_wgrad(const ASrc& a, const BSrc& b, const BXf& bxf, float* ou
     float* ws_cs = colsum_out ? ws + (size_t)ns * tile_elems : nullptr;
     EpPartialStore ep{ws, Ng, tile_elems, 0};
     launch_gemm<T, BN, true>(a, XfNone(), b, bxf, ep, Mg, Ng, tokens, ks, st, ws_cs);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(reduce_grid(tile_elems)), dim3(256), 0, st, (const float*)ws, out, ns,
-                       tile_elems, transpose_out ? Ng : 0);
-    if (colsum_out)
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(reduce_grid((size_t)Mg)), dim3(256), 0, st, (const float*)ws_cs,
-                           colsum_out, ns, (size_t)Mg, 0);
+    FoldJobs fj;                               // the weight tile and the bias column sums: one fold launch
+    fj.add(ws, out, ns, tile_elems, tile_elems, transpose_out ? Ng : 0);
+    if (colsum_out) fj.add(ws_cs, colsum_out, ns, (size_t)Mg, (size_t)Mg);
+    launch_fold_jobs(fj, st);
 }
 
 #define DISPATCH_WGRAD_BN(N, ...)                                    \

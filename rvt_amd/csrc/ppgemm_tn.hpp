@@ -325,10 +325,10 @@ inline void launch_ppgemm_tn(const bf16* dY, int ldy, const bf16* X, const bf16*
     hipLaunchKernelGGL((ppgemm_tn_kernel<0>), dim3(8 * ((n_tiles * k_tiles * ns_eff + 7) / 8)), dim3(512), 0, st, dY, ldy, X, X2, kcut, ldx, ws, ws_cs, M, N,
                        K, n_tiles, k_tiles, tps, PPTnConv{});
     const size_t elems = (size_t)N * K;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(reduce_grid(elems)), dim3(256), 0, st, (const float*)ws, out, ns_eff, elems, N);
-    if (colsum_out) {
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(reduce_grid((size_t)N)), dim3(256), 0, st, (const float*)ws_cs, colsum_out, ns_eff * 8, (size_t)N, 0);
-    }
+    FoldJobs fj;                               // the weight tile and the bias column sums: one fold launch
+    fj.add(ws, out, ns_eff, elems, elems, N);
+    if (colsum_out) fj.add(ws_cs, colsum_out, ns_eff * 8, (size_t)N, (size_t)N);
+    launch_fold_jobs(fj, st);
 }
 
 // conv weight gradient dw[Cout][k*k*Cin] += dy^T im2col(in) on the same kernel (CONV): the shapes that fit
