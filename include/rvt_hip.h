@@ -88,8 +88,9 @@ typedef struct RvtTuning {
     int lstm_scan3_rb128;     /* ... at C = 128 */
     int route_stage_driver_train; /* 1 (round 6): the training forward / backward of a stage take rvt_stage_seq_train_fwd / rvt_stage_seq_bwd (one call per stage and direction) where covered; 0: the Python host loop */
     int route_attn_preln;     /* 1 (round 6): the backward of a stage's first block on the fused attention half also carries the gradient through the down-sampling LayerNorm (rvt_attn_block_bwd_preln) where no token mask sits between them; 0: rvt_attn_block_bwd + rvt_layernorm_bwd */
+    int conv_fwd_pp;          /* 1 (round 6): 3 x 3 / stride 2 / pad 1 convs with Cin % 64 == 0 and Cout % 256 == 0 take the 256-wide kernel with the im2col gather in its load stream (ppgemm.hpp GATHER = 2); 0: the 128-row engine */
 } RvtTuning;
-#define RVT_TUNING_DEFAULTS {(int)sizeof(RvtTuning), 0, 1, 0, 512, 8192, 1, 4096, 0, 0, 0, 0, 1, 4, 0, 1, 1, 0, 0, 1, -1, 1, 1, -1, 1, 1, 0, 1, 1, 0, 1, 1, 1, 1, 1, 3, 1, 1, 1, 1}
+#define RVT_TUNING_DEFAULTS {(int)sizeof(RvtTuning), 0, 1, 0, 512, 8192, 1, 4096, 0, 0, 0, 0, 1, 4, 0, 1, 1, 0, 0, 1, -1, 1, 1, -1, 1, 1, 0, 1, 1, 0, 1, 1, 1, 1, 1, 3, 1, 1, 1, 1, 1}
 void rvt_tuning_defaults(RvtTuning* t);        /* fills *t with the production defaults */
 int rvt_get_tuning(RvtTuning* t);              /* t->struct_bytes must be set by the caller */
 int rvt_set_tuning(const RvtTuning* t);

@@ -24,6 +24,14 @@ size_t rvt_wgrad_workspace_floats(int dtype, int out_rows, int out_cols, int tok
 static bool conv_wgrad_tn(int dtype, int F, int H, int W, int Cin, int Cout, int k, int stride, int pad) {
     return tuning().ppgemm != 0 && tuning().conv_wgrad_tn != 0 && dtype == RVT_BF16 && ppgemm_tn_conv_shape_ok(F, H, W, Cin, Cout, k, stride, pad);
 }
+// the 3 x 3 / stride 2 / pad 1 down-sampling convs that take the 256-wide kernel with the im2col gather in its load stream
+// (ppgemm.hpp GATHER = 2; bf16, Cin % 64 == 0, Cout % 256 == 0, even H and W, input below 2 GiB)
+static bool conv_fwd_pp(int dtype, int F, int H, int W, int Cin, int Cout, int k, int stride, int pad) {
+    if (dtype != RVT_BF16 || k != 3 || stride != 2 || pad != 1 || (H & 1) || (W & 1) || Cin % 64 != 0) return false;
+    const long long M = (long long)F * (H / 2) * (W / 2);
+    if ((long long)F * H * W * Cin * 2 >= 0x7ffffff0ll || M * Cout * 2 >= (1ll << 40) || M >= (1ll << 31)) return false;
+    return tuning().conv_fwd_pp != 0 && use_ppgemm(dtype, (int)M, Cout, 9 * Cin, Cin, 9 * Cin, 1 << 30);
+}
 template <class T>
 static Im2colSrc<T> make_im2col(const void* in, int F, int H, int W, int Cin, int k, int stride, int pad) {
     Im2colSrc<T> s;
@@ -40,6 +48,18 @@ int rvt_conv_fwd(const void* in, const void* w, void* out, int dtype, int F, int
                  int stride, int pad, void* stream) {
     RVT_CHECK(Cin % 8 == 0 && Cout % 8 == 0, "conv_fwd: channels must be multiples of 8 (Cin=%d Cout=%d)", Cin, Cout);
     hipStream_t st = (hipStream_t)stream;
+    if (conv_fwd_pp(dtype, F, H, W, Cin, Cout, k, stride, pad)) {
+        // 256 x 256 tiles, im2col as a per-lane source address of the LDS-DMA load stream (ppgemm.hpp, GATHER = 2)
+        PPConv cv;
+        cv.Ho = H / 2; cv.Wo = W / 2; cv.Cout = Cin; cv.H = H; cv.W = W; cv.Cin = Cin;
+        cv.dHoWo = FastDiv(cv.Ho * cv.Wo); cv.dWo = FastDiv(cv.Wo);
+        for (int nt = 0; nt < 8; nt++) cv.taps[nt] = 0;
+        const int M = F * cv.Ho * cv.Wo, K = 9 * Cin;
+        const PPMat xs{(const bf16*)in, (const bf16*)in, Cin, 1 << 30}, ws{(const bf16*)w, (const bf16*)w, K, 1 << 30};
+        const PPEpArgs ep{(bf16*)out, nullptr, nullptr, nullptr, nullptr, Cout};
+        launch_ppgemm<PP_STORE, 2>(xs, ws, ep, M, Cout, K, st, cv);
+        return check_launch("conv_fwd");
+    }
     DISPATCH_DTYPE(dtype, {
         Im2colSrc<T> a = make_im2col<T>(in, F, H, W, Cin, k, stride, pad);
         PlainSrc<T> b{(const T*)w, a.cols, Cout, a.cols};

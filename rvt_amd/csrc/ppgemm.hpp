@@ -134,6 +134,12 @@ struct PPConv {
     int taps[8];                          // per N tile (N = 4 Cin <= 2048: up to 8 tiles): bit (2 da + db)
 };
 
+// GATHER = 2 (round 6): the 3 x 3 / stride 2 / pad 1 down-sampling conv itself (reference maxvit.py:160-168) with im2col in the load
+// stream: row m = output pixel (frame, oy, ox), K tile (tap (ky, kx), 64-channel chunk) reads the input pixel
+// (2 oy - 1 + ky, 2 ox - 1 + kx) - a per-lane source address formed when the unit is issued (two exact divisions by constants;
+// the load side runs ahead of the output tile, so nothing per tile is kept in registers), out-of-image taps (oy = 0 with ky = 0,
+// ox = 0 with kx = 0; H, W even) and rows beyond M get an out-of-range address = zeros.  W = the tap-major packed weight
+// [Cout][9 Cin] (PACK_CONV_FWD), plain output rows.  PPConv: Ho, Wo = output size, H, W = input size, Cout = channels per tap (Cin).
 // ABL: ablation bits for profiles/probes/ppgemm_probe.hip (0 in the library): 1 no LDS-DMA / vmcnt waits, 2 no fragment reads,
 // 4 no MFMAs, 8 no barriers, 16 no epilogue, 32 epilogue stores dropped (empty output buffer)
 template <int EP, int ABL = 0, int GATHER = 0>
@@ -146,14 +152,14 @@ ppgemm_kernel(PPMat X, PPMat W, PPEpArgs ep, int M, int N, int K, int m_tiles, i
     const int wave = wave_uniform(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int cpt = GATHER ? cv.Cout / G::BK : 0;     // K tiles per tap
-    auto nk_of = [&](int nt) __attribute__((always_inline)) { return GATHER ? __builtin_popcount(cv.taps[nt & 7]) * cpt : K / G::BK; };
+    auto nk_of = [&](int nt) __attribute__((always_inline)) { return GATHER == 1 ? __builtin_popcount(cv.taps[nt & 7]) * cpt : K / G::BK; };
     constexpr bool SIDE = EP == PP_ADD || EP == PP_SCALE_RES || EP == PP_MUL;
 
     PPWork work;
     work.init(blockIdx.x, gridDim.x, m_tiles, n_tiles);
     if (work.count == 0) return;
     int nsteps = 0;
-    if (GATHER) {
+    if (GATHER == 1) {
         for (int u = 0; u < work.count; u++) { int mt_, nt_; work.tile(u, mt_, nt_); nsteps += nk_of(nt_); }
     } else {
         nsteps = work.count * nk_of(0);
@@ -190,7 +196,15 @@ ppgemm_kernel(PPMat X, PPMat W, PPEpArgs ep, int M, int N, int K, int m_tiles, i
         if (lstep < nsteps) {
             int mt, nt;
             work.tile(lu, mt, nt);
-            if (GATHER) {
+            if (GATHER == 2) {
+                const int tap = lkt / cpt, coff = (lkt - tap * cpt) * G::BK;
+                const int ky = tap / 3;
+                d.da = ky; d.db = tap - 3 * ky; d.mask = mt * G::BM;              // (mask: first row of the tile)
+                d.rx = pp_make_rsrc(X.p0, (unsigned)((size_t)(M / (cv.Ho * cv.Wo)) * cv.H * cv.W * cv.Cout * 2));
+                d.sx = coff * 2;
+                d.rw = pp_make_rsrc(W.p0 + (size_t)nt * G::BN * W.ld, (unsigned)(G::BN * W.ld * 2));
+                d.sw = lkt * G::BK * 2;
+            } else if (GATHER) {
                 if (lkt == 0) {                      // new tile on the load side: border / tail masks of this lane's four rows
                     gmask = 0;
 #pragma unroll
@@ -236,7 +250,15 @@ ppgemm_kernel(PPMat X, PPMat W, PPEpArgs ep, int M, int N, int K, int m_tiles, i
     };
     auto issue_x = [&](const Desc& d, int stage, int i) __attribute__((always_inline)) {
         int v = vx0 + i * ldx64;
-        if (GATHER) {
+        if (GATHER == 2) {
+            const int m = d.mask + (lr >> 5) * 128 + i * 32 + (lr & 31);
+            uint32_t f, rem, oy, ox;
+            cv.dHoWo.divmod((uint32_t)(m < M ? m : 0), f, rem);
+            cv.dWo.divmod(rem, oy, ox);
+            const int pix = ((int)f * cv.H + 2 * (int)oy - 1 + d.da) * cv.W + 2 * (int)ox - 1 + d.db;
+            const bool kill = m >= M || ((int)oy == 0 && d.da == 0) || ((int)ox == 0 && d.db == 0);
+            v = kill ? (int)0x80000000u : pix * cv.Cout * 2 + chunk * 16;
+        } else if (GATHER) {
             const bool kill = ((d.mask >> i) & 1) | (d.da & (d.mask >> (4 + i)) & 1) | (d.db & (d.mask >> (8 + i)) & 1);
             v = kill ? (int)0x80000000u : v;         // beyond any permitted extent (the descriptor spans < 2^31 bytes), whatever the scalar offset: the DMA writes zeros
         }
@@ -255,9 +277,9 @@ ppgemm_kernel(PPMat X, PPMat W, PPEpArgs ep, int M, int N, int K, int m_tiles, i
         OutDesc o;
         const int rows = M - mt * G::BM;
         // (GATHER: the rows scatter over the whole dIn tensor: one descriptor for all of it, offsets from its start)
-        const unsigned bytes = GATHER ? (unsigned)((size_t)(M / (cv.Ho * cv.Wo)) * cv.H * cv.W * cv.Cin * 2)
-                                      : (unsigned)((rows > G::BM ? G::BM : rows) * ep.ld * 2);
-        const size_t base = GATHER ? 0 : (size_t)mt * G::BM * ep.ld;
+        const unsigned bytes = GATHER == 1 ? (unsigned)((size_t)(M / (cv.Ho * cv.Wo)) * cv.H * cv.W * cv.Cin * 2)
+                                           : (unsigned)((rows > G::BM ? G::BM : rows) * ep.ld * 2);
+        const size_t base = GATHER == 1 ? 0 : (size_t)mt * G::BM * ep.ld;
         o.m0 = mt * G::BM;
         o.out = pp_make_rsrc(ep.out + base, (ABL & 32) ? 0u : bytes);          // (ABL 32: stores issued but dropped)
         o.out2 = pp_make_rsrc(ep.out2 ? ep.out2 + base : ep.out, ep.out2 ? bytes : 0u);
@@ -274,7 +296,7 @@ ppgemm_kernel(PPMat X, PPMat W, PPEpArgs ep, int M, int N, int K, int m_tiles, i
     auto row_voff = [&](int i, int it, const OutDesc& od, int lane) __attribute__((always_inline)) {
         const int r = wr * 128 + i * 32 + it * 8 + (lane >> 3), pc = lane & 7, colb = od.n0 + wc * 64;
         int voff = (r * ep.ld + colb + 8 * pc) * 2;
-        if (GATHER) {                                 // row (frame, a, b), wave column (py, px, channel block) -> pixel (2a + py, 2b + px)
+        if (GATHER == 1) {                            // row (frame, a, b), wave column (py, px, channel block) -> pixel (2a + py, 2b + px)
             const int m = od.m0 + r;
             uint32_t f, rem, a, b;
             cv.dHoWo.divmod((uint32_t)(m < M ? m : 0), f, rem);
@@ -429,7 +451,7 @@ ppgemm_kernel(PPMat X, PPMat W, PPEpArgs ep, int M, int N, int K, int m_tiles, i
         constexpr int ST = (ABL & 16) ? 0 : (EP == PP_GELU_DUAL ? 8 : 4) + ((ABL & 64) ? 4 : 0);      // (ABL 64, timing probe only: counts too lax)
         constexpr int SL = (SIDE && !(ABL & 16)) ? 4 : 0;
         // (GATHER: the scatter addresses leave no registers for a second set of side rows: they are loaded right before their use)
-        constexpr bool PREF = !GATHER;
+        constexpr bool PREF = GATHER != 1;
         constexpr int E0 = ST + (PREF ? 2 * SL : SL), E1 = ST + SL, E2 = ST + SL, E3 = ST + (PREF ? 0 : SL);
         constexpr int W0 = 8 + (MODE == 2 ? E0 + E1 + E2 + E3 : 0), W1 = 9 + (MODE == 1 ? E0 : MODE == 2 ? E1 + E2 + E3 : 0),
                       W2 = 10 + (MODE == 1 ? E0 + E1 : MODE == 2 ? E1 + E2 + E3 : 0), W3 = 7 + (MODE == 1 ? E0 + E1 + E2 : 0);

@@ -21,7 +21,7 @@ from typing import Dict, Iterator
 _GEOMETRY = ('gemm_resident', 'gemm_xcd_panels', 'wgrad_bn', 'wgrad_blocks', 'wgrad_slice_tokens', 'ppgemm', 'ppgemm_min_m',
              'ppgemm_all', 'ppgemm_grid', 'ppgemm_tn_items', 'one_per_cu_grid', 'stem', 'stem_depth', 'mlp_tm', 'mlp_chain',
              'mlp_chain_wgrad', 'chain_resident', 'attn_block_resident', 'dgrad_ln')
-_LATE = ('lstm_scan_v2', 'route_stage_driver', 'route_mlp_store_pre', 'route_mlp_bwd_both', 'mlp_stream', 'ln_linear', 'conv_wgrad_tn', 'attn_staged', 'lstm_scan3', 'lstm_scan3_rb256', 'lstm_scan3_rb128', 'route_stage_driver_train', 'route_attn_preln')          # fields appended after the routes (struct order = _GEOMETRY + _ROUTES + _LATE)
+_LATE = ('lstm_scan_v2', 'route_stage_driver', 'route_mlp_store_pre', 'route_mlp_bwd_both', 'mlp_stream', 'ln_linear', 'conv_wgrad_tn', 'attn_staged', 'lstm_scan3', 'lstm_scan3_rb256', 'lstm_scan3_rb128', 'route_stage_driver_train', 'route_attn_preln', 'conv_fwd_pp')          # fields appended after the routes (struct order = _GEOMETRY + _ROUTES + _LATE)
 _ROUTES = ('route_fused_mlp', 'route_mlp_bwd_fused', 'route_attn_block', 'route_lstm_scan', 'route_lstm_scan_wgrad',
            'route_conv_dgrad4', 'route_wgrad_stream')
 FIELDS = _GEOMETRY + _ROUTES + _LATE

@@ -602,6 +602,25 @@ def test_conv_dgrad4(backend, case):
     close(ops.conv_dgrad4(dy, wd4, add, H, W, Cin), f64(old), dt, 'conv_dgrad4 vs parity-class route', f32_mult=0.5)
 
 
+@pytest.mark.parametrize('case', [(3, 16, 24, 64, 256), (2, 20, 36, 128, 512), (5, 12, 20, 256, 512), (9, 8, 16, 64, 256)])   # F, H, W, Cin, Cout
+def test_conv_fwd_pp(backend, case):
+    """The 3x3 / 2 / 1 down-sampling conv on the 256-wide kernel with the im2col gather in its load stream (csrc/ppgemm.hpp GATHER = 2)
+    vs fp64 conv2d and vs the 128-row engine: image borders (top / left taps outside), ragged last row tile, several tiles per
+    workgroup, one and two N tiles, 9 / 18 / 36 K tiles."""
+    Fr, H, W, Cin, Cout = case
+    dt = torch.bfloat16
+    x = rnd((Fr, H, W, Cin), backend, dt, 1)
+    w = rnd((Cout, Cin, 3, 3), backend, torch.float32, 2, 0.2).to(dt)
+    wp = weights.pack_conv_fwd(w.float(), Cin, dt)
+    want = F.conv2d(f64(x).permute(0, 3, 1, 2), f64(w), None, 2, 1).permute(0, 2, 3, 1)
+    with tuning.override(conv_fwd_pp=1):
+        y = ops.conv_fwd(x, wp, 3, 2, 1)
+    with tuning.override(conv_fwd_pp=0):
+        y0 = ops.conv_fwd(x, wp, 3, 2, 1)
+    close(y, want, dt, 'conv_fwd_pp')
+    close(y, f64(y0), dt, 'conv_fwd_pp vs the 128-row engine', f32_mult=0.5)
+
+
 CONV_WGRAD_TN_CASES = [  # F, H, W, Cin, Cout, k, stride, pad
     (3, 24, 40, 128, 256, 3, 2, 1),      # stage-3 down-sampling conv: K = 1152 = 4.5 k tiles (the last one half beyond K), two taps per tile
     (5, 12, 20, 256, 512, 3, 2, 1),      # stage 4: one tap per k tile, two n tiles, Wo = 10 (a 64-token step spans 6 image rows and frames)
