@@ -76,8 +76,11 @@ ppgemm_tn_kernel(const bf16* __restrict__ dY, int ldy, const bf16* __restrict__ 
     const int lds0 = wave * 1024;
     const bf16* const ybase = dY + (size_t)nt * 256;
     // the X side may be two matrices side by side ([x_t | h_{t-1}] of the ConvLSTM, rnn.py:52): k tiles never straddle the cut
+    // (round 6: the cut may also fall INSIDE a k tile, on a 64-column unit boundary - C = 128: [x | h] is one k tile, units 0 - 1 from x,
+    // 2 - 3 from h: the units of the second segment take their own descriptor, rx2, whose column 0 is the cut)
     const bf16* const xbase = kt * 256 < kcut ? X + (size_t)kt * 256 : X2 + (size_t)(kt * 256 - kcut);
-    struct Desc { pp_rsrc ry, rx; int vx[CONV ? 4 : 1]; };
+    const int cut_unit = (kcut > kt * 256 && kcut < kt * 256 + 256) ? (kcut - kt * 256) >> 6 : 4;       // first unit of the second segment (4: none)
+    struct Desc { pp_rsrc ry, rx, rx2; int vx[CONV ? 4 : 1]; };
     // CONV: the four X units of this k tile = (tap, 64-channel slab) pairs, fixed per workgroup; (f, oy, ox) of the lane's token of
     // the NEXT step to be described, advanced by 64 tokens per step
     int c_dy[4], c_dx[4], c_off[4], c_f = 0, c_by = 0, c_bx = 0;
@@ -105,13 +108,16 @@ ppgemm_tn_kernel(const bf16* __restrict__ dY, int ldy, const bf16* __restrict__ 
             const int rows = tok1 - t0 < 64 ? tok1 - t0 : 64;
             // the last token row of the buffer ends at its last tile column: row stride ld, tile width 256 columns
             d.ry = pp_make_rsrc(ybase + (size_t)t0 * ldy, (unsigned)(((rows - 1) * ldy + 256) * 2));
-            if constexpr (!CONV) d.rx = pp_make_rsrc(xbase + (size_t)t0 * ldx, (unsigned)(((rows - 1) * ldx + 256) * 2));
+            if constexpr (!CONV) {
+                d.rx = pp_make_rsrc(xbase + (size_t)t0 * ldx, (unsigned)(((rows - 1) * ldx + (cut_unit < 4 ? 64 * cut_unit : 256)) * 2));
+                d.rx2 = cut_unit < 4 ? pp_make_rsrc(X2 + (size_t)t0 * ldx, (unsigned)(((rows - 1) * ldx + 64 * (4 - cut_unit)) * 2)) : d.rx;
+            }
         } else {
             d.ry = pp_make_rsrc(dY, 0u);
-            if constexpr (!CONV) d.rx = pp_make_rsrc(X, 0u);
+            if constexpr (!CONV) { d.rx = pp_make_rsrc(X, 0u); d.rx2 = d.rx; }
         }
         if constexpr (CONV) {
-            d.rx = rx_all;
+            d.rx = rx_all; d.rx2 = rx_all;
             const bool in = lstep < nsteps && t0 + t_l < tok1;
             const int base = ((c_f * cv.H + c_by) * cv.W + c_bx) * cv.Cin * 2 + cpos * 16;
 #pragma unroll
@@ -132,7 +138,9 @@ ppgemm_tn_kernel(const bf16* __restrict__ dY, int ldy, const bf16* __restrict__ 
     auto issue_x = [&](const Desc& d, int stage, int g) __attribute__((always_inline)) {
         int v = vx0 + g * 128;
         if constexpr (CONV) v = d.vx[g];
-        if (!(ABL & 1) && !(ABL & 64)) pp_glds16(d.rx, smem, stage * G::STAGE + G::OFF_W + g * G::UNIT + lds0, v, 0);
+        const bool second = !CONV && g >= cut_unit;                  // (wave-uniform)
+        if (second) v = vx0 + (g - cut_unit) * 128;
+        if (!(ABL & 1) && !(ABL & 64)) pp_glds16(second ? d.rx2 : d.rx, smem, stage * G::STAGE + G::OFF_W + g * G::UNIT + lds0, v, 0);
     };
 
     // ---- fragment reads (transposing): lane -> token 16 ks + 8 hi + (lane % 16) / 4 (+ 4), 4 columns 16 ((lane / 16) % 2) + 4 (lane % 4) ----
@@ -298,7 +306,7 @@ ppgemm_tn_kernel(const bf16* __restrict__ dY, int ldy, const bf16* __restrict__ 
 // host side ------------------------------------------------------------------------------------------------------------
 inline bool ppgemm_tn_shape_ok(int M, int N, int K, int ldy, int ldx, int kcut) {
     const int min_m = g_tuning.ppgemm_min_m;
-    return N % 256 == 0 && K % 256 == 0 && kcut % 256 == 0 && ldy % 8 == 0 && ldx % 8 == 0 && M >= min_m &&
+    return N % 256 == 0 && K % 256 == 0 && kcut % 64 == 0 && ldy % 8 == 0 && ldx % 8 == 0 && M >= min_m &&
            (size_t)64 * (size_t)(ldy > ldx ? ldy : ldx) * 2 + 512 < (1ull << 31);
 }
 // token slices: as many as fill the chip once (one item per CU), at least 4 steps of 64 tokens each
