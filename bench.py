@@ -179,6 +179,8 @@ def traffic_lookup(workload_key, key):
         subs = ['stem_wgrad_kernel']
     elif n in ('rvt_attn_block_bwd', 'rvt_attn_block_fwd'):
         subs = [n[4:] + '_kernel', 'Li2ELb0ELi' if shp[-1] == 1 else 'Li2ELb1ELi']      # (RVT-Base: the window block of a stage has no norm1, the grid block has)
+    elif n == 'rvt_attn_block_bwd_preln':
+        subs = ['attn_block_bwd_kernel', 'Li2ELb0ELi4ELb1E']                            # (LN = false, four waves, PRE = true)
     if subs is None:
         return None
     try:

@@ -119,6 +119,10 @@ def model(name: str, a) -> Optional[Tuple[float, float]]:
         e, F, H, W, C, dh, ph, pw = _elt(a[12]), *a[13:20]
         M, L = F * H * W, ph * pw
         return M * (8.0 * C * C + 8.0 * L * C), ((6.0 + (1 if P(4) else 0)) * M * C + 7 * C * C) * e
+    if name == 'rvt_attn_block_bwd_preln':               # the same products; rows: x, y0, dxmid in, dy0 + dqkv (3) out
+        e, F, H, W, C, dh, ph, pw = _elt(a[11]), *a[12:19]
+        M, L = F * H * W, ph * pw
+        return M * (8.0 * C * C + 8.0 * L * C), (7.0 * M * C + 7 * C * C) * e
     if name == 'rvt_lstm_fwd':
         e, M, C = _elt(a[8]), a[9], a[10]
         return 16.0 * M * C * C, 1.0 * M * C * (3 * e + 8 + (4 * e if P(7) else 0)) + 8.0 * C * C * e
@@ -206,6 +210,9 @@ def executed(name: str, a) -> Optional[float]:
         return fl + 2.0 * F * H * W * ph * pw * C
     if name == 'rvt_attn_block_bwd':
         F, H, W, C, dh, ph, pw = a[13:20]
+        return fl + F * H * W * (6.0 * C * C + 2.0 * ph * pw * C)
+    if name == 'rvt_attn_block_bwd_preln':
+        F, H, W, C, dh, ph, pw = a[12:19]
         return fl + F * H * W * (6.0 * C * C + 2.0 * ph * pw * C)
     if name == 'rvt_lstm_scan_bwd' and not P(16):
         M, C, T = a[18], a[19], a[20]
