@@ -114,7 +114,9 @@ int rvt_prepack_input(const void* src, int src_u8, void* dst, int dtype, int F, 
                       int H, int W, int Cp, void* stream);
 
 /* Down-sampling conv (maxvit.py:160-168,175; bias-free): in [F][H][W][Cin], w [Cout][k*k*Cin]
- * (tap-major, cin fastest) -> out [F][Ho][Wo][Cout], Ho=(H+2*pad-k)/stride+1. */
+ * (tap-major, cin fastest) -> out [F][Ho][Wo][Cout], Ho=(H+2*pad-k)/stride+1.  bf16, k = 3, stride 2, pad 1, even H and W,
+ * Cin % 64 == 0, Cout % 256 == 0 (stages 3-4 of RVT-Base): the 256-wide LDS-DMA kernel with the im2col gather in its load
+ * stream (tuning.conv_fwd_pp; same products, fp32 summation order of that kernel); everything else: the 128-row engine. */
 int rvt_conv_fwd(const void* in, const void* w, void* out, int dtype, int F, int H, int W, int Cin, int Cout,
                  int k, int stride, int pad, void* stream);
 /* Input gradient of the 3x3 / stride-2 / pad-1 down-sampling conv of stages 2-4 (reference maxvit.py:160-168, autograd) as ONE
