@@ -87,7 +87,7 @@ typedef struct RvtTuning {
     int lstm_scan3_rb256;     /* 32-token blocks per workgroup tile of that forward at C = 256: 1 or 2 */
     int lstm_scan3_rb128;     /* ... at C = 128 */
     int route_stage_driver_train; /* 1 (round 6): the training forward / backward of a stage take rvt_stage_seq_train_fwd / rvt_stage_seq_bwd (one call per stage and direction) where covered; 0: the Python host loop */
-    int route_attn_preln;     /* 1 (round 6): the backward of a stage's first block on the fused attention half also carries the gradient through the down-sampling LayerNorm (rvt_attn_block_bwd_preln) where no token mask sits between them; 0: rvt_attn_block_bwd + rvt_layernorm_bwd */
+    int route_attn_preln;     /* 1 (round 6): the backward of a stage's first block also carries the gradient through the down-sampling LayerNorm where no token mask sits between them: rvt_attn_block_bwd_preln on the fused attention half, rvt_linear_dgrad_preln on the op-by-op route (C <= 128); 0: separate rvt_layernorm_bwd */
     int conv_fwd_pp;          /* 1 (round 6): 3 x 3 / stride 2 / pad 1 convs with Cin % 64 == 0 and Cout % 256 == 0 take the 256-wide kernel with the im2col gather in its load stream (ppgemm.hpp GATHER = 2); 0: the 128-row engine */
 } RvtTuning;
 #define RVT_TUNING_DEFAULTS {(int)sizeof(RvtTuning), 0, 1, 0, 512, 8192, 1, 4096, 0, 0, 0, 0, 1, 4, 0, 1, 1, 0, 0, 1, -1, 1, 1, -1, 1, 1, 0, 1, 1, 0, 1, 1, 1, 1, 1, 3, 1, 1, 1, 1, 1}
@@ -181,6 +181,11 @@ int rvt_linear_dgrad(const void* dy, const void* wt, const void* gelu_pre, const
 int rvt_linear_dgrad_ln_supported(int dtype, int C, int K);
 int rvt_linear_dgrad_ln(const void* dy, const void* w, const void* x, const void* add, void* dx, const float* ln_w,
                         float* dln_w, float* dln_b, int dtype, int M, int C, int K, float eps, void* stream);
+/* The same launch for a stage's FIRST block (no norm1, maxvit_rnn.py:153), carried through the down-sampling norm in front of it
+ * (maxvit.py:177): dy0 = LN'(dy w + add ; y0) - the added cotangent (the block's residual path) enters the norm.  Replaces
+ * rvt_linear_dgrad(.., add) + rvt_layernorm_bwd(y0, ..).  Shapes as rvt_linear_dgrad_ln_supported; add is required. */
+int rvt_linear_dgrad_preln(const void* dy, const void* w, const void* y0, const void* add, void* dy0, const float* ln_w,
+                           float* dln_w, float* dln_b, int dtype, int M, int C, int K, float eps, void* stream);
 
 /* u = LN(x; ln_w, ln_b), y = u W^T + bias in one launch (csrc/ln_linear.hpp; replaces rvt_layernorm_fwd + rvt_linear_fwd for
  * `self.qkv(self.norm1(x))`, reference maxvit.py:268 -> :347).  W [N][C] row-major, bias may be NULL, u may be NULL (no-grad
@@ -406,7 +411,7 @@ typedef struct RvtStageTrain {
     int lstm_route;                       /* 0: one launch per step; 1: the rvt_lstm_scan_ kernels, gates recomputed; 2: the same with saved gates; 3: the rvt_lstm_scan3_ kernels */
     int lstm_scan_wgrad;                  /* routes 1: ConvLSTM weight gradients inside the reverse scan */
     int conv_dgrad4;                      /* 1: rvt_conv_dgrad4 for the input gradient of the down-sampling conv */
-    int attn_preln;                       /* attn_block = 1: the first block's backward also carries the gradient through the down-sampling norm (rvt_attn_block_bwd_preln) */
+    int attn_preln;                       /* the first block's backward also carries the gradient through the down-sampling norm: rvt_attn_block_bwd_preln (attn_block = 1) or rvt_linear_dgrad_preln (op-by-op attention, where rvt_linear_dgrad_ln_supported(C, 3C)) */
     const RvtBlockSaved* saved;           /* HOST arrays, 2 * num_blocks entries each */
     const RvtBlockTrain* tb;
     void *y0, *x0;                        /* conv output, LayerNorm output (= saved[0].xin) */

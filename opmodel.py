@@ -81,6 +81,9 @@ def model(name: str, a) -> Optional[Tuple[float, float]]:
         e, M, N, K = _elt(a[6]), a[7], a[8], a[9]
         side = 1 if (P(2) or P(3) or P(4)) else 0
         return 2.0 * M * N * K, (1.0 * M * (N + K * (1 + side)) + N * K) * e
+    if name == 'rvt_linear_dgrad_preln':                 # dy0 = LN'(dy w + add; y0): same rows as the form below with add
+        e, M, C, K = _elt(a[8]), a[9], a[10], a[11]
+        return 2.0 * M * C * K, (1.0 * M * (K + 3 * C) + K * C) * e
     if name == 'rvt_linear_dgrad_ln':                    # dx = add + LN'(dy w; x)
         e, M, C, K = _elt(a[8]), a[9], a[10], a[11]
         return 2.0 * M * C * K, (1.0 * M * (K + C * (2 + (1 if P(3) else 0))) + K * C) * e

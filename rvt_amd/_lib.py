@@ -37,6 +37,7 @@ _SIGS = {
     'rvt_linear_scale_res_fwd': [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     'rvt_linear_dgrad': [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     'rvt_linear_dgrad_ln': [_vp] * 8 + [_i, _i, _i, _i, _f, _vp],
+    'rvt_linear_dgrad_preln': [_vp] * 8 + [_i, _i, _i, _i, _f, _vp],
     'rvt_ln_linear_fwd': [_vp] * 7 + [_i, _i, _i, _i, _f, _vp],
     'rvt_linear_gelu_fwd': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     'rvt_linear_wgrad': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],

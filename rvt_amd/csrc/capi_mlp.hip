@@ -83,6 +83,25 @@ int rvt_linear_dgrad_ln(const void* dy, const void* w, const void* x, const void
     return check_launch("linear_dgrad_ln");
 }
 
+// dy0 = LN'(dy W + add; y0): the qkv input gradient of a stage's first block (no norm1) carried through the down-sampling norm in front of it
+int rvt_linear_dgrad_preln(const void* dy, const void* w, const void* y0, const void* add, void* dy0, const float* ln_w,
+                           float* dln_w, float* dln_b, int dtype, int M, int C, int K, float eps, void* stream) {
+    RVT_CHECK(rvt_linear_dgrad_ln_supported(dtype, C, K), "linear_dgrad_preln: not built for dtype=%d C=%d K=%d", dtype, C, K);
+    RVT_CHECK(M >= 1 && add != nullptr && ln_w != nullptr && dln_w != nullptr && dln_b != nullptr, "linear_dgrad_preln: add, LayerNorm weight and gradient buffers required");
+    hipStream_t st = (hipStream_t)stream;
+#define RVT_DGLI(CC, AH)                                                                                                   \
+    do {                                                                                                                   \
+        auto k = dgrad_ln_kernel<bf16, CC, 8, AH, true>;                                                                   \
+        hipLaunchKernelGGL(k, dim3(mc_grid(k, 512, M, 8)), dim3(512), 0, st, (const bf16*)dy, (const bf16*)w, (const bf16*)y0, \
+                           (const bf16*)add, (bf16*)dy0, ln_w, dln_w, dln_b, M, K, eps);                                   \
+    } while (0)
+    const bool four = (K / 32) % 4 == 0;
+    if (C == 128) RVT_DGLI(128, 4);
+    else { if (four) RVT_DGLI(64, 4); else RVT_DGLI(64, 2); }
+#undef RVT_DGLI
+    return check_launch("linear_dgrad_preln");
+}
+
 // u = LN(x), y = u W^T + bias in one launch (csrc/ln_linear.hpp): the qkv projection of a C = 128 block.  tuning.ln_linear = 0 disables.
 int rvt_ln_linear_supported(int dtype, int C, int N) {
     return tuning().ln_linear != 0 && dtype == RVT_BF16 && C == 128 && N == 384;

@@ -258,7 +258,11 @@ int rvt_stage_seq_bwd(const RvtStageDesc* dp, const RvtStageTrain* tp, const voi
             RVT_TRY(rvt_linear_dgrad(dxmid, tb.proj_wt, nullptr, nullptr, nullptr, t1, dt, M, C, C, stream));          // da
             RVT_TRY(rvt_attn_bwd(sv.qkv, t1, dqkv, dt, F, H, W, C, d.dim_head, d.ph, d.pw, window, stream));
             RVT_TRY(rvt_linear_wgrad(dqkv, bw.n1_w != nullptr ? sv.u : sv.xin, tb.d_qkv_w, tb.d_qkv_b, ws_wgrad, dt, M, 3 * C, C, 0, stream));
-            if (bw.n1_w == nullptr) {
+            if (bw.n1_w == nullptr && bi == 0 && t.attn_preln) {
+                // the stage's first block: qkv input gradient + residual cotangent carried through the down-sampling norm (one launch)
+                RVT_TRY(rvt_linear_dgrad_preln(dqkv, bw.qkv_w, t.y0, dxmid, dy0, d.ln_w, t.d_ln_w, t.d_ln_b, dt, M, C, 3 * C, d.eps, stream));
+                preln_done = true;
+            } else if (bw.n1_w == nullptr) {
                 RVT_TRY(rvt_linear_dgrad(dqkv, tb.qkv_wt, nullptr, dxmid, nullptr, dxi, dt, M, 3 * C, C, stream));
             } else if (t.dgrad_ln_qkv) {
                 RVT_TRY(rvt_linear_dgrad_ln(dqkv, bw.qkv_w, sv.xin, dxmid, dxi, bw.n1_w, tb.d_n1_w, tb.d_n1_b, dt, M, C, 3 * C, d.eps, stream));

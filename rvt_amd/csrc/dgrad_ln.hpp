@@ -27,7 +27,10 @@ template <class T, int C> struct DglSmem {
     static constexpr int BYTES_FOR(int wpb) { return OFF_SCR + wpb * SCR_WAVE; }
 };
 
-template <class T, int C, int WPB, int AHEAD>
+// INSIDE (round 6): the added cotangent enters the norm instead of by-passing it,  dx = LN'( dy W + add ; x )  - the first block of a
+// stage (no norm1; `skip_first_norm`, maxvit_rnn.py:153): its qkv input gradient plus the block's residual cotangent is the cotangent
+// of the down-sampling norm's output (maxvit.py:177), x = that norm's input y0.  Replaces the GEMM and the LayerNorm backward launch.
+template <class T, int C, int WPB, int AHEAD, bool INSIDE = false>
 __global__ void __launch_bounds__(64 * WPB, 2)
 dgrad_ln_kernel(const T* __restrict__ dy, const T* __restrict__ W, const T* __restrict__ x, const T* __restrict__ add,
                 T* __restrict__ dx, const float* __restrict__ ln_w, float* __restrict__ dln_w, float* __restrict__ dln_b,
@@ -124,6 +127,10 @@ dgrad_ln_kernel(const T* __restrict__ dy, const T* __restrict__ W, const T* __re
         group(0, std::true_type());
         for (int jc0 = AHEAD; jc0 < NJC; jc0 += AHEAD) group(jc0, std::false_type());
         if (tile + (int)(gridDim.x * WPB) < n_tiles) prime(tile + gridDim.x * WPB);
+        // INSIDE: the added rows are needed in pass 1 already; the pieces of channel block cb + 1 are requested while block cb is folded
+        const T* const addr_in = INSIDE ? add + (size_t)rowc * C + half * 8 : nullptr;
+        frag_t<T> ai[2] = {frag_zero<T>(), frag_zero<T>()}, ain[2] = {frag_zero<T>(), frag_zero<T>()};
+        if (INSIDE) { ai[0] = frag_load<T>(addr_in); ai[1] = frag_load<T>(addr_in + 16); }
         sched_fence();
         // row statistics of x (lane = row: in-lane sums + one exchange)
         float s = 0.f;
@@ -149,6 +156,14 @@ dgrad_ln_kernel(const T* __restrict__ dy, const T* __restrict__ W, const T* __re
         for (int cb = 0; cb < NCB; cb++) {
             float r8[2][8];
             acc_to_rows(dacc[cb], r8);
+            if (INSIDE) {
+                if (cb + 1 < NCB) { ain[0] = frag_load<T>(addr_in + 16 * (2 * cb + 2)); ain[1] = frag_load<T>(addr_in + 16 * (2 * cb + 3)); }
+#pragma unroll
+                for (int m = 0; m < 2; m++)
+#pragma unroll
+                    for (int e = 0; e < 8; e++) r8[m][e] += (float)ai[m][e];
+                ai[0] = ain[0]; ai[1] = ain[1];
+            }
             if (!interior) {
 #pragma unroll
                 for (int m = 0; m < 2; m++)
@@ -178,7 +193,7 @@ dgrad_ln_kernel(const T* __restrict__ dy, const T* __restrict__ W, const T* __re
         // pass 2.  The rows leave through a wave-private LDS bounce, two 16-channel pieces (64 bytes of every row) at a time: in
         // operand form a store instruction would write 32 bytes of each of 32 rows (0.95 ms; 0.85 with the bounce, 0.82 with the
         // residual pieces requested ahead of the stores); from the bounce a store instruction writes 64 contiguous bytes of 16 rows.  (DS operations of one wave execute in order: no barrier.)
-        const T* const addr = add != nullptr ? add + (size_t)rowc * C + half * 8 : nullptr;
+        const T* const addr = (!INSIDE && add != nullptr) ? add + (size_t)rowc * C + half * 8 : nullptr;
         // (vmcnt retires loads and stores in issue order: a residual piece requested AFTER the stores of the previous pair would
         // wait for their acknowledgement - the next pair's pieces are requested before this pair's rows are stored)
         frag_t<T> af[2] = {frag_zero<T>(), frag_zero<T>()}, afn[2] = {frag_zero<T>(), frag_zero<T>()};

@@ -194,6 +194,19 @@ def linear_dgrad_ln(dy: Tensor, w: Tensor, x: Tensor, dres: Optional[Tensor], ln
     return dx
 
 
+def linear_dgrad_preln(dy: Tensor, w: Tensor, y0: Tensor, add: Tensor, ln_w: Tensor, dw: Tensor, db: Tensor, eps: float) -> Tensor:
+    """dy0 = LN'(dy @ w + add; y0): the qkv input gradient of a stage's first block (no norm1) plus its residual cotangent, carried
+    through the down-sampling norm in front of the block (maxvit.py:177) in one launch; dw / db += that norm's parameter gradients."""
+    C = y0.shape[-1]
+    K = dy.shape[-1]
+    rows = y0.numel() // C
+    assert tuple(w.shape) == (K, C) and w.dtype == y0.dtype == dy.dtype == add.dtype and dy.numel() // K == rows
+    out = torch.empty_like(y0)
+    L.call('rvt_linear_dgrad_preln', L.ptr(dy), L.ptr(w), L.ptr(y0), L.ptr(add), L.ptr(out), L.ptr(ln_w), L.ptr(dw), L.ptr(db),
+           L.dtype_code(y0.dtype), rows, C, K, float(eps), L.stream_of(y0))
+    return out
+
+
 def linear_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor], gelu_in: bool = False, out: Optional[Tensor] = None) -> Tensor:
     K = x.shape[-1]
     M = x.numel() // K

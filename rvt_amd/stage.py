@@ -520,7 +520,13 @@ def stage_seq_backward(sw: StageWeights, g: StageGeom, sv: StageSaved, dH: Optio
             def qkv_wgrad_fn(dqkv=dqkv, s=s, bp=bp):
                 ops.linear_wgrad(dqkv, s['u'], G(bp + 'self_attn.qkv.weight'), colsum_out=G(bp + 'self_attn.qkv.bias'))
             side.run(qkv_wgrad_fn, dqkv, s['xin'])
-            if bw['n1_w'] is None:
+            if bw['n1_w'] is None and bi_flat == 0 and sv.mask is None and tuning.get('route_attn_preln') != 0 and \
+                    ops.linear_dgrad_ln_supported(dt, C, 3 * C):
+                # the stage's first block: qkv input gradient + residual cotangent carried through the down-sampling norm (one launch)
+                dy0_fused = ops.linear_dgrad_preln(dqkv, bw['qkv_w'], sv.y0, dxmid, sw.ln_w, G(pre + 'downsample_cf2cl.norm.weight'),
+                                                   G(pre + 'downsample_cf2cl.norm.bias'), g.eps)
+                dx = None
+            elif bw['n1_w'] is None:
                 dx = ops.linear_dgrad(dqkv, bw['qkv_wt'], add=dxmid)
             elif ops.linear_dgrad_ln_supported(dt, C, 3 * C):           # qkv input gradient + norm1 backward + residual: one launch
                 dx = ops.linear_dgrad_ln(dqkv, bw['qkv_w'], s['xin'], dxmid, bw['n1_w'], G(bp + 'norm1.weight'),

@@ -179,7 +179,8 @@ def train_routes(sw, g, dt, T: int, B: int, token_mask) -> Optional[dict]:
     r['conv_dgrad4'] = int(sw.conv_wd4 is not None and tuning.get('route_conv_dgrad4') != 0 and
                            ops.conv_dgrad4_supported(dt, g.H_in, g.W_in, g.Cin, C, g.k, g.stride, g.pad, T * B))
     # (the first block of a stage never has a norm1: maxvit_rnn.py:153 `skip_first_norm`; no token mask on this route)
-    r['attn_preln'] = int(r['attn_block'] and tuning.get('route_attn_preln') != 0 and sw.blocks[0][0]['n1_w'] is None)
+    r['attn_preln'] = int((r['attn_block'] or ops.linear_dgrad_ln_supported(dt, C, 3 * C)) and tuning.get('route_attn_preln') != 0 and
+                          sw.blocks[0][0]['n1_w'] is None)
     return r
 
 

@@ -291,6 +291,32 @@ def test_linear_dgrad_ln(backend, C, K, M):
     close(dx3, xr.grad, dt, 'dgrad_ln dx, no residual')
 
 
+@pytest.mark.parametrize('C,K', [(64, 192), (128, 384)])
+@pytest.mark.parametrize('M', [45, 300, 1000, 33, 129])
+def test_linear_dgrad_preln(backend, C, K, M):
+    """dy0 = LN'(dy W + add; y0) in one launch (csrc/dgrad_ln.hpp, INSIDE: the first block of a stage on the op-by-op attention
+    route, carried through the down-sampling norm) vs fp64 autograd and vs the two launches it replaces."""
+    dt = torch.bfloat16
+    y0 = rnd((M, C), backend, dt, 1, 2.0)
+    lw = rnd((C,), backend, torch.float32, 2) * 0.3 + 1.0
+    w = rnd((K, C), backend, dt, 3, 0.2)
+    dy, add = rnd((M, K), backend, dt, 4), rnd((M, C), backend, dt, 5)
+    dw, db = torch.zeros(C, device=backend), torch.zeros(C, device=backend)
+    out = ops.linear_dgrad_preln(dy, w, y0, add, lw, dw, db, 1e-5)
+    yr, lwr, lbr = f64(y0).requires_grad_(True), f64(lw).requires_grad_(True), torch.zeros(C, dtype=torch.float64, requires_grad=True)
+    u = F.layer_norm(yr, (C,), lwr, lbr, 1e-5)
+    ((u @ f64(w).t() * f64(dy)).sum() + (u * f64(add)).sum()).backward()
+    close(out, yr.grad, dt, 'dgrad_preln dy0')
+    close(dw, lwr.grad, dt, 'dgrad_preln dln_w')
+    close(db, lbr.grad, dt, 'dgrad_preln dln_b')
+    dw2, db2 = torch.zeros(C, device=backend), torch.zeros(C, device=backend)
+    dx = ops.linear_dgrad(dy, w.t().contiguous(), add=add)
+    out2 = ops.layernorm_bwd(y0, lw, dx, None, dw2, db2, 1e-5)
+    close(out, out2.double(), dt, 'dgrad_preln vs chain dy0')
+    close(dw, dw2.double(), dt, 'dgrad_preln vs chain dln_w')
+    close(db, db2.double(), dt, 'dgrad_preln vs chain dln_b')
+
+
 def ref_attention(qkv, Fr, H, W, C, dh, ph, pw, window):
     """plain restatement of maxvit.py:273-304,343-354 on (F,H,W,3C) -> (F,H,W,C)"""
     heads = C // dh
