@@ -72,6 +72,11 @@ __device__ __forceinline__ void mma32_zero(f32x16& c, const bf16x8& a, const bf1
     const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, z, 0, 0, 0);
 }
+__device__ __forceinline__ void mma32_zero(f32x16& c, const f32x8& a, const f32x8& b) {       // (parity mode: zero fill + the eight k = 2 products)
+#pragma unroll
+    for (int i = 0; i < 16; i++) c[i] = 0.0f;
+    mma32(c, a, b);
+}
 #else
 template <class F> inline void mma32_emu(f32x16& c, const F& a, const F& b) {
     float ab[16];
@@ -92,6 +97,7 @@ template <class F> inline void mma32_emu(f32x16& c, const F& a, const F& b) {
 inline void mma32(f32x16& c, const bf16x8& a, const bf16x8& b) { mma32_emu(c, a, b); }
 inline void mma32(f32x16& c, const f32x8& a, const f32x8& b) { mma32_emu(c, a, b); }
 inline void mma32_zero(f32x16& c, const bf16x8& a, const bf16x8& b) { for (int i = 0; i < 16; i++) c[i] = 0.f; mma32_emu(c, a, b); }
+inline void mma32_zero(f32x16& c, const f32x8& a, const f32x8& b) { for (int i = 0; i < 16; i++) c[i] = 0.f; mma32_emu(c, a, b); }
 #endif
 
 // ---- MFMA: one 16x16 output block, K = 32 (v_mfma_f32_16x16x32_bf16) ----------------------------------------------

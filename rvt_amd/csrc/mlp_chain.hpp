@@ -133,12 +133,14 @@ mlpc_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, const float* _
             mc_load_row<T, C>(xn, xmid, tn * 32 + li, tn < n_tiles && tn * 32 + li < M, half);
         }
         float mean, rstd;
-        mc_layernorm<T, C>(xf, uf, kst + S::K_LNW, kst + S::K_LNB, valid, half, eps, mean, rstd);
+        // (interior tiles - wave-uniform - take the LayerNorm without the per-lane "row exists" selects: the kernel is bound by VALU issue,
+        //  profiles/r6/experiments.txt item 9, and a tile spent 35 v_cndmask on rows that all exist)
+        if (tile * 32 + 32 <= M) mc_layernorm<T, C>(xf, uf, kst + S::K_LNW, kst + S::K_LNB, true, half, eps, mean, rstd);
+        else mc_layernorm<T, C>(xf, uf, kst + S::K_LNW, kst + S::K_LNB, valid, half, eps, mean, rstd);
         f32x16 oacc[NCB];
-#pragma unroll
-        for (int cb = 0; cb < NCB; cb++) acc_zero(oacc[cb]);
-#pragma unroll 2
-        for (int jc = 0; jc < NJC; jc++) {
+        // the first hidden chunk is peeled: its fc2 products take C = 0 from the instruction (no zero fill of the 16 NCB accumulators)
+        auto chunk = [&](int jc, auto first) __attribute__((always_inline)) {
+            constexpr bool FIRST = decltype(first)::value;
             f32x16 h;
             acc_load_rows(h, kst + S::K_B1 + 32 * jc, half);           // fc1 bias = initial value of the accumulator
 #pragma unroll
@@ -153,9 +155,15 @@ mlpc_fwd_kernel(const T* __restrict__ xmid, T* __restrict__ xout, const float* _
 #pragma unroll
             for (int cb = 0; cb < NCB; cb++)
 #pragma unroll
-                for (int q = 0; q < 2; q++)
-                    mma32(oacc[cb], opm_load_frag<T>(W2_l, C, cb * 32 + li, 4 * jc + 2 * q + half), gf[q]);
-        }
+                for (int q = 0; q < 2; q++) {
+                    const frag_t<T> wf = opm_load_frag<T>(W2_l, C, cb * 32 + li, 4 * jc + 2 * q + half);
+                    if (FIRST && q == 0) mma32_zero(oacc[cb], wf, gf[q]);
+                    else mma32(oacc[cb], wf, gf[q]);
+                }
+        };
+        chunk(0, std::true_type());
+#pragma unroll 2
+        for (int jc = 1; jc < NJC; jc++) chunk(jc, std::false_type());
         // LayerScale + residual (maxvit.py:51-53,269); the raw row pieces are still in registers
 #pragma unroll
         for (int cb = 0; cb < NCB; cb++) {
