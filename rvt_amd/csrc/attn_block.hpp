@@ -194,7 +194,7 @@ __device__ __forceinline__ void ab_partition(AbPart<NB>& pt, const AttnGeom& g, 
 #pragma unroll
     for (int b = 0; b < NB; b++) {
         const int l = 32 * b + li;
-        pt.valid[b] = l < g.L;
+        pt.valid[b] = b < NB - 1 ? true : l < g.L;        // (NB = ceil(L / 32): only the LAST block has rows beyond L - a compile-time `true` drops the selects of the others)
         pt.tok[b] = attn_token(g, (int)f, (int)p, pt.valid[b] ? l : 0);
     }
 }
