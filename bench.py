@@ -361,6 +361,26 @@ def stream_latency(wl, dtype, device, args, with_detector=True):
            'mfma_frac_p50': round(Bs * wl['f_fwd'] / (pct(wall, 0.5) * 1e-3) / (PEAK_TFLOPS[args.dtype] * 1e12), 4),
            'event_tensors_per_s_p50': round(Bs / pct(wall, 0.5) * 1e3, 1),
            'steps_timed': len(lat), 'higher_is_better': False, 'data': 'synthetic'}
+    # the same step replayed as ONE hipGraph (rvt_amd.graph.GraphedStreamStep: static frame / state buffers, state updated inside the graph)
+    try:
+        from rvt_amd.graph import GraphedStreamStep
+        model.eval()
+        gs = GraphedStreamStep(model, frames[0])
+        glat = []
+        for i in range(8):
+            gs(frames[i % 4])
+        torch.cuda.synchronize()
+        for i in range(max(args.steps, 50)):
+            t0 = time.perf_counter()
+            gs(frames[i % 4])
+            torch.cuda.synchronize()
+            glat.append(1e3 * (time.perf_counter() - t0))
+        glat.sort()
+        rec['hipgraph_wall_p50'] = round(pct(glat, 0.5), 3)
+        rec['hipgraph_wall_p99'] = round(pct(glat, 0.99), 3)
+        gs.close()
+    except Exception as e:                                          # (reported, never fatal: the eager numbers above are the record)
+        rec['hipgraph_error'] = f'{type(e).__name__}: {e}'[:200]
     if not with_detector:
         return rec
     # the whole detector step (rows f2 / f3): backbone step + YOLOX PAFPN + head + decode, inference mode, random-init weights
@@ -440,6 +460,9 @@ def also_configs(dtype_name, device, args):
                                  'p50': r['wall_p50'], 'p99': r['wall_p99'], 'gpu_p50': r['gpu_p50'], 'gpu_p99': r['gpu_p99'],
                                  'host_enqueue_p50': r['host_enqueue_p50'], 'unit': 'ms', 'steps': r['steps_timed'],
                                  'mfma_frac_p50': r['mfma_frac_p50'], 'event_tensors_per_s_p50': r['event_tensors_per_s_p50']}
+        for k in ('hipgraph_wall_p50', 'hipgraph_wall_p99', 'hipgraph_error'):        # the same step as ONE hipGraph launch (GraphedStreamStep)
+            if k in r:
+                out['stream_latency'][k.replace('_wall', '')] = r[k]
     except Exception as e:
         out['stream_latency'] = {'error': f'{type(e).__name__}: {e}'[:300]}
     return out

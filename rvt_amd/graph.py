@@ -56,3 +56,57 @@ class GraphedStep:
         self.graph.replay()
         for m in self.models:
             m.invalidate_weight_cache()
+
+
+class GraphedStreamStep:
+    """One streaming-inference step (T = 1, the ConvLSTM state carried from call to call: the validation / deployment loop of
+    modules/detection.py:231-255) as ONE hipGraph launch.  A step is ~50 short launches (20 - 250 us each at B = 64); replayed as a
+    graph the gaps between them shrink.  The input frame and the recurrent state live in static buffers:
+
+        stream = GraphedStreamStep(model, example_frame)       # eager warm-up + capture (the state starts from zeros)
+        feats = stream(frame)                                   # copies `frame` in, replays; feats: {stage: (B, C, H, W)} STATIC tensors
+        stream.reset()  /  stream.reset(mask)                   # new sequences: zero the state (of the samples where mask is set)
+
+    The features returned are the graph's own buffers: valid until the next call (copy what has to outlive it).  The parameters must
+    not change while the graph lives (inference); call close() before training the model again."""
+
+    def __init__(self, model, example_frame: torch.Tensor, warmup: int = 3):
+        assert example_frame.is_cuda and not model.training, 'GraphedStreamStep: an eval-mode model and a CUDA frame (B, C, h, w)'
+        self.model = model
+        self.x = torch.empty_like(example_frame)
+        self.x.copy_(example_frame)
+        with torch.no_grad():
+            st = None
+            for _ in range(max(2, warmup)):                     # eager warm-up: weight pack, workspaces, occupancy caches
+                _, st = model(self.x, st)
+            # static state buffers (same shapes / strides as the states the model hands back)
+            self.states = [tuple(t.clone(memory_format=torch.preserve_format) for t in pair) for pair in st]
+            self.reset()
+            torch.cuda.synchronize(self.x.device)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                feats, new = model(self.x, self.states)
+                for (h, c), (hn, cn) in zip(self.states, new):
+                    h.copy_(hn)
+                    c.copy_(cn)
+            self.feats = feats
+        self.reset()
+
+    def reset(self, mask: Optional[torch.Tensor] = None) -> None:
+        """Zero the recurrent state - of every sample, or of those where the bool mask (B,) is set (modules/utils/detection.py:96-113)."""
+        for h, c in self.states:
+            if mask is None:
+                h.zero_()
+                c.zero_()
+            else:
+                h[mask] = 0
+                c[mask] = 0
+
+    def __call__(self, frame: torch.Tensor):
+        self.x.copy_(frame)
+        self.graph.replay()
+        return self.feats
+
+    def close(self) -> None:
+        self.graph = None
+        self.feats = None

@@ -102,3 +102,36 @@ def test_training_step_graph_matches_eager():
         fe, _ = m_e.forward_sequence(xs, None)
     for s_ in range(1, 5):
         assert torch.equal(fg[s_], fe[s_])
+
+
+def test_streaming_step_graph_matches_eager():
+    """Streaming inference (T = 1, state carried across calls; modules/detection.py:231-255) replayed as one hipGraph
+    (rvt_amd.graph.GraphedStreamStep): features of every step == the eager loop's, bit for bit, incl. a masked state reset."""
+    from rvt_amd import RNNDetector, backbone_config
+    from rvt_amd.graph import GraphedStreamStep
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(0)
+    m = RNNDetector(backbone_config('tiny', 'gen1'), compute_dtype=torch.bfloat16).to(dev).eval()
+    g = torch.Generator(device=dev).manual_seed(1)
+    frames = [torch.randint(0, 11, (3, 20, 240, 304), generator=g, dtype=torch.uint8, device=dev) for _ in range(5)]
+    mask = torch.tensor([False, True, False], device=dev)
+    want = []
+    with torch.no_grad():
+        st = None
+        for i, f in enumerate(frames):
+            if i == 3:                                         # sequence boundary of sample 1: its state restarts from zeros
+                st = [(h.clone(), c.clone()) for h, c in st]
+                for h, c in st:
+                    h[mask] = 0
+                    c[mask] = 0
+            feats, st = m(f, st)
+            want.append({k: v.clone() for k, v in feats.items()})
+    gs = GraphedStreamStep(m, frames[0])
+    for i, f in enumerate(frames):
+        if i == 3:
+            gs.reset(mask)
+        feats = gs(f)
+        torch.cuda.synchronize()
+        for k in want[i]:
+            assert torch.equal(feats[k], want[i][k]), (i, k)
+    gs.close()
