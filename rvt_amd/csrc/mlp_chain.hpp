@@ -445,13 +445,14 @@ mlpc_bwd_wgrad_kernel(const bf16* __restrict__ dxout, const bf16* __restrict__ x
 #pragma unroll
             for (int e = 0; e < 8; e++) x8[e] = h[8 * q + e];
             gelu_both_nlut2_8(lut, x8, g8, p8);
+            float d8[8];
 #pragma unroll
             for (int e = 0; e < 8; e++) {
-                const float d = mul_nopack(dg[8 * q + e], p8[e], e);
-                db1 += d;
-                gf[q][e] = (T)g8[e];
-                dhf[q][e] = (T)d;
+                d8[e] = mul_nopack(dg[8 * q + e], p8[e], e);
+                db1 += d8[e];
             }
+            gf[q] = frag_from_float<T>(g8);             // (converted as whole fragments: pairs per v_cvt_pk_bf16_f32)
+            dhf[q] = frag_from_float<T>(d8);
         }
         if (DGRAD) {                  // dh^T[j][t]: this lane's hidden column is a ROW of the tile; accumulator registers 4 g .. 4 g + 3 are the
                                       // four consecutive tokens 8 g + 4 half ..: four 8-byte stores (the [t][j] form took sixteen 2-byte stores)
